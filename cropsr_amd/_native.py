@@ -1,0 +1,83 @@
+"""ctypes binding of libcropsr_hip.so (C ABI: include/cropsr_hip.h).
+
+The library is the only compute path of this package: if it is missing, or no
+HIP device can be opened, the callers raise -- nothing falls back to the CPU.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcropsr_hip.so")
+
+u8p = ctypes.POINTER(ctypes.c_uint8)
+u32p = ctypes.POINTER(ctypes.c_uint32)
+u64p = ctypes.POINTER(ctypes.c_uint64)
+f64p = ctypes.POINTER(ctypes.c_double)
+voidpp = ctypes.POINTER(ctypes.c_void_p)
+
+# every symbol include/cropsr_hip.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "crp_abi_version": (ctypes.c_int, []),
+    "crp_strerror": (ctypes.c_char_p, [ctypes.c_int]),
+    "crp_init": (ctypes.c_int, [ctypes.c_int, voidpp]),
+    "crp_destroy": (ctypes.c_int, [ctypes.c_void_p]),
+    "crp_last_error": (ctypes.c_char_p, [ctypes.c_void_p]),
+    "crp_device_info": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int,
+                                       ctypes.POINTER(ctypes.c_int), u64p]),
+    "crp_arena_words_for": (ctypes.c_uint64, [ctypes.c_uint64]),
+    "crp_arena_words_total": (ctypes.c_uint64, [ctypes.c_uint64]),
+    "crp_pack_ascii": (ctypes.c_int, [u8p, ctypes.c_uint64, u64p, u64p, u64p, u64p, ctypes.c_int]),
+    "crp_arena_create": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, voidpp]),
+    "crp_arena_destroy": (ctypes.c_int, [ctypes.c_void_p]),
+    "crp_arena_add_contig_ascii": (ctypes.c_int, [ctypes.c_void_p, u8p, ctypes.c_uint64, u64p]),
+    "crp_arena_add_contig_packed": (ctypes.c_int, [ctypes.c_void_p, u64p, u64p, u64p, u64p,
+                                                   ctypes.c_uint64, u64p]),
+    "crp_arena_seal": (ctypes.c_int, [ctypes.c_void_p]),
+    "crp_arena_stats": (ctypes.c_int, [ctypes.c_void_p, u64p, u64p, u64p]),
+    "crp_scan_score": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, u64p, u64p]),
+    "crp_fetch_hits": (ctypes.c_int, [ctypes.c_void_p, u32p, f64p, f64p, u32p, f64p, f64p]),
+    "crp_hits_device": (ctypes.c_int, [ctypes.c_void_p, voidpp, voidpp, voidpp, voidpp]),
+    "crp_score_30mers": (ctypes.c_int, [ctypes.c_void_p, u8p, ctypes.c_uint64, f64p, f64p]),
+    "crp_profile_enable": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    "crp_profile_read": (ctypes.c_int, [ctypes.c_void_p, f64p, u64p, ctypes.c_int]),
+    "crp_synchronize": (ctypes.c_int, [ctypes.c_void_p]),
+}
+
+CRP_OK = 0
+CRP_ERR_NO_DEVICE = -2
+
+_lib = None
+
+
+class CropsrHipError(RuntimeError):
+    def __init__(self, status, what, detail=""):
+        self.status = status
+        msg = "%s failed: %s" % (what, lib().crp_strerror(status).decode())
+        if detail:
+            msg += " [%s]" % detail
+        super().__init__(msg)
+
+
+def lib():
+    """Load the shared library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C cropsr_amd/csrc`).  cropsr_amd has no CPU fallback." % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        if L.crp_abi_version() != 1:
+            raise ImportError("libcropsr_hip.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def check(status, what, ctx=None):
+    if status != CRP_OK:
+        detail = lib().crp_last_error(ctx).decode() if ctx else ""
+        raise CropsrHipError(status, what, detail)

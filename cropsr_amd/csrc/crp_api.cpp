@@ -1,0 +1,524 @@
+// crp_api.cpp -- C ABI of libcropsr_hip.so (see include/cropsr_hip.h).
+//
+// Host side of the MI355X PAM-scan/score engine: owns the HIP stream, the
+// device-resident arena (four bit-planes in HBM), the hit tables and the
+// count -> scan -> emit launch sequence.  No CPU compute path exists here except
+// crp_pack_ascii (host packing, the alternative to the on-GPU pack kernel).
+#include "cropsr_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "crp_kernels.h"
+
+namespace {
+
+constexpr uint64_t kMaxArenaWords = (1ull << 32) / 64 - 2 * crp::ARENA_ALIGN_WORDS;  // positions stay 32-bit
+constexpr uint64_t kUploadChunk = 64ull << 20;  // characters per H2D + pack round (multiple of 4096)
+
+inline uint64_t round_up(uint64_t x, uint64_t m) { return (x + m - 1) / m * m; }
+
+}  // namespace
+
+struct crp_ctx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    std::string last_error;
+    char name[128] = {0};
+    int n_cu = 0;
+    uint64_t hbm = 0;
+    // upload staging (characters) and seam-2 scratch
+    uint8_t *d_text = nullptr;
+    uint64_t d_text_cap = 0;
+    uint8_t *d_rows = nullptr;
+    double *d_rpre = nullptr, *d_rscore = nullptr;
+    uint64_t d_rows_cap = 0;
+    // measurement
+    bool profiling = false;
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    double ms[3] = {0, 0, 0};
+    uint64_t launches[3] = {0, 0, 0};
+};
+
+struct crp_arena {
+    crp_ctx *ctx = nullptr;
+    uint64_t cap_words = 0;     // what the caller asked for
+    uint64_t padded_words = 0;  // allocation per plane
+    uint64_t *d_plane[4] = {nullptr, nullptr, nullptr, nullptr};
+    uint64_t used_words = 1;    // word 0 is the leading separator
+    uint64_t n_contigs = 0, n_chars = 0;
+    bool sealed = false;
+    // per-tile scratch
+    uint2 *d_tile_cnt = nullptr, *d_tile_off = nullptr;
+    uint64_t *d_totals = nullptr;
+    uint64_t *h_totals = nullptr;  // pinned
+    uint32_t n_tiles = 0;
+    // hit tables: [0] = '+', [1] = '-'
+    uint32_t *d_pos[2] = {nullptr, nullptr};
+    double *d_score[2] = {nullptr, nullptr};
+    double *d_pre[2] = {nullptr, nullptr};
+    uint64_t tab_cap[2] = {0, 0};
+    uint64_t pre_cap[2] = {0, 0};
+    uint64_t n_hits[2] = {0, 0};
+    bool have_hits = false, have_pre = false;
+};
+
+#define CRP_HIP(ctx, call)                                                              \
+    do {                                                                                \
+        hipError_t e__ = (call);                                                        \
+        if (e__ != hipSuccess) {                                                        \
+            (ctx)->last_error = std::string(#call) + ": " + hipGetErrorString(e__);     \
+            return e__ == hipErrorOutOfMemory ? CRP_ERR_NOMEM : CRP_ERR_HIP;            \
+        }                                                                               \
+    } while (0)
+
+extern "C" {
+
+int crp_abi_version(void) { return CRP_ABI_VERSION; }
+
+const char *crp_strerror(int status)
+{
+    switch (status) {
+        case CRP_OK: return "ok";
+        case CRP_ERR_INVALID: return "invalid argument";
+        case CRP_ERR_NO_DEVICE: return "no usable HIP device (this library has no CPU fallback)";
+        case CRP_ERR_HIP: return "HIP runtime error";
+        case CRP_ERR_NOMEM: return "out of memory";
+        case CRP_ERR_STATE: return "call out of order";
+        case CRP_ERR_CAPACITY: return "arena capacity exceeded";
+        case CRP_ERR_UNSUPPORTED: return "unsupported parameter";
+        default: return "unknown status";
+    }
+}
+
+int crp_init(int device_id, crp_ctx **out)
+{
+    if (!out || device_id < 0) return CRP_ERR_INVALID;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device_id >= n) return CRP_ERR_NO_DEVICE;
+    if (hipSetDevice(device_id) != hipSuccess) return CRP_ERR_NO_DEVICE;
+    crp_ctx *ctx = new (std::nothrow) crp_ctx();
+    if (!ctx) return CRP_ERR_NOMEM;
+    ctx->device = device_id;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) {
+        std::snprintf(ctx->name, sizeof ctx->name, "%s (%s)", prop.name, prop.gcnArchName);
+        ctx->n_cu = prop.multiProcessorCount;
+        ctx->hbm = prop.totalGlobalMem;
+    }
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return CRP_ERR_HIP;
+    }
+    for (auto &e : ctx->ev)
+        if (hipEventCreate(&e) != hipSuccess) {
+            crp_destroy(ctx);
+            return CRP_ERR_HIP;
+        }
+    *out = ctx;
+    return CRP_OK;
+}
+
+int crp_destroy(crp_ctx *ctx)
+{
+    if (!ctx) return CRP_OK;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (auto &e : ctx->ev)
+        if (e) (void)hipEventDestroy(e);
+    (void)hipFree(ctx->d_text);
+    (void)hipFree(ctx->d_rows);
+    (void)hipFree(ctx->d_rpre);
+    (void)hipFree(ctx->d_rscore);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return CRP_OK;
+}
+
+const char *crp_last_error(const crp_ctx *ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+
+int crp_device_info(const crp_ctx *ctx, char *name, int name_cap, int *n_cu, uint64_t *hbm_bytes)
+{
+    if (!ctx) return CRP_ERR_INVALID;
+    if (name && name_cap > 0) {
+        std::strncpy(name, ctx->name, (size_t)name_cap - 1);
+        name[name_cap - 1] = 0;
+    }
+    if (n_cu) *n_cu = ctx->n_cu;
+    if (hbm_bytes) *hbm_bytes = ctx->hbm;
+    return CRP_OK;
+}
+
+// ---------------------------------------------------------------- host pack
+uint64_t crp_arena_words_for(uint64_t len) { return (len + 63) / 64 + 1; }
+uint64_t crp_arena_words_total(uint64_t sum) { return sum + 1; }
+
+static void pack_range(const uint8_t *text, uint64_t len, uint64_t w0, uint64_t w1, const uint8_t *lut,
+                       uint64_t *hi, uint64_t *lo, uint64_t *up, uint64_t *ac)
+{
+    for (uint64_t w = w0; w < w1; ++w) {
+        uint64_t b[4] = {0, 0, 0, 0};
+        const uint64_t base = w * 64;
+        const uint64_t n = std::min<uint64_t>(64, len - base);
+        for (uint64_t k = 0; k < n; ++k) {
+            const uint64_t nib = lut[text[base + k]];
+            b[0] |= (nib & 1) << k;
+            b[1] |= ((nib >> 1) & 1) << k;
+            b[2] |= ((nib >> 2) & 1) << k;
+            b[3] |= ((nib >> 3) & 1) << k;
+        }
+        if (n < 64) {  // void past the end: hi = lo = 1, up = ac = 0
+            const uint64_t tail = ~0ull << n;
+            b[0] |= tail;
+            b[1] |= tail;
+        }
+        hi[w] = b[0];
+        lo[w] = b[1];
+        up[w] = b[2];
+        ac[w] = b[3];
+    }
+}
+
+int crp_pack_ascii(const uint8_t *text, uint64_t len, uint64_t *hi, uint64_t *lo, uint64_t *up, uint64_t *ac,
+                   int n_threads)
+{
+    if ((len && !text) || !hi || !lo || !up || !ac) return len ? CRP_ERR_INVALID : CRP_OK;
+    uint8_t lut[256];
+    for (int c = 0; c < 256; ++c) lut[c] = crp::host_classify_char((uint32_t)c);
+    const uint64_t n_words = (len + 63) / 64;
+    if (n_threads <= 1 || n_words < 4096) {
+        pack_range(text, len, 0, n_words, lut, hi, lo, up, ac);
+        return CRP_OK;
+    }
+    std::vector<std::thread> pool;
+    const uint64_t per = (n_words + n_threads - 1) / n_threads;
+    for (int t = 0; t < n_threads; ++t) {
+        const uint64_t w0 = std::min<uint64_t>(n_words, per * t), w1 = std::min<uint64_t>(n_words, w0 + per);
+        if (w0 < w1) pool.emplace_back(pack_range, text, len, w0, w1, lut, hi, lo, up, ac);
+    }
+    for (auto &th : pool) th.join();
+    return CRP_OK;
+}
+
+// -------------------------------------------------------------------- arena
+int crp_arena_create(crp_ctx *ctx, uint64_t capacity_words, crp_arena **out)
+{
+    if (!ctx || !out || capacity_words < 1) return CRP_ERR_INVALID;
+    *out = nullptr;
+    if (capacity_words > kMaxArenaWords) return CRP_ERR_CAPACITY;
+    CRP_HIP(ctx, hipSetDevice(ctx->device));
+    crp_arena *a = new (std::nothrow) crp_arena();
+    if (!a) return CRP_ERR_NOMEM;
+    a->ctx = ctx;
+    a->cap_words = capacity_words;
+    a->padded_words = round_up(capacity_words + 1, crp::ARENA_ALIGN_WORDS);
+    const size_t bytes = a->padded_words * sizeof(uint64_t);
+    for (int p = 0; p < 4; ++p) {
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&a->d_plane[p]), bytes);
+        if (e == hipSuccess) e = hipMemsetAsync(a->d_plane[p], p < 2 ? 0xFF : 0x00, bytes, ctx->stream);  // all void
+        if (e != hipSuccess) {
+            ctx->last_error = std::string("arena plane allocation: ") + hipGetErrorString(e);
+            crp_arena_destroy(a);
+            return CRP_ERR_NOMEM;
+        }
+    }
+    *out = a;
+    return CRP_OK;
+}
+
+int crp_arena_destroy(crp_arena *a)
+{
+    if (!a) return CRP_OK;
+    (void)hipSetDevice(a->ctx->device);
+    (void)hipStreamSynchronize(a->ctx->stream);
+    for (int p = 0; p < 4; ++p) (void)hipFree(a->d_plane[p]);
+    (void)hipFree(a->d_tile_cnt);
+    (void)hipFree(a->d_tile_off);
+    (void)hipFree(a->d_totals);
+    if (a->h_totals) (void)hipHostFree(a->h_totals);
+    for (int s = 0; s < 2; ++s) {
+        (void)hipFree(a->d_pos[s]);
+        (void)hipFree(a->d_score[s]);
+        (void)hipFree(a->d_pre[s]);
+    }
+    delete a;
+    return CRP_OK;
+}
+
+static int arena_reserve(crp_arena *a, uint64_t len, uint64_t *first_word)
+{
+    if (a->sealed) return CRP_ERR_STATE;
+    const uint64_t need = crp_arena_words_for(len);
+    if (a->used_words + need > a->cap_words) return CRP_ERR_CAPACITY;
+    *first_word = a->used_words;
+    return CRP_OK;
+}
+
+int crp_arena_add_contig_ascii(crp_arena *a, const uint8_t *text, uint64_t len, uint64_t *arena_offset)
+{
+    if (!a || (len && !text)) return CRP_ERR_INVALID;
+    crp_ctx *ctx = a->ctx;
+    uint64_t w_first = 0;
+    int rc = arena_reserve(a, len, &w_first);
+    if (rc != CRP_OK) return rc;
+    CRP_HIP(ctx, hipSetDevice(ctx->device));
+    const uint64_t n_words = crp_arena_words_for(len);
+    const uint64_t want = std::min<uint64_t>(kUploadChunk, round_up(std::max<uint64_t>(len, 1), 4096));
+    if (ctx->d_text_cap < want) {
+        CRP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        (void)hipFree(ctx->d_text);
+        ctx->d_text = nullptr;
+        ctx->d_text_cap = 0;
+        CRP_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_text), want));
+        ctx->d_text_cap = want;
+    }
+    // Upload and pack in rounds of kUploadChunk characters (word-aligned cuts).
+    uint64_t c0 = 0;
+    do {
+        const uint64_t c1 = std::min<uint64_t>(len, c0 + kUploadChunk);
+        const bool last = c1 == len;
+        const uint64_t w0 = c0 / 64, w1 = last ? n_words : c1 / 64;
+        if (c1 > c0) CRP_HIP(ctx, hipMemcpyAsync(ctx->d_text, text + c0, c1 - c0, hipMemcpyHostToDevice, ctx->stream));
+        CRP_HIP(ctx, crp::launch_pack(ctx->stream, ctx->d_text, c1 - c0, w1 - w0, a->d_plane[0] + w_first + w0,
+                                      a->d_plane[1] + w_first + w0, a->d_plane[2] + w_first + w0,
+                                      a->d_plane[3] + w_first + w0));
+        // the staging buffer is reused by the next round
+        CRP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        c0 = c1;
+    } while (c0 < len);
+    a->used_words += n_words;
+    a->n_contigs += 1;
+    a->n_chars += len;
+    if (arena_offset) *arena_offset = w_first * 64;
+    return CRP_OK;
+}
+
+int crp_arena_add_contig_packed(crp_arena *a, const uint64_t *hi, const uint64_t *lo, const uint64_t *up,
+                                const uint64_t *ac, uint64_t len, uint64_t *arena_offset)
+{
+    if (!a) return CRP_ERR_INVALID;
+    if (len && (!hi || !lo || !up || !ac)) return CRP_ERR_INVALID;
+    crp_ctx *ctx = a->ctx;
+    uint64_t w_first = 0;
+    int rc = arena_reserve(a, len, &w_first);
+    if (rc != CRP_OK) return rc;
+    CRP_HIP(ctx, hipSetDevice(ctx->device));
+    const uint64_t body = (len + 63) / 64;
+    const uint64_t *src[4] = {hi, lo, up, ac};
+    if (body)
+        for (int p = 0; p < 4; ++p)
+            CRP_HIP(ctx, hipMemcpyAsync(a->d_plane[p] + w_first, src[p], body * sizeof(uint64_t),
+                                        hipMemcpyHostToDevice, ctx->stream));
+    CRP_HIP(ctx, hipStreamSynchronize(ctx->stream));  // caller may free its planes on return
+    // the separator word after the body is still void from crp_arena_create
+    a->used_words += crp_arena_words_for(len);
+    a->n_contigs += 1;
+    a->n_chars += len;
+    if (arena_offset) *arena_offset = w_first * 64;
+    return CRP_OK;
+}
+
+int crp_arena_seal(crp_arena *a)
+{
+    if (!a) return CRP_ERR_INVALID;
+    if (a->sealed) return CRP_OK;
+    crp_ctx *ctx = a->ctx;
+    CRP_HIP(ctx, hipSetDevice(ctx->device));
+    const uint64_t eff = round_up(a->used_words, crp::TILE_WORDS);  // <= padded_words
+    a->n_tiles = (uint32_t)(eff / crp::TILE_WORDS);
+    CRP_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&a->d_tile_cnt), a->n_tiles * sizeof(uint2)));
+    CRP_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&a->d_tile_off), a->n_tiles * sizeof(uint2)));
+    CRP_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&a->d_totals), 2 * sizeof(uint64_t)));
+    CRP_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&a->h_totals), 2 * sizeof(uint64_t), hipHostMallocDefault));
+    CRP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    a->sealed = true;
+    return CRP_OK;
+}
+
+int crp_arena_stats(const crp_arena *a, uint64_t *n_contigs, uint64_t *n_chars, uint64_t *n_words)
+{
+    if (!a) return CRP_ERR_INVALID;
+    if (n_contigs) *n_contigs = a->n_contigs;
+    if (n_chars) *n_chars = a->n_chars;
+    if (n_words) *n_words = a->used_words;
+    return CRP_OK;
+}
+
+// --------------------------------------------------------------- scan+score
+static int grow(crp_ctx *ctx, void **p, uint64_t *cap, uint64_t need, size_t elem)
+{
+    if (*cap >= need && *p) return CRP_OK;
+    (void)hipFree(*p);
+    *p = nullptr;
+    *cap = 0;
+    const uint64_t n = std::max<uint64_t>(need + need / 16, 64);
+    CRP_HIP(ctx, hipMalloc(p, n * elem));
+    *cap = n;
+    return CRP_OK;
+}
+
+static void prof_begin(crp_ctx *ctx, int k)
+{
+    if (ctx->profiling) (void)hipEventRecord(ctx->ev[2 * k], ctx->stream);
+}
+static void prof_end(crp_ctx *ctx, int k)
+{
+    if (ctx->profiling) (void)hipEventRecord(ctx->ev[2 * k + 1], ctx->stream);
+}
+
+int crp_scan_score(crp_arena *a, int guide_len, int want_pre, uint64_t *n_plus, uint64_t *n_minus)
+{
+    if (!a) return CRP_ERR_INVALID;
+    if (!a->sealed) return CRP_ERR_STATE;
+    if (guide_len < 1 || guide_len > 50) return CRP_ERR_UNSUPPORTED;
+    crp_ctx *ctx = a->ctx;
+    CRP_HIP(ctx, hipSetDevice(ctx->device));
+    a->have_hits = false;
+    const uint64_t eff_words = (uint64_t)a->n_tiles * crp::TILE_WORDS;
+    crp::Planes pl{{a->d_plane[0], a->d_plane[1], a->d_plane[2], a->d_plane[3]}};
+
+    prof_begin(ctx, 0);
+    CRP_HIP(ctx, crp::launch_count(ctx->stream, pl, eff_words, guide_len, a->d_tile_cnt));
+    prof_end(ctx, 0);
+    prof_begin(ctx, 1);
+    CRP_HIP(ctx, crp::launch_tile_scan(ctx->stream, a->d_tile_cnt, a->n_tiles, a->d_tile_off, a->d_totals));
+    prof_end(ctx, 1);
+    CRP_HIP(ctx, hipMemcpyAsync(a->h_totals, a->d_totals, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    CRP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const uint64_t n[2] = {a->h_totals[0], a->h_totals[1]};
+
+    for (int s = 0; s < 2; ++s) {
+        uint64_t cap_pos = a->tab_cap[s], cap_score = a->tab_cap[s];
+        int rc = grow(ctx, reinterpret_cast<void **>(&a->d_pos[s]), &cap_pos, n[s], sizeof(uint32_t));
+        if (rc == CRP_OK) rc = grow(ctx, reinterpret_cast<void **>(&a->d_score[s]), &cap_score, n[s], sizeof(double));
+        if (rc != CRP_OK) { a->tab_cap[s] = 0; return rc; }
+        a->tab_cap[s] = std::min(cap_pos, cap_score);
+        if (want_pre) {
+            rc = grow(ctx, reinterpret_cast<void **>(&a->d_pre[s]), &a->pre_cap[s], n[s], sizeof(double));
+            if (rc != CRP_OK) return rc;
+        }
+    }
+    crp::HitTables out{a->d_pos[0], a->d_score[0], want_pre ? a->d_pre[0] : nullptr,
+                       a->d_pos[1], a->d_score[1], want_pre ? a->d_pre[1] : nullptr};
+    prof_begin(ctx, 2);
+    CRP_HIP(ctx, crp::launch_emit(ctx->stream, pl, eff_words, guide_len, a->d_tile_off, out));
+    prof_end(ctx, 2);
+    CRP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->profiling) {
+        for (int k = 0; k < 3; ++k) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, ctx->ev[2 * k], ctx->ev[2 * k + 1]) == hipSuccess) {
+                ctx->ms[k] += ms;
+                ctx->launches[k] += 1;
+            }
+        }
+    }
+    a->n_hits[0] = n[0];
+    a->n_hits[1] = n[1];
+    a->have_hits = true;
+    a->have_pre = want_pre != 0;
+    if (n_plus) *n_plus = n[0];
+    if (n_minus) *n_minus = n[1];
+    return CRP_OK;
+}
+
+int crp_fetch_hits(crp_arena *a, uint32_t *pos_plus, double *pre_plus, double *score_plus, uint32_t *pos_minus,
+                   double *pre_minus, double *score_minus)
+{
+    if (!a) return CRP_ERR_INVALID;
+    if (!a->have_hits) return CRP_ERR_STATE;
+    if ((pre_plus || pre_minus) && !a->have_pre) return CRP_ERR_STATE;
+    crp_ctx *ctx = a->ctx;
+    CRP_HIP(ctx, hipSetDevice(ctx->device));
+    uint32_t *hp[2] = {pos_plus, pos_minus};
+    double *hs[2] = {score_plus, score_minus};
+    double *hr[2] = {pre_plus, pre_minus};
+    for (int s = 0; s < 2; ++s) {
+        const uint64_t n = a->n_hits[s];
+        if (!n) continue;
+        if (hp[s]) CRP_HIP(ctx, hipMemcpyAsync(hp[s], a->d_pos[s], n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        if (hs[s]) CRP_HIP(ctx, hipMemcpyAsync(hs[s], a->d_score[s], n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        if (hr[s]) CRP_HIP(ctx, hipMemcpyAsync(hr[s], a->d_pre[s], n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    CRP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CRP_OK;
+}
+
+int crp_hits_device(crp_arena *a, void **pos_plus, void **score_plus, void **pos_minus, void **score_minus)
+{
+    if (!a) return CRP_ERR_INVALID;
+    if (!a->have_hits) return CRP_ERR_STATE;
+    if (pos_plus) *pos_plus = a->d_pos[0];
+    if (score_plus) *score_plus = a->d_score[0];
+    if (pos_minus) *pos_minus = a->d_pos[1];
+    if (score_minus) *score_minus = a->d_score[1];
+    return CRP_OK;
+}
+
+// ------------------------------------------------------------------- seam 2
+int crp_score_30mers(crp_ctx *ctx, const uint8_t *rows, uint64_t n, double *pre, double *score)
+{
+    if (!ctx || (n && (!rows || !score))) return CRP_ERR_INVALID;
+    if (n == 0) return CRP_OK;
+    CRP_HIP(ctx, hipSetDevice(ctx->device));
+    if (ctx->d_rows_cap < n) {
+        CRP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        (void)hipFree(ctx->d_rows);
+        (void)hipFree(ctx->d_rpre);
+        (void)hipFree(ctx->d_rscore);
+        ctx->d_rows = nullptr;
+        ctx->d_rpre = ctx->d_rscore = nullptr;
+        ctx->d_rows_cap = 0;
+        const uint64_t cap = n + n / 8 + 64;
+        CRP_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_rows), cap * 30));
+        CRP_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_rpre), cap * sizeof(double)));
+        CRP_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_rscore), cap * sizeof(double)));
+        ctx->d_rows_cap = cap;
+    }
+    CRP_HIP(ctx, hipMemcpyAsync(ctx->d_rows, rows, n * 30, hipMemcpyHostToDevice, ctx->stream));
+    CRP_HIP(ctx, crp::launch_score30(ctx->stream, ctx->d_rows, n, ctx->d_rpre, ctx->d_rscore));
+    if (pre) CRP_HIP(ctx, hipMemcpyAsync(pre, ctx->d_rpre, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    CRP_HIP(ctx, hipMemcpyAsync(score, ctx->d_rscore, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    CRP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CRP_OK;
+}
+
+// -------------------------------------------------------------- measurement
+int crp_profile_enable(crp_ctx *ctx, int on)
+{
+    if (!ctx) return CRP_ERR_INVALID;
+    ctx->profiling = on != 0;
+    return CRP_OK;
+}
+
+int crp_profile_read(crp_ctx *ctx, double ms[3], uint64_t launches[3], int reset)
+{
+    if (!ctx) return CRP_ERR_INVALID;
+    for (int k = 0; k < 3; ++k) {
+        if (ms) ms[k] = ctx->ms[k];
+        if (launches) launches[k] = ctx->launches[k];
+        if (reset) {
+            ctx->ms[k] = 0;
+            ctx->launches[k] = 0;
+        }
+    }
+    return CRP_OK;
+}
+
+int crp_synchronize(crp_ctx *ctx)
+{
+    if (!ctx) return CRP_ERR_INVALID;
+    CRP_HIP(ctx, hipSetDevice(ctx->device));
+    CRP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CRP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,36 @@
+// crp_kernels.h -- host-visible launch interface of crp_kernels.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace crp {
+
+constexpr int BLOCK = 256;     // threads per workgroup (4 wavefronts of 64)
+constexpr int TILE_WPT = 1;    // 64-position words per thread in the count/emit passes
+constexpr int TILE_WORDS = BLOCK * TILE_WPT;
+constexpr int ARENA_ALIGN_WORDS = 1024;  // arena planes are padded to this many words
+
+struct Planes {
+    const uint64_t *plane[4];  // hi, lo, up, ac
+};
+
+struct HitTables {
+    uint32_t *pos_plus;
+    double *score_plus;
+    double *pre_plus;   // may be null
+    uint32_t *pos_minus;
+    double *score_minus;
+    double *pre_minus;  // may be null
+};
+
+hipError_t launch_count(hipStream_t s, const Planes &pl, uint64_t n_words_padded, int l, uint2 *tile_cnt);
+hipError_t launch_tile_scan(hipStream_t s, const uint2 *tile_cnt, uint32_t n_tiles, uint2 *tile_off,
+                            uint64_t *totals);
+hipError_t launch_emit(hipStream_t s, const Planes &pl, uint64_t n_words_padded, int l, const uint2 *tile_off,
+                       const HitTables &out);
+hipError_t launch_score30(hipStream_t s, const uint8_t *rows, uint64_t n, double *pre, double *score);
+hipError_t launch_pack(hipStream_t s, const uint8_t *text, uint64_t len, uint64_t n_words, uint64_t *hi,
+                       uint64_t *lo, uint64_t *up, uint64_t *ac);
+uint8_t host_classify_char(uint32_t ch);
+
+}  // namespace crp

@@ -1,0 +1,478 @@
+// crp_kernels.hip -- gfx950 kernels of the PAM-scan + on-target-score path.
+//
+// Replaces, for a whole arena of contigs in one pass, the reference's per-contig
+// hot loops:
+//   CROPSR.py:415-416, :426-427   re.finditer('(?=.GG)') / ('(?=CC.)')
+//   CROPSR.py:417-423, :428-434   window arithmetic + keep-filter
+//   CROPSR.py:458-461, :285-313   scoring-string build + rs1_score
+//
+// Device representation (DESIGN.md "Data layout"): four bit-planes, 64 characters
+// per 64-bit word, bit k of word w = arena position 64*w + k.
+//   hi, lo : base code A=00 T=01 C=10 G=11      up : upper-case base
+//   ac     : scoring base (acgtACGT, U == A)
+//   void   : hi & lo & ~up & ~ac  -- positions outside every contig string
+//   'Z'    : hi & ~lo & up & ~ac  -- scores as C but never matches the PAM regex
+// Contigs are separated by >= 64 void positions, so every reference bounds test
+// (i-l >= 5, j+3 >= 5, j+3+l <= len+10, j+2 < len, complete 30-window) becomes a
+// test of a void bit at a fixed distance, and no kernel needs a contig table.
+//
+// Work decomposition: one 256-thread workgroup per tile of 256*WPT words.  PAM
+// masks are 64-wide bit-parallel per lane; kept hits are ranked with popcounts and
+// a block scan, compacted to an LDS list, and then scored one hit per lane so the
+// f64 work is balanced and the table stores are coalesced.  Output order is
+// ascending arena position per strand (two-pass count / scan / emit, no atomics):
+// bitwise reproducible and identical to the reference's row order.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "crp_kernels.h"
+#include "crp_score.h"
+
+namespace crp {
+
+static constexpr uint64_t ALL = ~0ull;
+
+// ------------------------------------------------------------------ helpers
+// bit k of result = bit (k + d) of the stream (cur, next), 0 < d < 64
+__device__ __forceinline__ uint64_t ahead(uint64_t cur, uint64_t next, int d)
+{
+    return (cur >> d) | (next << (64 - d));
+}
+// bit k of result = bit (k - e) of the stream (prev, cur), 0 < e < 64
+__device__ __forceinline__ uint64_t behind(uint64_t prev, uint64_t cur, int e)
+{
+    return (cur << e) | (prev >> (64 - e));
+}
+
+struct WordTriple {
+    uint64_t p, c, n;
+};
+
+// Kept-hit masks of one 64-position word.
+//   plus : (?=.GG) at i  <=>  G(i+1) & G(i+2);  keep  i - l >= 5   (CROPSR.py:419)
+//   minus: (?=CC.) at j  <=>  C(j) & C(j+1) & exists(j+2);
+//          keep  j+3 >= 5  and  j+3+l <= len+10               (CROPSR.py:430)
+// "exists"/"index >= 0"/"index < len" are void tests at fixed distances.
+__device__ __forceinline__ void word_masks(const WordTriple &hi, const WordTriple &lo,
+                                           const WordTriple &up, const WordTriple &ac, int l,
+                                           uint64_t &mplus, uint64_t &mminus)
+{
+    const uint64_t g_c = hi.c & lo.c & up.c & ac.c, g_n = hi.n & lo.n & up.n & ac.n;
+    const uint64_t c_c = hi.c & ~lo.c & up.c & ac.c, c_n = hi.n & ~lo.n & up.n & ac.n;
+    const uint64_t v_p = hi.p & lo.p & ~up.p & ~ac.p;
+    const uint64_t v_c = hi.c & lo.c & ~up.c & ~ac.c;
+    const uint64_t v_n = hi.n & lo.n & ~up.n & ~ac.n;
+
+    mplus = ahead(g_c, g_n, 1) & ahead(g_c, g_n, 2) & ~behind(v_p, v_c, l + 5);
+
+    uint64_t m = c_c & ahead(c_c, c_n, 1) & ~ahead(v_c, v_n, 2) & ~behind(v_p, v_c, 2);
+    if (l > 8) m &= ~ahead(v_c, v_n, l - 8);
+    mminus = m;
+}
+
+// Stage TW words (+ one halo word each side) of the four planes into LDS.
+// sh[p][0] = word t0-1, sh[p][1+k] = word t0+k, sh[p][TW+1] = word t0+TW.
+// The arena allocation is padded to a multiple of the tile, so the body is
+// always in range; halos beyond the arena read as void.
+template <int TW>
+__device__ __forceinline__ void stage_tile(const Planes &pl, uint64_t t0, uint64_t n_words_padded,
+                                           uint64_t (*sh)[TW + 2])
+{
+    const int tid = threadIdx.x;
+    constexpr int PAIRS = TW / 2;  // 16-byte units per plane
+#pragma unroll
+    for (int it = 0; it < (4 * PAIRS) / BLOCK; ++it) {
+        const int q = tid + it * BLOCK;
+        const int p = q / PAIRS, k = q % PAIRS;
+        const uint64_t *src = pl.plane[p] + t0 + 2 * k;
+        const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(src);
+        sh[p][1 + 2 * k] = v.x;
+        sh[p][2 + 2 * k] = v.y;
+    }
+    if (tid < 8) {
+        const int p = tid >> 1;
+        const bool right = tid & 1;
+        const uint64_t voidw = (p < 2) ? ALL : 0ull;
+        uint64_t w;
+        if (right) {
+            const uint64_t idx = t0 + TW;
+            w = idx < n_words_padded ? pl.plane[p][idx] : voidw;
+            sh[p][TW + 1] = w;
+        } else {
+            w = t0 > 0 ? pl.plane[p][t0 - 1] : voidw;
+            sh[p][0] = w;
+        }
+    }
+}
+
+// 64-bit inclusive scan across the wave.
+__device__ __forceinline__ uint64_t wave_inclusive_scan(uint64_t v)
+{
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint64_t o = __shfl_up(v, d, 64);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+
+// Block-wide exclusive scan of a packed (plus | minus << 32) count.
+// `wave_tot` is LDS scratch of BLOCK/64 entries.  Returns the exclusive prefix,
+// sets `total` to the block total.
+__device__ __forceinline__ uint64_t block_exclusive_scan(uint64_t v, uint64_t *wave_tot, uint64_t &total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t inc = wave_inclusive_scan(v);
+    if (lane == 63) wave_tot[wave] = inc;
+    __syncthreads();
+    uint64_t base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < BLOCK / 64; ++w) {
+        const uint64_t t = wave_tot[w];
+        if (w < wave) base += t;
+        tot += t;
+    }
+    total = tot;
+    return base + inc - v;
+}
+
+template <int WPT, int TW>
+__device__ __forceinline__ void thread_masks(uint64_t (*sh)[TW + 2], int l, uint64_t (&mp)[WPT],
+                                             uint64_t (&mm)[WPT])
+{
+    const int w0 = threadIdx.x * WPT;  // tile-local first word of this thread
+#pragma unroll
+    for (int k = 0; k < WPT; ++k) {
+        const int s = 1 + w0 + k;
+        WordTriple t[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) t[p] = WordTriple{sh[p][s - 1], sh[p][s], sh[p][s + 1]};
+        word_masks(t[0], t[1], t[2], t[3], l, mp[k], mm[k]);
+    }
+}
+
+// -------------------------------------------------------------- pass 1: count
+template <int WPT>
+__global__ __launch_bounds__(BLOCK) void count_kernel(Planes pl, uint64_t n_words_padded, int l,
+                                                       uint2 *__restrict__ tile_cnt)
+{
+    constexpr int TW = BLOCK * WPT;
+    __shared__ uint64_t sh[4][TW + 2];
+    __shared__ uint64_t wave_tot[BLOCK / 64];
+    const uint64_t t0 = (uint64_t)blockIdx.x * TW;
+    stage_tile<TW>(pl, t0, n_words_padded, sh);
+    __syncthreads();
+    uint64_t mp[WPT], mm[WPT];
+    thread_masks<WPT, TW>(sh, l, mp, mm);
+    uint64_t c = 0;
+#pragma unroll
+    for (int k = 0; k < WPT; ++k) c += (uint64_t)__popcll(mp[k]) | ((uint64_t)__popcll(mm[k]) << 32);
+    // wave reduce, then one LDS round
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d, 64);
+    if ((threadIdx.x & 63) == 0) wave_tot[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t t = 0;
+#pragma unroll
+        for (int w = 0; w < BLOCK / 64; ++w) t += wave_tot[w];
+        tile_cnt[blockIdx.x] = make_uint2((uint32_t)t, (uint32_t)(t >> 32));
+    }
+}
+
+// ------------------------------------------------- pass 2: tile offset scan
+// One workgroup; exclusive scan of the per-tile counts, totals as 64-bit.
+__global__ __launch_bounds__(1024) void tile_scan_kernel(const uint2 *__restrict__ tile_cnt, uint32_t n_tiles,
+                                                          uint2 *__restrict__ tile_off,
+                                                          uint64_t *__restrict__ totals)
+{
+    __shared__ uint64_t wave_tot[16];
+    __shared__ uint64_t carry_s;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n_tiles; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        uint64_t v = 0;
+        if (i < n_tiles) {
+            const uint2 c = tile_cnt[i];
+            v = (uint64_t)c.x | ((uint64_t)c.y << 32);
+        }
+        const uint64_t inc = wave_inclusive_scan(v);
+        if (lane == 63) wave_tot[wave] = inc;
+        __syncthreads();
+        uint64_t pre = carry_s, tot = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            const uint64_t t = wave_tot[w];
+            if (w < wave) pre += t;
+            tot += t;
+        }
+        const uint64_t ex = pre + inc - v;
+        if (i < n_tiles) tile_off[i] = make_uint2((uint32_t)ex, (uint32_t)(ex >> 32));
+        __syncthreads();
+        // Per-strand totals stay below 2^32 (arena positions are 32-bit), so the
+        // packed halves never carry into each other.
+        if (threadIdx.x == 0) carry_s += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        totals[0] = carry_s & 0xffffffffull;
+        totals[1] = carry_s >> 32;
+    }
+}
+
+// ------------------------------------------------------- pass 3: emit + score
+// 30 bits of an LDS plane starting at bit position q (q counted from bit 0 of
+// the left halo word).
+__device__ __forceinline__ uint32_t window30(const uint64_t *plane, uint32_t q)
+{
+    const uint32_t *p32 = reinterpret_cast<const uint32_t *>(plane);
+    const uint32_t i = q >> 5;
+    return __builtin_amdgcn_alignbit(p32[i + 1], p32[i], q & 31) & 0x3fffffffu;
+}
+
+__device__ __forceinline__ uint32_t reverse30(uint32_t x) { return __brev(x) >> 2; }
+
+template <int WPT>
+__global__ __launch_bounds__(BLOCK) void emit_kernel(Planes pl, uint64_t n_words_padded, int l,
+                                                      const uint2 *__restrict__ tile_off, HitTables out)
+{
+    constexpr int TW = BLOCK * WPT;
+    constexpr int CAP = 2048 * WPT;  // list entries per round; typical tiles need one round
+    __shared__ uint64_t sh[4][TW + 2];
+    __shared__ uint64_t exp_tab[256];
+    __shared__ uint64_t wave_tot[BLOCK / 64];
+    __shared__ uint16_t list[CAP];
+
+    const int tid = threadIdx.x;
+    const uint64_t t0 = (uint64_t)blockIdx.x * TW;
+    stage_tile<TW>(pl, t0, n_words_padded, sh);
+    exp_tab[tid] = CRP_EXP_TAB[tid];
+    __syncthreads();
+
+    uint64_t mp[WPT], mm[WPT];
+    thread_masks<WPT, TW>(sh, l, mp, mm);
+    uint64_t c = 0;
+#pragma unroll
+    for (int k = 0; k < WPT; ++k) c += (uint64_t)__popcll(mp[k]) | ((uint64_t)__popcll(mm[k]) << 32);
+    uint64_t total;
+    const uint64_t ex = block_exclusive_scan(c, wave_tot, total);
+    const uint32_t n_plus = (uint32_t)total, n_minus = (uint32_t)(total >> 32);
+    const uint32_t n_all = n_plus + n_minus;
+    if (n_all == 0) return;
+    const uint2 off = tile_off[blockIdx.x];
+    const uint32_t tile_pos = (uint32_t)(t0 * 64);
+
+    for (uint32_t lo_rank = 0; lo_rank < n_all; lo_rank += CAP) {
+        if (lo_rank) __syncthreads();  // previous round's readers are done
+        // ---- compact: rank -> tile-local position, '+' hits first, then '-'
+        {
+            uint32_t rp = (uint32_t)ex - lo_rank;                    // rank of next '+' hit, window-relative
+            uint32_t rm = n_plus + (uint32_t)(ex >> 32) - lo_rank;  // same for '-'
+#pragma unroll
+            for (int k = 0; k < WPT; ++k) {
+                const uint32_t wbase = (uint32_t)(tid * WPT + k) * 64u;
+                uint64_t m = mp[k];
+                while (m) {
+                    const int b = __builtin_ctzll(m);
+                    m &= m - 1;
+                    if (rp < (uint32_t)CAP) list[rp] = (uint16_t)(wbase + b);
+                    ++rp;
+                }
+                m = mm[k];
+                while (m) {
+                    const int b = __builtin_ctzll(m);
+                    m &= m - 1;
+                    if (rm < (uint32_t)CAP) list[rm] = (uint16_t)(wbase + b);
+                    ++rm;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- one hit per lane: extract the 30-window, score, store
+        const uint32_t n_round = min((uint32_t)CAP, n_all - lo_rank);
+        for (uint32_t k = tid; k < n_round; k += BLOCK) {
+            const uint32_t r = lo_rank + k;
+            const uint32_t e = list[k];
+            const bool minus = r >= n_plus;
+            // '+': long window = s[i-25 : i+5]   (CROPSR.py:421 with l = 20)
+            // '-': long window = s[j-2  : j+28]  (CROPSR.py:432)
+            const uint32_t q = 64u + e - (minus ? 2u : 25u);
+            double pre = -1.0, score = -1.0;
+            if (l == 20) {
+                uint32_t h = window30(sh[0], q), w = window30(sh[1], q);
+                const uint32_t u = window30(sh[2], q), a = window30(sh[3], q);
+                const bool complete = (h & w & ~u & ~a) == 0;  // no void position inside
+                uint32_t valid = a | u;                         // acgtACGT, U, Z
+                if (!minus) {
+                    // get_gRNA_sequence (CROPSR.py:128): complement upper-case
+                    // bases only, then reverse.  Complement = flip the low code bit.
+                    h = reverse30(h);
+                    w = reverse30(w ^ u);
+                    valid = reverse30(valid);
+                }
+                if (complete) {
+                    const uint32_t mG = h & w & valid, mC = h & ~w & valid;
+                    const uint32_t mT = ~h & w & valid, mA = ~h & ~w & valid;
+                    crp_score_masks(mA, mT, mC, mG, exp_tab, pre, score);
+                }
+            }
+            const uint32_t pos = tile_pos + e;
+            if (minus) {
+                const uint64_t o = (uint64_t)off.y + (r - n_plus);
+                out.pos_minus[o] = pos;
+                out.score_minus[o] = score;
+                if (out.pre_minus) out.pre_minus[o] = pre;
+            } else {
+                const uint64_t o = (uint64_t)off.x + r;
+                out.pos_plus[o] = pos;
+                out.score_plus[o] = score;
+                if (out.pre_plus) out.pre_plus[o] = pre;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------ seam 2 kernel
+// rs1_score on rows of 30 raw bytes: compare with 'A','T','C','G' exactly as
+// CROPSR.py:300-309 does; no case folding here (the caller did it, :458).
+__global__ __launch_bounds__(BLOCK) void score30_kernel(const uint8_t *__restrict__ rows, uint64_t n,
+                                                         double *__restrict__ pre_out,
+                                                         double *__restrict__ score_out)
+{
+    __shared__ uint64_t exp_tab[256];
+    exp_tab[threadIdx.x] = CRP_EXP_TAB[threadIdx.x];
+    __syncthreads();
+    for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * BLOCK) {
+        const uint8_t *r = rows + 30 * i;
+        uint32_t mA = 0, mT = 0, mC = 0, mG = 0;
+#pragma unroll
+        for (int p = 0; p < 30; ++p) {
+            const uint32_t ch = r[p];
+            mA |= (uint32_t)(ch == 'A') << p;
+            mT |= (uint32_t)(ch == 'T') << p;
+            mC |= (uint32_t)(ch == 'C') << p;
+            mG |= (uint32_t)(ch == 'G') << p;
+        }
+        double pre, score;
+        crp_score_masks(mA, mT, mC, mG, exp_tab, pre, score);
+        if (pre_out) pre_out[i] = pre;
+        score_out[i] = score;
+    }
+}
+
+// -------------------------------------------------------------- pack kernel
+// Characters -> bit-planes with wavefront ballots: 64 lanes classify 64
+// characters, four __ballot()s ARE the four plane words.
+__host__ __device__ inline uint8_t classify_char(uint32_t ch)
+{
+    // bit0 = hi, bit1 = lo, bit2 = up, bit3 = ac
+    switch (ch) {
+        case 'A': case 'U': return 0xC;       // 'U' behaves as 'A': both str.replace chains
+        case 'T': return 0xE;                 //   (CROPSR.py:120,128) start with A -> U
+        case 'C': return 0xD;
+        case 'G': return 0xF;
+        case 'a': return 0x8;
+        case 't': return 0xA;
+        case 'c': return 0x9;
+        case 'g': return 0xB;
+        case 'Z': return 0x5;                 // C -> Z is the chains' second step: scores as C,
+        default:  return 0x0;                 //   but 'Z' is not matched by the PAM regexes
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void pack_kernel(const uint8_t *__restrict__ text, uint64_t len,
+                                                      uint64_t n_words, uint64_t *__restrict__ hi,
+                                                      uint64_t *__restrict__ lo, uint64_t *__restrict__ up,
+                                                      uint64_t *__restrict__ ac)
+{
+    __shared__ uint8_t lut[256];
+    __shared__ __attribute__((aligned(16))) uint8_t buf[BLOCK / 64][4096];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    lut[tid] = classify_char(tid);
+    const uint64_t n_groups = (n_words + 63) / 64;             // 64 words = 4096 characters per wave
+    const uint64_t n_block_iters = (n_groups + BLOCK / 64 - 1) / (BLOCK / 64);
+    for (uint64_t bi = blockIdx.x; bi < n_block_iters; bi += gridDim.x) {
+        const uint64_t group = bi * (BLOCK / 64) + wave;
+        const uint64_t base = group * 4096;
+        __syncthreads();  // lut ready / previous iteration's reads done
+        if (group < n_groups) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const uint64_t off = base + (uint64_t)it * 1024 + (uint64_t)lane * 16;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (off + 16 <= len) {
+                    v = *reinterpret_cast<const uint4 *>(text + off);
+                } else if (off < len) {
+                    uint8_t tmp[16];
+                    for (int b = 0; b < 16; ++b) tmp[b] = off + b < len ? text[off + b] : 0;
+                    v = *reinterpret_cast<const uint4 *>(tmp);
+                }
+                *reinterpret_cast<uint4 *>(&buf[wave][it * 1024 + lane * 16]) = v;
+            }
+        }
+        __syncthreads();
+        if (group < n_groups) {
+            uint64_t w_hi = 0, w_lo = 0, w_up = 0, w_ac = 0;
+            for (int t = 0; t < 64; ++t) {
+                const uint64_t idx = base + (uint64_t)t * 64 + lane;
+                const uint32_t nib = idx < len ? lut[buf[wave][t * 64 + lane]] : 0x3u;  // void past the end
+                const uint64_t b0 = __ballot(nib & 1), b1 = __ballot(nib & 2);
+                const uint64_t b2 = __ballot(nib & 4), b3 = __ballot(nib & 8);
+                if (lane == t) { w_hi = b0; w_lo = b1; w_up = b2; w_ac = b3; }
+            }
+            const uint64_t w = group * 64 + lane;
+            if (w < n_words) { hi[w] = w_hi; lo[w] = w_lo; up[w] = w_up; ac[w] = w_ac; }
+        }
+    }
+}
+
+// ------------------------------------------------------------ launch wrappers
+hipError_t launch_count(hipStream_t s, const Planes &pl, uint64_t n_words_padded, int l, uint2 *tile_cnt)
+{
+    constexpr int TW = BLOCK * TILE_WPT;
+    const uint32_t n_tiles = (uint32_t)(n_words_padded / TW);
+    hipLaunchKernelGGL(count_kernel<TILE_WPT>, dim3(n_tiles), dim3(BLOCK), 0, s, pl, n_words_padded, l, tile_cnt);
+    return hipGetLastError();
+}
+
+hipError_t launch_tile_scan(hipStream_t s, const uint2 *tile_cnt, uint32_t n_tiles, uint2 *tile_off,
+                            uint64_t *totals)
+{
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, s, tile_cnt, n_tiles, tile_off, totals);
+    return hipGetLastError();
+}
+
+hipError_t launch_emit(hipStream_t s, const Planes &pl, uint64_t n_words_padded, int l, const uint2 *tile_off,
+                       const HitTables &out)
+{
+    constexpr int TW = BLOCK * TILE_WPT;
+    const uint32_t n_tiles = (uint32_t)(n_words_padded / TW);
+    hipLaunchKernelGGL(emit_kernel<TILE_WPT>, dim3(n_tiles), dim3(BLOCK), 0, s, pl, n_words_padded, l, tile_off, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_score30(hipStream_t s, const uint8_t *rows, uint64_t n, double *pre, double *score)
+{
+    if (n == 0) return hipSuccess;
+    const uint64_t blocks = (n + BLOCK - 1) / BLOCK;
+    const uint32_t grid = (uint32_t)(blocks < 8192 ? blocks : 8192);
+    hipLaunchKernelGGL(score30_kernel, dim3(grid), dim3(BLOCK), 0, s, rows, n, pre, score);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack(hipStream_t s, const uint8_t *text, uint64_t len, uint64_t n_words, uint64_t *hi,
+                       uint64_t *lo, uint64_t *up, uint64_t *ac)
+{
+    if (n_words == 0) return hipSuccess;
+    const uint64_t iters = ((n_words + 63) / 64 + BLOCK / 64 - 1) / (BLOCK / 64);
+    const uint32_t grid = (uint32_t)(iters < 4096 ? iters : 4096);
+    hipLaunchKernelGGL(pack_kernel, dim3(grid), dim3(BLOCK), 0, s, text, len, n_words, hi, lo, up, ac);
+    return hipGetLastError();
+}
+
+uint8_t host_classify_char(uint32_t ch) { return classify_char(ch); }
+
+}  // namespace crp

@@ -1,0 +1,240 @@
+"""Host-side face of the MI355X scan/score engine.
+
+Mirrors the two seams of the reference that the HIP library replaces:
+
+  seam 1  CROPSR.py:413-434 -- for one contig string, the kept '+' and '-' PAM
+          hits in regex order                        -> Arena.scan_score()
+  seam 2  CROPSR.py:285-313 -- rs1_score(ndarray[n,30] uint8) -> ndarray[n] f64
+                                                     -> Engine.rs1_score()
+
+Everything numeric happens in libcropsr_hip.so on the GPU; this module only moves
+buffers and slices tables.  There is no CPU fallback.
+"""
+import ctypes
+import weakref
+
+import numpy as np
+
+from . import _native as nat
+
+
+def _as_u8(s):
+    if isinstance(s, str):
+        # one byte per character, whatever the character: positions must not shift
+        s = s.encode("ascii", "replace")
+    if isinstance(s, np.ndarray):
+        return np.ascontiguousarray(s, dtype=np.uint8)
+    return np.frombuffer(s, dtype=np.uint8)
+
+
+class Hits:
+    """Hit tables of one Arena.scan_score() call (host copies).
+
+    pos_* are ARENA positions, ascending per strand; `contig(k)` returns the
+    slice that belongs to contig k with positions local to its string, i.e.
+    exactly the regex match indices the reference iterates over:
+      '+': i of (?=.GG): start_pos = i-l, end_pos = i, cutsite = i-3   (CROPSR.py:418,157)
+      '-': j of (?=CC.): start_pos = j+3+l, end_pos = j+3, cutsite = j  (CROPSR.py:429,433)
+    score == -1 marks rows whose 30-character window is incomplete (CROPSR.py:466-468).
+    """
+
+    def __init__(self, offsets, lengths, guide_len, cols):
+        self.offsets = offsets
+        self.lengths = lengths
+        self.guide_len = guide_len
+        self.pos_plus, self.pre_plus, self.score_plus = cols[0:3]
+        self.pos_minus, self.pre_minus, self.score_minus = cols[3:6]
+        ends = offsets + lengths
+        self._cut_plus = (np.searchsorted(self.pos_plus, offsets, "left"),
+                          np.searchsorted(self.pos_plus, ends, "left"))
+        self._cut_minus = (np.searchsorted(self.pos_minus, offsets, "left"),
+                           np.searchsorted(self.pos_minus, ends, "left"))
+
+    @property
+    def n_plus(self):
+        return int(self.pos_plus.size)
+
+    @property
+    def n_minus(self):
+        return int(self.pos_minus.size)
+
+    def contig(self, k):
+        off = int(self.offsets[k])
+        a, b = int(self._cut_plus[0][k]), int(self._cut_plus[1][k])
+        c, d = int(self._cut_minus[0][k]), int(self._cut_minus[1][k])
+        sl = lambda arr, x, y: None if arr is None else arr[x:y]
+        return dict(
+            pos_plus=(self.pos_plus[a:b] - np.uint32(off)), pre_plus=sl(self.pre_plus, a, b),
+            score_plus=self.score_plus[a:b],
+            pos_minus=(self.pos_minus[c:d] - np.uint32(off)), pre_minus=sl(self.pre_minus, c, d),
+            score_minus=self.score_minus[c:d])
+
+
+class Arena:
+    """Device-resident set of contigs (four bit-planes in HBM)."""
+
+    def __init__(self, engine, handle, offsets, lengths):
+        self._engine = engine
+        self._h = handle
+        self.offsets = offsets
+        self.lengths = lengths
+
+    def close(self):
+        if self._h:
+            nat.lib().crp_arena_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def stats(self):
+        a, b, c = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
+        nat.check(nat.lib().crp_arena_stats(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)),
+                  "crp_arena_stats")
+        return dict(n_contigs=a.value, n_chars=b.value, n_words=c.value)
+
+    def scan_score_device(self, guide_len=20, want_pre=False):
+        """Run the kernels; tables stay in HBM.  Returns (n_plus, n_minus)."""
+        npl, nmi = ctypes.c_uint64(), ctypes.c_uint64()
+        nat.check(nat.lib().crp_scan_score(self._h, guide_len, int(bool(want_pre)),
+                                           ctypes.byref(npl), ctypes.byref(nmi)),
+                  "crp_scan_score", self._engine._ctx)
+        return npl.value, nmi.value
+
+    def device_tables(self):
+        """Raw device addresses (pos_plus, score_plus, pos_minus, score_minus)."""
+        p = [ctypes.c_void_p() for _ in range(4)]
+        nat.check(nat.lib().crp_hits_device(self._h, *[ctypes.byref(x) for x in p]), "crp_hits_device")
+        return tuple(x.value for x in p)
+
+    def fetch(self, n_plus, n_minus, want_pre=False):
+        cols = []
+        for n in (n_plus, n_minus):
+            cols.append(np.empty(n, dtype=np.uint32))
+            cols.append(np.empty(n, dtype=np.float64) if want_pre else None)
+            cols.append(np.empty(n, dtype=np.float64))
+        ptr = lambda a, t: None if a is None else a.ctypes.data_as(t)
+        nat.check(nat.lib().crp_fetch_hits(
+            self._h, ptr(cols[0], nat.u32p), ptr(cols[1], nat.f64p), ptr(cols[2], nat.f64p),
+            ptr(cols[3], nat.u32p), ptr(cols[4], nat.f64p), ptr(cols[5], nat.f64p)),
+            "crp_fetch_hits", self._engine._ctx)
+        return cols
+
+    def scan_score(self, guide_len=20, want_pre=True):
+        """Seam 1 + 2 for every contig of the arena -> Hits (host copies)."""
+        n_plus, n_minus = self.scan_score_device(guide_len, want_pre)
+        cols = self.fetch(n_plus, n_minus, want_pre)
+        return Hits(self.offsets, self.lengths, guide_len, cols)
+
+
+class Engine:
+    """One HIP device opened through libcropsr_hip.so."""
+
+    def __init__(self, device=0):
+        self._ctx = None
+        L = nat.lib()
+        h = ctypes.c_void_p()
+        st = L.crp_init(int(device), ctypes.byref(h))
+        if st != nat.CRP_OK:
+            raise nat.CropsrHipError(st, "crp_init(device=%d)" % device)
+        self._ctx = h
+        self._arenas = weakref.WeakSet()
+
+    def close(self):
+        if self._ctx:
+            for a in list(self._arenas):  # arenas hold device memory of this context
+                a.close()
+            nat.lib().crp_destroy(self._ctx)
+            self._ctx = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def device_info(self):
+        name = ctypes.create_string_buffer(128)
+        cu = ctypes.c_int()
+        mem = ctypes.c_uint64()
+        nat.check(nat.lib().crp_device_info(self._ctx, name, 128, ctypes.byref(cu), ctypes.byref(mem)),
+                  "crp_device_info")
+        return dict(name=name.value.decode(), n_cu=cu.value, hbm_bytes=mem.value)
+
+    # ---- arena construction
+    def arena(self, contigs, pack="device", pack_threads=8):
+        """Upload contig strings (bytes / str / uint8 arrays).
+
+        pack="device": characters go over PCIe and a ballot kernel packs them;
+        pack="host":   crp_pack_ascii packs on the host, planes go over PCIe.
+        """
+        L = nat.lib()
+        bufs = [_as_u8(c) for c in contigs]
+        total = sum(int(L.crp_arena_words_for(b.size)) for b in bufs)
+        h = ctypes.c_void_p()
+        nat.check(L.crp_arena_create(self._ctx, L.crp_arena_words_total(total), ctypes.byref(h)),
+                  "crp_arena_create", self._ctx)
+        offsets = np.zeros(len(bufs), dtype=np.uint64)
+        lengths = np.array([b.size for b in bufs], dtype=np.uint64)
+        try:
+            for k, b in enumerate(bufs):
+                off = ctypes.c_uint64()
+                if pack == "device":
+                    st = L.crp_arena_add_contig_ascii(h, b.ctypes.data_as(nat.u8p), b.size, ctypes.byref(off))
+                elif pack == "host":
+                    planes = pack_ascii(b, pack_threads)
+                    st = L.crp_arena_add_contig_packed(h, *[p.ctypes.data_as(nat.u64p) for p in planes],
+                                                       b.size, ctypes.byref(off))
+                else:
+                    raise ValueError("pack must be 'device' or 'host'")
+                nat.check(st, "crp_arena_add_contig", self._ctx)
+                offsets[k] = off.value
+            nat.check(L.crp_arena_seal(h), "crp_arena_seal", self._ctx)
+        except Exception:
+            L.crp_arena_destroy(h)
+            raise
+        a = Arena(self, h, offsets, lengths)
+        self._arenas.add(a)
+        return a
+
+    # ---- seam 2
+    def score_30mers(self, rows):
+        """(pre, score) for an (n,30) uint8 array; see crp_score_30mers."""
+        rows = np.ascontiguousarray(rows, dtype=np.uint8)
+        if rows.ndim != 2 or rows.shape[1] != 30:
+            raise ValueError("expected an (n, 30) uint8 array")
+        n = rows.shape[0]
+        pre = np.empty(n, dtype=np.float64)
+        score = np.empty(n, dtype=np.float64)
+        nat.check(nat.lib().crp_score_30mers(self._ctx, rows.ctypes.data_as(nat.u8p), n,
+                                             pre.ctypes.data_as(nat.f64p), score.ctypes.data_as(nat.f64p)),
+                  "crp_score_30mers", self._ctx)
+        return pre, score
+
+    def rs1_score(self, sequences):
+        """Drop-in for the reference's rs1_score (CROPSR.py:285): same argument,
+        same return value."""
+        return self.score_30mers(sequences)[1]
+
+    # ---- measurement
+    def profile(self, on=True):
+        nat.check(nat.lib().crp_profile_enable(self._ctx, int(on)), "crp_profile_enable")
+
+    def profile_read(self, reset=True):
+        ms = (ctypes.c_double * 3)()
+        n = (ctypes.c_uint64 * 3)()
+        nat.check(nat.lib().crp_profile_read(self._ctx, ms, n, int(reset)), "crp_profile_read")
+        names = ("count", "tile_scan", "emit_score")
+        return {names[k]: dict(ms=ms[k], launches=int(n[k])) for k in range(3)}
+
+
+def pack_ascii(text, n_threads=1):
+    """Host packing (crp_pack_ascii): characters -> (hi, lo, up, ac) uint64 planes."""
+    b = _as_u8(text)
+    n_words = (b.size + 63) // 64
+    planes = [np.empty(n_words, dtype=np.uint64) for _ in range(4)]
+    nat.check(nat.lib().crp_pack_ascii(b.ctypes.data_as(nat.u8p), b.size,
+                                       *[p.ctypes.data_as(nat.u64p) for p in planes], n_threads),
+              "crp_pack_ascii")
+    return planes

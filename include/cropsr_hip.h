@@ -1,0 +1,145 @@
+/*
+ * cropsr_hip.h -- C ABI of libcropsr_hip.so, the MI355X (gfx950) PAM-scan +
+ * on-target-score engine that replaces CROPSR's inner loop.
+ *
+ * The reference (H2muller/CROPSR) is one Python script and has no FFI of its
+ * own; the two seams this library slots into are
+ *
+ *   seam 1  CROPSR.py:413-434  per contig string: regex (?=.GG) / (?=CC.) scan,
+ *           window slicing and keep-filter that append to Complete_dataset
+ *           -> crp_arena_* + crp_scan_score + crp_fetch_hits
+ *   seam 2  CROPSR.py:285-313, called at :461  rs1_score(ndarray[n,30] uint8)
+ *           -> ndarray[n] float64      -> crp_score_30mers
+ *
+ * The binding a CROPSR maintainer would add (ctypes) is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain C types only; every function returns 0 (CRP_OK) or a negative
+ *     crp_status; nothing throws, aborts or prints.
+ *   - the caller owns every host buffer; the library owns every device buffer.
+ *   - one crp_ctx per process and GPU (one process per GPU); calls on one
+ *     handle are serialised by the caller.
+ *   - there is NO CPU fallback: without a usable HIP device crp_init fails.
+ *
+ * Coordinates.  A contig is handed over as the exact character string the
+ * reference scans (CROPSR.py:409 `sequence`, including the decoration left by
+ * cropsr_functions.py:221-229 when the FASTA was re-formatted), one byte per
+ * character.  Hit positions come back as indices into that string:
+ *   '+' table: i = re match index of (?=.GG)   start_pos=i-l end_pos=i cutsite=i-3
+ *   '-' table: j = re match index of (?=CC.)   start_pos=j+3+l end_pos=j+3 cutsite=j
+ * shifted by the contig's arena offset (see crp_arena_add_contig_*).
+ */
+#ifndef CROPSR_HIP_H
+#define CROPSR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CRP_ABI_VERSION 1
+
+typedef enum crp_status {
+    CRP_OK = 0,
+    CRP_ERR_INVALID = -1,     /* bad argument */
+    CRP_ERR_NO_DEVICE = -2,   /* no usable HIP device (never falls back to CPU) */
+    CRP_ERR_HIP = -3,         /* a HIP runtime call failed; see crp_last_error */
+    CRP_ERR_NOMEM = -4,       /* host or device allocation failed */
+    CRP_ERR_STATE = -5,       /* call out of order (e.g. scan before seal) */
+    CRP_ERR_CAPACITY = -6,    /* arena capacity exceeded */
+    CRP_ERR_UNSUPPORTED = -7  /* e.g. guide length outside [1, 50] */
+} crp_status;
+
+typedef struct crp_ctx crp_ctx;
+typedef struct crp_arena crp_arena;
+
+/* ---- library ----------------------------------------------------------- */
+int crp_abi_version(void);
+const char *crp_strerror(int status);
+
+/* ---- context ----------------------------------------------------------- */
+/* Opens HIP device `device_id` (index as seen by this process). */
+int crp_init(int device_id, crp_ctx **out);
+int crp_destroy(crp_ctx *ctx);
+/* Text of the last failing HIP call on this context ("" if none). */
+const char *crp_last_error(const crp_ctx *ctx);
+/* Name / CU count / HBM bytes of the device, for logs and bench output. */
+int crp_device_info(const crp_ctx *ctx, char *name, int name_cap, int *n_cu, uint64_t *hbm_bytes);
+
+/* ---- host-side packing (no GPU needed) --------------------------------- */
+/* Number of 64-base words one contig of `len` characters occupies in an arena
+ * (its bases, padded to a word, plus one separator word). */
+uint64_t crp_arena_words_for(uint64_t len);
+/* Arena words needed for contigs whose crp_arena_words_for() sum is `sum`
+ * (adds the leading and trailing separator words). */
+uint64_t crp_arena_words_total(uint64_t sum);
+/* Classify `len` characters into the four bit-planes the kernels read, 64
+ * characters per word, bit k of word w = character 64*w + k:
+ *   hi,lo  2-bit base code, alphabet order of CROPSR.py:300 (A=00 T=01 C=10 G=11)
+ *   up     upper-case base: complemented on the '+' strand (CROPSR.py:128 only
+ *          maps upper case) and eligible for the PAM (regexes match 'G'/'C' only)
+ *   ac     a scoring base (acgtACGT; 'U' counts as 'A')
+ * Characters past `len` in the last word are encoded as "void" (outside any
+ * contig).  Each plane needs ceil(len/64) words.  n_threads <= 1: serial. */
+int crp_pack_ascii(const uint8_t *text, uint64_t len, uint64_t *hi, uint64_t *lo,
+                   uint64_t *up, uint64_t *ac, int n_threads);
+
+/* ---- arena: the device-resident genome --------------------------------- */
+/* An arena holds any number of contigs as four bit-planes in HBM, separated by
+ * void words, so one kernel launch scans all of them.  capacity_words bounds
+ * the total (use crp_arena_words_total). */
+int crp_arena_create(crp_ctx *ctx, uint64_t capacity_words, crp_arena **out);
+int crp_arena_destroy(crp_arena *arena);
+/* Append one contig given as characters; packing runs on the GPU.  Returns the
+ * arena offset (in characters) of its first character: a hit at arena position
+ * P belongs to the contig with the largest offset <= P, at index P - offset. */
+int crp_arena_add_contig_ascii(crp_arena *arena, const uint8_t *text, uint64_t len,
+                               uint64_t *arena_offset);
+/* Same, from planes packed on the host with crp_pack_ascii. */
+int crp_arena_add_contig_packed(crp_arena *arena, const uint64_t *hi, const uint64_t *lo,
+                                const uint64_t *up, const uint64_t *ac, uint64_t len,
+                                uint64_t *arena_offset);
+/* No more contigs; waits for the uploads. */
+int crp_arena_seal(crp_arena *arena);
+/* Totals: contigs, characters, words used. */
+int crp_arena_stats(const crp_arena *arena, uint64_t *n_contigs, uint64_t *n_chars, uint64_t *n_words);
+
+/* ---- seam 1 + 2 over a whole arena -------------------------------------- */
+/* Scan both strands of every contig, keep what CROPSR.py:419/:430 keep for
+ * guide length `guide_len`, score every kept hit whose 30-character window is
+ * complete (guide_len == 20 only; others get -1 like CROPSR.py:466-468), leave
+ * the tables in HBM.  Tables are ascending in arena position per strand, i.e.
+ * per contig in the reference's own order.  want_pre != 0 also keeps the
+ * pre-sigmoid sum (CROPSR.py:312). */
+int crp_scan_score(crp_arena *arena, int guide_len, int want_pre,
+                   uint64_t *n_plus, uint64_t *n_minus);
+/* Copy the tables of the last crp_scan_score to host arrays sized n_plus /
+ * n_minus.  Any pointer may be NULL to skip that column. */
+int crp_fetch_hits(crp_arena *arena, uint32_t *pos_plus, double *pre_plus, double *score_plus,
+                   uint32_t *pos_minus, double *pre_minus, double *score_minus);
+/* Device addresses of the same tables (valid until the next crp_scan_score or
+ * crp_arena_destroy) for a device-to-device gather such as RCCL send/recv. */
+int crp_hits_device(crp_arena *arena, void **pos_plus, void **score_plus,
+                    void **pos_minus, void **score_minus);
+
+/* ---- seam 2 alone -------------------------------------------------------- */
+/* rs1_score (CROPSR.py:285-313) on n rows of 30 bytes, row-major, exactly the
+ * array CROPSR.py:458-461 builds: bytes equal to 'A','T','C','G' select weights,
+ * every other byte selects none.  pre may be NULL. */
+int crp_score_30mers(crp_ctx *ctx, const uint8_t *rows, uint64_t n, double *pre, double *score);
+
+/* ---- measurement --------------------------------------------------------- */
+/* When enabled, every kernel launched by crp_scan_score is bracketed by HIP
+ * events on the library's stream. */
+int crp_profile_enable(crp_ctx *ctx, int on);
+/* Sum of durations (ms) and launch count per kernel since the last reset:
+ * index 0 = count pass, 1 = tile-offset scan, 2 = emit+score pass. */
+int crp_profile_read(crp_ctx *ctx, double ms[3], uint64_t launches[3], int reset);
+/* Blocks until everything queued on the library's stream has finished. */
+int crp_synchronize(crp_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CROPSR_HIP_H */

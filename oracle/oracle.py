@@ -1,0 +1,133 @@
+"""ctypes face of the CPU oracle (oracle/crp_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py.  The product package never imports this module.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+_u8p = ctypes.POINTER(ctypes.c_uint8)
+_u32p = ctypes.POINTER(ctypes.c_uint32)
+_f64p = ctypes.POINTER(ctypes.c_double)
+_i64p = ctypes.POINTER(ctypes.c_int64)
+
+
+def build():
+    """Compile liborc.so in place (gcc only)."""
+    subprocess.run(["make", "-s", "-C", _HERE], check=True)
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "liborc.so")
+        if not os.path.exists(path):
+            build()
+        L = ctypes.CDLL(path)
+        L.orc_exp.restype = ctypes.c_double
+        L.orc_exp.argtypes = [ctypes.c_double]
+        L.orc_exp_many.argtypes = [_f64p, ctypes.c_int64, _f64p]
+        L.orc_score30.argtypes = [_u8p, ctypes.c_int64, _f64p, _f64p]
+        L.orc_scan.argtypes = [_u8p, ctypes.c_int64, ctypes.c_int, _u32p, _i64p, _u32p, _i64p]
+        L.orc_score_hits.argtypes = [_u8p, ctypes.c_int64, ctypes.c_int, _u32p, ctypes.c_int64,
+                                     ctypes.c_int, _f64p, _f64p]
+        L.orc_long_sequence.restype = ctypes.c_int64
+        L.orc_long_sequence.argtypes = [_u8p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_int, _u8p]
+        L.orc_short_sequence.restype = ctypes.c_int64
+        L.orc_short_sequence.argtypes = [_u8p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_int, _u8p]
+        L.orc_weights.argtypes = [_f64p, _f64p, _f64p]
+        _LIB = L
+    return _LIB
+
+
+def _as_u8(s):
+    if isinstance(s, str):
+        s = s.encode("latin-1")
+    a = np.frombuffer(s, dtype=np.uint8) if not isinstance(s, np.ndarray) else s
+    return np.ascontiguousarray(a, dtype=np.uint8)
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t)
+
+
+def exp(x):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    out = np.empty_like(x)
+    lib().orc_exp_many(_p(x, _f64p), x.size, _p(out, _f64p))
+    return out
+
+
+def score30(rows):
+    """Seam 2: rs1_score on an (n,30) uint8 array -> (pre, score)."""
+    rows = np.ascontiguousarray(rows, dtype=np.uint8)
+    assert rows.ndim == 2 and rows.shape[1] == 30
+    n = rows.shape[0]
+    pre = np.empty(n)
+    score = np.empty(n)
+    lib().orc_score30(_p(rows, _u8p), n, _p(pre, _f64p), _p(score, _f64p))
+    return pre, score
+
+
+def scan(s, l=20):
+    """Kept hit positions of one contig string: (plus, minus) uint32 arrays."""
+    a = _as_u8(s)
+    npl = ctypes.c_int64()
+    nmi = ctypes.c_int64()
+    L = lib()
+    L.orc_scan(_p(a, _u8p), a.size, l, None, ctypes.byref(npl), None, ctypes.byref(nmi))
+    plus = np.empty(npl.value, dtype=np.uint32)
+    minus = np.empty(nmi.value, dtype=np.uint32)
+    L.orc_scan(_p(a, _u8p), a.size, l, _p(plus, _u32p), ctypes.byref(npl), _p(minus, _u32p), ctypes.byref(nmi))
+    return plus, minus
+
+
+def score_hits(s, pos, minus, l=20):
+    a = _as_u8(s)
+    pos = np.ascontiguousarray(pos, dtype=np.uint32)
+    pre = np.empty(pos.size)
+    score = np.empty(pos.size)
+    lib().orc_score_hits(_p(a, _u8p), a.size, l, _p(pos, _u32p), pos.size, int(bool(minus)),
+                         _p(pre, _f64p), _p(score, _f64p))
+    return pre, score
+
+
+def scan_score(s, l=20):
+    """Whole seam 1+2 for one contig string.
+
+    Returns dict(pos_plus, pre_plus, score_plus, pos_minus, pre_minus, score_minus);
+    rows with an incomplete 30-window carry pre = score = -1.
+    """
+    a = _as_u8(s)
+    plus, minus = scan(a, l)
+    pp, sp = score_hits(a, plus, False, l)
+    pm, sm = score_hits(a, minus, True, l)
+    return dict(pos_plus=plus, pre_plus=pp, score_plus=sp, pos_minus=minus, pre_minus=pm, score_minus=sm)
+
+
+def long_sequence(s, pos, minus, l=20):
+    a = _as_u8(s)
+    out = np.empty(512, dtype=np.uint8)
+    n = lib().orc_long_sequence(_p(a, _u8p), a.size, int(pos), int(bool(minus)), l, _p(out, _u8p))
+    return out[:n].tobytes().decode("latin-1")
+
+
+def short_sequence(s, pos, minus, l=20):
+    a = _as_u8(s)
+    out = np.empty(512, dtype=np.uint8)
+    n = lib().orc_short_sequence(_p(a, _u8p), a.size, int(pos), int(bool(minus)), l, _p(out, _u8p))
+    return out[:n].tobytes().decode("latin-1")
+
+
+def weights():
+    f = np.empty(120)
+    s = np.empty(464)
+    c = np.empty(2)
+    lib().orc_weights(_p(f, _f64p), _p(s, _f64p), _p(c, _f64p))
+    return f, s, c
