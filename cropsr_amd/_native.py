@@ -37,13 +37,14 @@ SIGNATURES = {
     "crp_scan_score": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, u64p, u64p]),
     "crp_fetch_hits": (ctypes.c_int, [ctypes.c_void_p, u32p, f64p, f64p, u32p, f64p, f64p]),
     "crp_hits_device": (ctypes.c_int, [ctypes.c_void_p, voidpp, voidpp, voidpp, voidpp]),
-    "crp_score_30mers": (ctypes.c_int, [ctypes.c_void_p, u8p, ctypes.c_uint64, f64p, f64p]),
+    "crp_score_30mers": (ctypes.c_int, [ctypes.c_void_p, u8p, ctypes.c_uint64, ctypes.c_int, f64p, f64p]),
     "crp_profile_enable": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "crp_profile_read": (ctypes.c_int, [ctypes.c_void_p, f64p, u64p, ctypes.c_int]),
     "crp_synchronize": (ctypes.c_int, [ctypes.c_void_p]),
 }
 
 CRP_OK = 0
+ORDER_BODY4, ORDER_TAIL2, ORDER_DOT1 = 0, 1, 2
 CRP_ERR_NO_DEVICE = -2
 
 _lib = None

@@ -1,0 +1,206 @@
+"""`python -m cropsr_amd` -- the CROPSR command line on top of the MI355X engine.
+
+Same flags, defaults, stdout lines, time.txt and CSV bytes as the reference's
+CROPSR.py (v1.11b); the PAM scan and the scoring run in libcropsr_hip.so
+instead of re/str.replace/numpy.  Reference anchors are given per step.
+
+Differences that are NOT observable in the outputs:
+  * all contigs are uploaded and scanned in ONE arena pass before the per-contig
+    output loop starts (the reference scans inside the loop, CROPSR.py:413-434);
+  * the 5 s sleep per contig (CROPSR.py:478) is kept only with --reference-sleep.
+"""
+import argparse
+import sys
+import time
+from multiprocessing import cpu_count
+
+from . import fasta, rows
+
+__version__ = "1.11b"  # the CROPSR version whose behaviour is reproduced
+
+BANNER = r"""
+################################################################################
+##                                                                            ##
+##                                                                            ##
+##          .o88b.   d8888b.    .d88b.    d8888b.   .d8888.   d8888b.         ##
+##         d8P  Y8   88  `8D   .8P  Y8.   88  `8D   88'  YP   88  `8D         ##
+##         8P        88oobY'   88    88   88oodD'   `8bo.     88oobY'         ##
+##         8b        88`8b     88    88   88ººº       `Y8b.   88`8b           ##
+##         Y8b  d8   88 `88.   `8b  d8'   88        db   8D   88 `88.         ##
+##          `Y88P'   88   YD    `Y88P'    88        `8888Y'   88   YD         ##
+##                                                                            ##
+##                                                                            ##
+################################################################################
+U.S. Dept. of Energy's Center for Advanced Bioenergy and Bioproducts Innovation
+University of Illinois at Urbana-Champaign
+"""
+
+
+def build_parser():
+    """The reference's flags (CROPSR.py:24-49) plus engine options that default
+    to reference behaviour."""
+    p = argparse.ArgumentParser(prog="CROPSR.py")
+    p.add_argument("-f", "--fasta", metavar="", required=True, dest="f",
+                   help="[required] path to input file in FASTA format")
+    p.add_argument("-g", "--gff", metavar="", dest="g", help="path to input file in GFF format")
+    p.add_argument("-p", "--phytozome", metavar="", dest="p", default=None,
+                   help="path to input annotation info file in TXT format, default = None")
+    p.add_argument("-o", "--output", metavar="", dest="o", default="data.csv",
+                   help="path to output file, default = data.csv")
+    p.add_argument("-l", "--length", metavar="", dest="l", type=int, default=20,
+                   help="length of the gRNA se3quence, default = 20")
+    p.add_argument("-L", "--flanking", metavar="", dest="L", type=int, default=200,
+                   help="length of flanking region for verification, default = 200")
+    p.add_argument("--cas9", action="store_true",
+                   help="specifies that design will be made for the Cas9 CRISPR system")
+    p.add_argument("-v", "--verbose", action="store_true",
+                   help="prints visual indicators for each iteration")
+    eng = p.add_argument_group("MI355X engine")
+    eng.add_argument("--device", type=int, default=0, help="HIP device index, default = 0")
+    eng.add_argument("--seed", type=int, default=None,
+                     help="seed numpy's global RNG so crispr_id is reproducible (reference: unseeded)")
+    eng.add_argument("--reference-sleep", action="store_true",
+                     help="also reproduce the reference's 5 s pause per contig")
+    return p
+
+
+def import_gff_file(gff, verbose):
+    """Side effects of CROPSR.py:77-95.  The table is parsed exactly as the
+    reference parses it and, exactly as there, never used."""
+    import pandas as pd
+    start_index = 0
+    with open(gff, "r") as raw:
+        if verbose:
+            print(f"Annotation file {gff} successfully imported")
+        lines = raw.readlines()
+        for index, line in enumerate(lines):
+            if "##" not in line:
+                start_index = index
+                break
+    cols = ["chromosome", "source", "feature", "start", "end", "score", "strand", "phase", "attributes"]
+    table = pd.read_csv(gff, sep="\t", skiprows=start_index, header=None, names=cols)
+    if verbose:
+        print("Annotation database successfully generated")
+    return table
+
+
+class EngineBackend:
+    """The product's hit provider: libcropsr_hip.so on one MI355X."""
+
+    def __init__(self, device=0):
+        from .engine import Engine
+        self.engine = Engine(device)
+
+    def scan(self, contig_strings, guide_len):
+        """One arena pass on the GPU for all contig strings (seam 1 + 2)."""
+        arena = self.engine.arena(contig_strings)
+        hits = arena.scan_score(guide_len, want_pre=False)
+        out = [hits.contig(k) for k in range(len(contig_strings))]
+        arena.close()
+        return out
+
+    def rescore(self, rows_u8, order):
+        """Seam 2 on a few rows in one of the BLAS tail orders (rows.Dataset.rows)."""
+        return self.engine.score_30mers(rows_u8, order)[1]
+
+    def close(self):
+        self.engine.close()
+
+
+def run(args, backend=None, out=sys.stdout):
+    """main() of the reference (CROPSR.py:333-486) with the hot path swapped out.
+
+    `backend` provides scan(contig_strings, guide_len) -> [hits dict per contig]
+    and rescore(rows_u8, order) -> scores; it defaults to the HIP engine.  The CPU
+    test-suite injects the oracle here to pin this host logic against the golden
+    CSVs without a GPU.
+    """
+    begin = time.time()
+    if not args.cas9:
+        sys.exit("Please select at least one CRISPR system: Cas9")  # CROPSR.py:335-336
+    verbose = args.verbose
+    if verbose:
+        print(BANNER + f"""
+        You are currently utilizing the following settings:
+
+        CROPSR version:                                 {__version__}
+        Path to genome file in FASTA format:            {args.f}
+        Path to output file:                            {args.o}
+        Length of the gRNA sequence:                    {args.l}
+        Length of flanking region for verification:     {args.L}
+        Number of available CPUs:                       {cpu_count()}
+        Path to annotation file in GFF format:          {args.g}
+        Path to annotation_info file in TXT format:     {args.p}
+        Designing for CRISPR system:
+            Streptococcus pyogenes Cas9                 {args.cas9}
+        """, file=out)
+
+    timing = open("time.txt", "w")  # CROPSR.py:371 (CWD side effect, kept)
+
+    # CROPSR.py:374, 54-74
+    with open(args.f, "r") as f:
+        text = f.read()
+    if verbose:
+        print(f"Genome file {args.f} successfully imported", file=out)
+        if fasta.needs_formatting(text):
+            print("formatting genome", file=out)
+            print(f"Genome file {args.f} successfully formatted", file=out)
+    contigs = fasta.contig_table(text)
+    del text
+    if verbose:
+        print("The genome was successfully converted to a dictionary", file=out)
+    import_gff_file(args.g, verbose)  # CROPSR.py:375 (raises like the reference if -g is missing)
+
+    if verbose:
+        print("""
+            Initiating PAM site detection.
+
+            Please wait, this may take a while...
+            """, file=out)
+
+    if getattr(args, "seed", None) is not None:
+        import numpy as np
+        np.random.seed(args.seed)
+
+    rows.write_header(args.o)  # CROPSR.py:402-405
+
+    names = list(contigs.keys())
+    strings = [contigs[k] for k in names]
+    own_backend = backend is None
+    if own_backend:
+        backend = EngineBackend(getattr(args, "device", 0))
+    all_hits = backend.scan(strings, args.l)  # seam 1 + 2 for every contig, one GPU pass
+
+    dataset = rows.Dataset()  # Complete_dataset, CROPSR.py:407
+    for name, s, hits in zip(names, strings, all_hits):
+        print("Searching on Chromosome: ", name[:25], file=out)  # CROPSR.py:410-411
+        print("With start of sequence: ", s[:25], file=out)
+        block = rows.ContigRows(name, s, hits, args.l)
+        dataset.append(block)
+        if verbose:
+            # CROPSR.py:436-439 counts regex matches BEFORE the keep-filter; the
+            # engine reports kept hits, so re-count only for this message.
+            import re
+            n_sites = sum(1 for _ in re.finditer(r"(?=.GG)", s)) + sum(1 for _ in re.finditer(r"(?=CC.)", s))
+            print(f"""
+                {n_sites:n} Cas9 PAM sites were found on {name[1::]}
+                """, file=out)
+        rows.write_pass(args.o, dataset, backend.rescore)  # CROPSR.py:442-474
+        end = time.time()
+        timing.write("Total runtime of the program is " + str(end - begin))  # CROPSR.py:477
+        if getattr(args, "reference_sleep", False):
+            time.sleep(5)  # CROPSR.py:478
+    timing.close()
+    if own_backend:
+        backend.close()
+    if verbose:
+        print(f"The output file has been generated at {args.o}", file=out)
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    run(args)
+
+
+if __name__ == "__main__":
+    main()

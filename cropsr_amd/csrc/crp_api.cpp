@@ -464,9 +464,10 @@ int crp_hits_device(crp_arena *a, void **pos_plus, void **score_plus, void **pos
 }
 
 // ------------------------------------------------------------------- seam 2
-int crp_score_30mers(crp_ctx *ctx, const uint8_t *rows, uint64_t n, double *pre, double *score)
+int crp_score_30mers(crp_ctx *ctx, const uint8_t *rows, uint64_t n, int order, double *pre, double *score)
 {
     if (!ctx || (n && (!rows || !score))) return CRP_ERR_INVALID;
+    if (order < CRP_ORDER_BODY4 || order > CRP_ORDER_DOT1) return CRP_ERR_INVALID;
     if (n == 0) return CRP_OK;
     CRP_HIP(ctx, hipSetDevice(ctx->device));
     if (ctx->d_rows_cap < n) {
@@ -484,7 +485,7 @@ int crp_score_30mers(crp_ctx *ctx, const uint8_t *rows, uint64_t n, double *pre,
         ctx->d_rows_cap = cap;
     }
     CRP_HIP(ctx, hipMemcpyAsync(ctx->d_rows, rows, n * 30, hipMemcpyHostToDevice, ctx->stream));
-    CRP_HIP(ctx, crp::launch_score30(ctx->stream, ctx->d_rows, n, ctx->d_rpre, ctx->d_rscore));
+    CRP_HIP(ctx, crp::launch_score30(ctx->stream, ctx->d_rows, n, order, ctx->d_rpre, ctx->d_rscore));
     if (pre) CRP_HIP(ctx, hipMemcpyAsync(pre, ctx->d_rpre, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     CRP_HIP(ctx, hipMemcpyAsync(score, ctx->d_rscore, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     CRP_HIP(ctx, hipStreamSynchronize(ctx->stream));

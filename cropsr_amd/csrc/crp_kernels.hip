@@ -27,6 +27,7 @@
 
 #include "crp_kernels.h"
 #include "crp_score.h"
+#include "crp_score_generic.h"
 
 namespace crp {
 
@@ -363,6 +364,36 @@ __global__ __launch_bounds__(BLOCK) void score30_kernel(const uint8_t *__restric
     }
 }
 
+// Same rows, scored in one of the reference's other accumulation orders
+// (crp_score_generic.h).  Slow and generic on purpose: the host sends at most a
+// few rows per written chunk here.
+__global__ __launch_bounds__(64) void score30_order_kernel(const uint8_t *__restrict__ rows, uint64_t n, int order,
+                                                            double *__restrict__ pre_out,
+                                                            double *__restrict__ score_out)
+{
+    __shared__ uint64_t exp_tab[256];
+    for (int k = threadIdx.x; k < 256; k += 64) exp_tab[k] = CRP_EXP_TAB[k];
+    __syncthreads();
+    for (uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 64) {
+        int8_t code[30];
+        for (int p = 0; p < 30; ++p) {
+            const uint32_t ch = rows[30 * i + p];
+            code[p] = ch == 'A' ? 0 : ch == 'T' ? 1 : ch == 'C' ? 2 : ch == 'G' ? 3 : -1;
+        }
+        double s1, s2;
+        if (order == CRP_ORDER_TAIL2) {
+            s1 = crp_sum_tail2<false>(code);
+            s2 = crp_sum_tail2<true>(code);
+        } else {
+            s1 = crp_sum_dot1<false>(code);
+            s2 = crp_sum_dot1<true>(code);
+        }
+        const double pre = (((s1 + s2) + CRP_INTERSECT) + CRP_LOW_GC) * -1.0;
+        if (pre_out) pre_out[i] = pre;
+        score_out[i] = 1.0 / (1.0 + crp_exp(pre, exp_tab));
+    }
+}
+
 // -------------------------------------------------------------- pack kernel
 // Characters -> bit-planes with wavefront ballots: 64 lanes classify 64
 // characters, four __ballot()s ARE the four plane words.
@@ -454,9 +485,15 @@ hipError_t launch_emit(hipStream_t s, const Planes &pl, uint64_t n_words_padded,
     return hipGetLastError();
 }
 
-hipError_t launch_score30(hipStream_t s, const uint8_t *rows, uint64_t n, double *pre, double *score)
+hipError_t launch_score30(hipStream_t s, const uint8_t *rows, uint64_t n, int order, double *pre, double *score)
 {
     if (n == 0) return hipSuccess;
+    if (order != CRP_ORDER_BODY4) {
+        const uint64_t b = (n + 63) / 64;
+        hipLaunchKernelGGL(score30_order_kernel, dim3((uint32_t)(b < 1024 ? b : 1024)), dim3(64), 0, s, rows, n,
+                           order, pre, score);
+        return hipGetLastError();
+    }
     const uint64_t blocks = (n + BLOCK - 1) / BLOCK;
     const uint32_t grid = (uint32_t)(blocks < 8192 ? blocks : 8192);
     hipLaunchKernelGGL(score30_kernel, dim3(grid), dim3(BLOCK), 0, s, rows, n, pre, score);

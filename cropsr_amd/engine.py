@@ -199,23 +199,34 @@ class Engine:
         return a
 
     # ---- seam 2
-    def score_30mers(self, rows):
-        """(pre, score) for an (n,30) uint8 array; see crp_score_30mers."""
+    def score_30mers(self, rows, order=nat.ORDER_BODY4):
+        """(pre, score) for an (n,30) uint8 array; see crp_score_30mers.  `order`
+        selects the accumulation order of the reference's BLAS for rows at the
+        tail of a batch (include/cropsr_hip.h, CRP_ORDER_*)."""
         rows = np.ascontiguousarray(rows, dtype=np.uint8)
         if rows.ndim != 2 or rows.shape[1] != 30:
             raise ValueError("expected an (n, 30) uint8 array")
         n = rows.shape[0]
         pre = np.empty(n, dtype=np.float64)
         score = np.empty(n, dtype=np.float64)
-        nat.check(nat.lib().crp_score_30mers(self._ctx, rows.ctypes.data_as(nat.u8p), n,
+        nat.check(nat.lib().crp_score_30mers(self._ctx, rows.ctypes.data_as(nat.u8p), n, int(order),
                                              pre.ctypes.data_as(nat.f64p), score.ctypes.data_as(nat.f64p)),
                   "crp_score_30mers", self._ctx)
         return pre, score
 
     def rs1_score(self, sequences):
         """Drop-in for the reference's rs1_score (CROPSR.py:285): same argument,
-        same return value."""
-        return self.score_30mers(sequences)[1]
+        same return value -- including which rows of the batch are summed in
+        which BLAS order."""
+        sequences = np.ascontiguousarray(sequences, dtype=np.uint8)
+        n = sequences.shape[0]
+        if n == 1:
+            return self.score_30mers(sequences, nat.ORDER_DOT1)[1]
+        score = self.score_30mers(sequences, nat.ORDER_BODY4)[1]
+        base = 4 * (n // 4)
+        if n % 4 >= 2:
+            score[base:base + 2] = self.score_30mers(sequences[base:base + 2], nat.ORDER_TAIL2)[1]
+        return score
 
     # ---- measurement
     def profile(self, on=True):

@@ -1,0 +1,195 @@
+"""Hit tables -> CSV rows, byte-for-byte as the reference writes them.
+
+Host-side mirror of the part of CROPSR.py that sits BELOW the accelerated path:
+the row fields built at CROPSR.py:418-434, the id generator (:316-318, :448-449),
+the 1 000 000-row chunked scorer/writer (:442-474) and the csv dialect.  The hit
+positions and scores come from the HIP engine (cropsr_amd.engine); the two
+string columns are re-sliced here from the contig string, which keeps every
+string quirk of the reference without shipping strings through the GPU.
+
+Reference behaviours preserved on purpose:
+  B.3  Complete_dataset is never cleared: pass k re-emits contigs 1..k;
+  B.4  the final partial chunk is taken from index count*counter, not
+       1e6*counter; a total that is an exact multiple of 1e6 loses its last chunk;
+  B.5  ids are consumed backwards (ids[index_range-index-1]);
+  B.6  rows whose long_sequence is not 30 characters have 11 fields and -1;
+  B.7  CRLF line ends, minimal quoting, shortest-repr floats.
+"""
+import csv
+
+import numpy as np
+
+HEADER = ["crispr_id", "crispr_sys", "sequence", "long_sequence", "chromosome", "start_pos",
+          "end_pos", "cutsite", "strand", "on_site_score", "features", "status"]
+CHUNK = 1000000  # CROPSR.py:453
+ORDER_BODY4, ORDER_TAIL2, ORDER_DOT1 = 0, 1, 2  # include/cropsr_hip.h CRP_ORDER_*
+
+
+def _chain_map(steps):
+    """Character map equivalent to a chain of str.replace(a, b) calls."""
+    table = {}
+    for c in set("".join(a + b for a, b in steps)):
+        out = c
+        for a, b in steps:
+            if out == a:
+                out = b
+        if out != c:
+            table[ord(c)] = out
+    return table
+
+
+# get_gRNA_sequence (CROPSR.py:128) and get_reverse_complement (:120), without their [::-1]
+_RNA_STEPS = [("A", "U"), ("C", "Z"), ("G", "C"), ("Z", "G"), ("T", "A")]
+_REVC_STEPS = _RNA_STEPS + [("U", "T")]
+RNA_MAP = _chain_map(_RNA_STEPS)
+_REVC_MAP = _chain_map(_REVC_STEPS)
+# '-' strand: get_gRNA_sequence(get_reverse_complement(x)) -- the two reversals cancel
+MINUS_MAP = {}
+for _c in set(chr(k) for k in list(RNA_MAP) + list(_REVC_MAP)):
+    _o = _c.translate(_REVC_MAP).translate(RNA_MAP)
+    if _o != _c:
+        MINUS_MAP[ord(_c)] = _o
+
+
+def plus_text(s, a, b):
+    """get_gRNA_sequence(s[a:b])."""
+    return s[a:b].translate(RNA_MAP)[::-1]
+
+
+def minus_text(s, a, b):
+    """get_gRNA_sequence(get_reverse_complement(s[a:b]))."""
+    return s[a:b].translate(MINUS_MAP)
+
+
+class ContigRows:
+    """The rows one contig contributes to Complete_dataset, in reference order
+    (all '+' hits ascending, then all '-' hits ascending; CROPSR.py:417-434)."""
+
+    def __init__(self, name_token, s, hits, guide_len):
+        l = guide_len
+        self.chrom = name_token[1:]  # CROPSR.py:422 chromosome[1::]
+        ip = hits["pos_plus"].astype(np.int64)
+        jm = hits["pos_minus"].astype(np.int64)
+        self.n = int(ip.size + jm.size)
+        self.n_plus = int(ip.size)
+        # '+': pam_location = (i-l, i)            stored [start, end]   (:418, :422)
+        # '-': pam_location = (j+3, j+3+l)        stored [end', start'] (:429, :433)
+        self.start = np.concatenate([ip - l, jm + 3 + l]).tolist()
+        self.end = np.concatenate([ip, jm + 3]).tolist()
+        self.score = np.concatenate([hits["score_plus"], hits["score_minus"]]).tolist()
+        short, long_ = [], []
+        for i in ip.tolist():
+            short.append(plus_text(s, i - l, i))
+            long_.append(plus_text(s, i - l - 5, i + 5))
+        for j in jm.tolist():
+            short.append(minus_text(s, j + 3, j + 3 + l))
+            long_.append(minus_text(s, j + 3 - 5, j + 3 + l + 5))
+        self.short = short
+        self.long = long_
+
+    def row(self, k, crispr_id):
+        strand = "+" if k < self.n_plus else "-"
+        if len(self.long[k]) == 30:  # CROPSR.py:466
+            return (crispr_id, "cas9", self.short[k], self.long[k], self.chrom, self.start[k],
+                    self.end[k], self.end[k] - 3, strand, self.score[k], "", "completed")
+        return (crispr_id, "cas9", self.short[k], self.long[k], self.chrom, self.start[k],
+                self.end[k], strand, -1, "", "completed")
+
+
+def flush_plan(size, chunk=CHUNK):
+    """(index_range, count) of every writerows() call CROPSR.py:451-474 makes for
+    a dataset of `size` rows."""
+    if size <= 0:
+        return []
+    n_full = (size + chunk - 1) // chunk - 1  # flushed while i < size-1
+    plan = [(chunk * k, chunk) for k in range(n_full)]
+    rest = size - n_full * chunk
+    if rest < chunk:
+        plan.append((rest * n_full, rest))  # index_range = count*counter with the CURRENT count
+    return plan
+
+
+def make_ids(size):
+    """get_id (CROPSR.py:316-318) + the bytes->str step (:449); draws from the
+    GLOBAL numpy RNG exactly as the reference does, so a seeded run reproduces."""
+    alphanum = np.array(list("ABCDEFGHIJKLMNOPQRSTUVWXYZ0123456789"), dtype="|U1")
+    ids = np.random.choice(alphanum, [size, 7])
+    return np.ascontiguousarray(ids).view("<U7").ravel()
+
+
+class Dataset:
+    """Complete_dataset (CROPSR.py:407): grows by one ContigRows per contig pass
+    and is never cleared."""
+
+    def __init__(self):
+        self.blocks = []
+        self.starts = [0]
+
+    def append(self, block):
+        self.blocks.append(block)
+        self.starts.append(self.starts[-1] + block.n)
+
+    def __len__(self):
+        return self.starts[-1]
+
+    def _locate(self, g):
+        b = int(np.searchsorted(self.starts, g, "right") - 1)
+        return self.blocks[b], g - self.starts[b]
+
+    def rows(self, lo, count, ids, index_range, rescore):
+        """Row tuples for dataset[lo:lo+count] with ids[index_range-index-1].
+
+        The slice is one rs1_score batch (CROPSR.py:456-461).  The reference's BLAS
+        sums the rows at the tail of a batch in another order than the body
+        (include/cropsr_hip.h, CRP_ORDER_*); those <= 2 rows are re-scored through
+        `rescore(rows_u8[n,30], order) -> scores` so the CSV matches to the last bit.
+        """
+        size = len(self)
+        hi = min(lo + count, size)
+        out = []
+        b = int(np.searchsorted(self.starts, lo, "right") - 1)
+        g = lo
+        while g < hi:
+            blk = self.blocks[b]
+            base = self.starts[b]
+            for k in range(g - base, min(hi - base, blk.n)):
+                index = base + k - lo
+                out.append(blk.row(k, ids[index_range - index - 1]))
+            g = base + blk.n
+            b += 1
+        n = len(out)
+        if n == 1:
+            special, order = [0], ORDER_DOT1
+        elif n % 4 >= 2:
+            special, order = [4 * (n // 4), 4 * (n // 4) + 1], ORDER_TAIL2
+        else:
+            special, order = [], ORDER_BODY4
+        special = [k for k in special if len(out[k]) == 12]  # scored rows only
+        if special:
+            seqs = np.empty((len(special), 30), dtype=np.uint8)
+            for r, k in enumerate(special):
+                # the scoring string of CROPSR.py:458
+                seqs[r] = np.frombuffer(out[k][3].replace("U", "T").upper().encode("ascii", "replace"), dtype=np.uint8)
+            fixed = rescore(seqs, order)
+            for r, k in enumerate(special):
+                row = list(out[k])
+                row[9] = float(fixed[r])
+                out[k] = tuple(row)
+        return out
+
+
+def write_header(path):
+    """CROPSR.py:402-405."""
+    with open(path, "w", newline="") as f:
+        csv.writer(f).writerow(HEADER)
+
+
+def write_pass(path, dataset, rescore):
+    """One contig pass of CROPSR.py:442-474: fresh ids for the WHOLE dataset, then
+    the chunk walk.  `rescore`: see Dataset.rows."""
+    size = len(dataset)
+    with open(path, "a", newline="") as f:
+        writer = csv.writer(f)
+        ids = make_ids(size)
+        for index_range, count in flush_plan(size):
+            writer.writerows(dataset.rows(index_range, count, ids, index_range, rescore))

@@ -124,10 +124,22 @@ int crp_hits_device(crp_arena *arena, void **pos_plus, void **score_plus,
                     void **pos_minus, void **score_minus);
 
 /* ---- seam 2 alone -------------------------------------------------------- */
+/* Floating-point accumulation order of the two matmuls inside rs1_score
+ * (CROPSR.py:305,311).  With the reference's BLAS the order a row is summed in
+ * depends on its place in the batch of n rows handed to rs1_score:
+ *   BODY4  rows 0 .. 4*floor(n/4)-1, and the last row if n%4 is 1 or 3
+ *   TAIL2  rows 4*floor(n/4) and 4*floor(n/4)+1 if n%4 is 2 or 3
+ *   DOT1   the single row of a batch with n == 1
+ * crp_scan_score always uses BODY4; a host that wants the reference's CSV bytes
+ * re-scores the <= 2 TAIL2 rows (or the DOT1 row) of each written chunk. */
+#define CRP_ORDER_BODY4 0
+#define CRP_ORDER_TAIL2 1
+#define CRP_ORDER_DOT1 2
 /* rs1_score (CROPSR.py:285-313) on n rows of 30 bytes, row-major, exactly the
  * array CROPSR.py:458-461 builds: bytes equal to 'A','T','C','G' select weights,
- * every other byte selects none.  pre may be NULL. */
-int crp_score_30mers(crp_ctx *ctx, const uint8_t *rows, uint64_t n, double *pre, double *score);
+ * every other byte selects none.  Every row is summed in `order`.  pre may be
+ * NULL. */
+int crp_score_30mers(crp_ctx *ctx, const uint8_t *rows, uint64_t n, int order, double *pre, double *score);
 
 /* ---- measurement --------------------------------------------------------- */
 /* When enabled, every kernel launched by crp_scan_score is bracketed by HIP

@@ -178,6 +178,85 @@ void orc_score30(const uint8_t *rows, int64_t n, double *pre, double *score)
     for (int64_t i = 0; i < n; ++i) score_row(rows + 30 * i, pre + i, score + i);
 }
 
+/* ---- the other accumulation orders of the reference's BLAS --------------------
+ * np.matmul(one_hot[n,K], w[K]) reaches OpenBLAS dgemv_t (0.3.29, SkylakeX
+ * runtime core, one thread).  Its driver (kernel/x86_64/dgemv_t_4.c) hands rows
+ * four at a time to the AVX2 4x4 micro-kernel (order above), then a leftover
+ * PAIR of rows to dgemv_kernel_4x2 (SSE2: one 2-lane accumulator per row, so the
+ * lanes are flat index mod 2, combined by haddpd = l0 + l1), then a leftover
+ * single row to dgemv_kernel_4x1 (two 2-lane accumulators = the 4-lane order
+ * again).  A batch of exactly one row never reaches dgemv: numpy calls ddot,
+ * whose SkylakeX kernel (kernel/x86_64/ddot_microk_skylakex-2.c + ddot.c) runs
+ * 4 x 8 lanes over blocks of 32, folds them to 4 x 4, does the remaining block
+ * of 16 in 4 x 4 lanes, adds the four accumulators left to right, folds halves,
+ * hadds, and finishes the last K mod 16 elements one by one.
+ * Measured against the real reference on thousands of rows per case.
+ */
+static void one_hot(const uint8_t *t, double *v1, double *v2)
+{
+    int code[30];
+    for (int p = 0; p < 30; ++p) code[p] = base_index((char)t[p]);
+    for (int p = 0; p < 30; ++p)
+        for (int b = 0; b < 4; ++b) v1[p * 4 + b] = code[p] == b ? 1.0 : 0.0;
+    for (int p = 0; p < 29; ++p)
+        for (int b1 = 0; b1 < 4; ++b1)
+            for (int b2 = 0; b2 < 4; ++b2)
+                v2[p * 16 + b1 * 4 + b2] = (code[p] == b1 && code[p + 1] == b2) ? 1.0 : 0.0;
+}
+
+static double dot_tail2(const double *v, const double *w, int k)
+{
+    double l[2] = {0.0, 0.0};
+    for (int i = 0; i < k; ++i) l[i & 1] += v[i] * w[i];
+    return l[0] + l[1];
+}
+
+static double dot_skylakex(const double *v, const double *w, int k)
+{
+    const int k16 = k & -16, k32 = k16 & ~31;
+    double wide[4][8] = {{0}}, acc[4][4], col[4], d;
+    int i = 0;
+    for (; i < k32; i += 32)
+        for (int q = 0; q < 4; ++q)
+            for (int j = 0; j < 8; ++j) wide[q][j] += v[i + 8 * q + j] * w[i + 8 * q + j];
+    for (int q = 0; q < 4; ++q)
+        for (int j = 0; j < 4; ++j) acc[q][j] = wide[q][j] + wide[q][j + 4];
+    for (; i < k16; i += 16)
+        for (int q = 0; q < 4; ++q)
+            for (int j = 0; j < 4; ++j) acc[q][j] += v[i + 4 * q + j] * w[i + 4 * q + j];
+    for (int j = 0; j < 4; ++j) col[j] = ((acc[0][j] + acc[1][j]) + acc[2][j]) + acc[3][j];
+    d = (col[0] + col[2]) + (col[1] + col[3]);
+    for (; i < k; ++i) d += v[i] * w[i];
+    return d;
+}
+
+/* order: 0 = 4-lane body (same as orc_score30), 1 = 2-lane pair tail, 2 = single-row ddot */
+void orc_score30_order(const uint8_t *rows, int64_t n, int order, double *pre, double *score)
+{
+    build_weights();
+    for (int64_t i = 0; i < n; ++i) {
+        if (order == 0) { score_row(rows + 30 * i, pre + i, score + i); continue; }
+        double v1[120], v2[464], s1, s2;
+        one_hot(rows + 30 * i, v1, v2);
+        if (order == 1) { s1 = dot_tail2(v1, W1, 120); s2 = dot_tail2(v2, W2, 464); }
+        else { s1 = dot_skylakex(v1, W1, 120); s2 = dot_skylakex(v2, W2, 464); }
+        pre[i] = (((s1 + s2) + ORC_INTERSECT) + ORC_LOW_GC) * -1.0;
+        score[i] = 1.0 / (1.0 + orc_exp(pre[i]));
+    }
+}
+
+/* rs1_score on a whole batch exactly as the reference computes it: the order of
+ * each row follows from its position in the batch. */
+void orc_rs1_batch(const uint8_t *rows, int64_t n, double *pre, double *score)
+{
+    if (n == 1) { orc_score30_order(rows, 1, 2, pre, score); return; }
+    const int64_t body = 4 * (n / 4);
+    orc_score30_order(rows, body, 0, pre, score);
+    int64_t k = body;
+    if ((n & 3) >= 2) { orc_score30_order(rows + 30 * k, 2, 1, pre + k, score + k); k += 2; }
+    if (k < n) orc_score30_order(rows + 30 * k, 1, 0, pre + k, score + k);
+}
+
 /* ------------------------------------------------------- string transforms */
 /* A chain of str.replace(a, b) calls acts on every character independently, so
  * it is a byte map obtained by pushing each byte through the chain. */

@@ -34,6 +34,8 @@ def lib():
         L.orc_exp.argtypes = [ctypes.c_double]
         L.orc_exp_many.argtypes = [_f64p, ctypes.c_int64, _f64p]
         L.orc_score30.argtypes = [_u8p, ctypes.c_int64, _f64p, _f64p]
+        L.orc_score30_order.argtypes = [_u8p, ctypes.c_int64, ctypes.c_int, _f64p, _f64p]
+        L.orc_rs1_batch.argtypes = [_u8p, ctypes.c_int64, _f64p, _f64p]
         L.orc_scan.argtypes = [_u8p, ctypes.c_int64, ctypes.c_int, _u32p, _i64p, _u32p, _i64p]
         L.orc_score_hits.argtypes = [_u8p, ctypes.c_int64, ctypes.c_int, _u32p, ctypes.c_int64,
                                      ctypes.c_int, _f64p, _f64p]
@@ -72,6 +74,26 @@ def score30(rows):
     pre = np.empty(n)
     score = np.empty(n)
     lib().orc_score30(_p(rows, _u8p), n, _p(pre, _f64p), _p(score, _f64p))
+    return pre, score
+
+
+def score30_order(rows, order):
+    """Seam 2 with every row summed in BLAS order 0 (body), 1 (pair tail) or 2 (single row)."""
+    rows = np.ascontiguousarray(rows, dtype=np.uint8)
+    n = rows.shape[0]
+    pre = np.empty(n)
+    score = np.empty(n)
+    lib().orc_score30_order(_p(rows, _u8p), n, int(order), _p(pre, _f64p), _p(score, _f64p))
+    return pre, score
+
+
+def rs1_batch(rows):
+    """rs1_score on a batch as the reference computes it (row order by batch position)."""
+    rows = np.ascontiguousarray(rows, dtype=np.uint8)
+    n = rows.shape[0]
+    pre = np.empty(n)
+    score = np.empty(n)
+    lib().orc_rs1_batch(_p(rows, _u8p), n, _p(pre, _f64p), _p(score, _f64p))
     return pre, score
 
 

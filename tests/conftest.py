@@ -1,0 +1,92 @@
+import gzip
+import json
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN
+
+
+@pytest.fixture(scope="session")
+def manifest():
+    with open(os.path.join(GOLDEN, "manifest.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """The CPU oracle (test infrastructure); compiled on first use."""
+    from oracle import oracle as orc
+    orc.lib()
+    return orc
+
+
+@pytest.fixture(scope="session")
+def sample_fasta_text():
+    with gzip.open(os.path.join(GOLDEN, "sample_genome.fa.gz"), "rt") as f:
+        return f.read()
+
+
+PROBES = ["multi", "twoline", "spaces", "edges", "mixed", "rightend", "tiny", "dupname"]
+
+
+def read_golden_csv(name):
+    if name == "sample":
+        with gzip.open(os.path.join(GOLDEN, "sample_libm.csv.gz"), "rb") as f:
+            return f.read()
+    with open(os.path.join(GOLDEN, "probe_%s.libm.csv" % name), "rb") as f:
+        return f.read()
+
+
+def golden_fasta_path(name, tmp_path):
+    if name == "sample":
+        p = tmp_path / "sample_genome.fa"
+        with gzip.open(os.path.join(GOLDEN, "sample_genome.fa.gz"), "rb") as f:
+            p.write_bytes(f.read())
+        return str(p)
+    return os.path.join(GOLDEN, "probe_%s.fa" % name)
+
+
+class OracleBackend:
+    """cli backend built on the CPU oracle, for pinning the host logic without a GPU."""
+
+    def __init__(self, orc):
+        self.orc = orc
+
+    def scan(self, strings, l):
+        return [self.orc.scan_score(s.encode("ascii", "replace"), l) for s in strings]
+
+    def rescore(self, rows_u8, order):
+        return self.orc.score30_order(rows_u8, order)[1]
+
+
+def oracle_scan_provider(orc):
+    return OracleBackend(orc)
+
+
+def run_cli(tmp_path, monkeypatch, fasta_path, backend, seed, extra=()):
+    """Run cropsr_amd.cli in tmp_path; returns (csv bytes, stdout text)."""
+    import io
+    from cropsr_amd import cli
+    monkeypatch.chdir(tmp_path)
+    gff = os.path.join(GOLDEN, "sample_head.gff")
+    out_csv = str(tmp_path / "out.csv")
+    argv = ["-f", fasta_path, "-g", gff, "-o", out_csv, "--cas9", "--seed", str(seed)] + list(extra)
+    args = cli.build_parser().parse_args(argv)
+    buf = io.StringIO()
+    cli.run(args, backend=backend, out=buf)
+    with open(out_csv, "rb") as f:
+        return f.read(), buf.getvalue()

@@ -224,6 +224,25 @@ def main():
     np.savez_compressed(os.path.join(HERE, "rs1_vectors.npz"), seqs=seqs, libm=s_libm, avx512=s_avx)
     manifest["cases"]["rs1_vectors"] = {"n": n, "differs": int((s_libm != s_avx).sum())}
 
+    # ---- seam-2 batch-position vectors: the reference's BLAS sums the last rows of a
+    # batch (n mod 4 of them) and a batch of one row in other orders than the body
+    bchild = SCORE_CHILD.replace("np.save(out, CROPSR.rs1_score(seqs))", """
+res = {}
+for n in (1, 2, 3, 5, 6, 7, 10, 11):
+    m = (len(seqs) // n) * n
+    res['n%d' % n] = np.concatenate([CROPSR.rs1_score(seqs[k:k + n].copy()) for k in range(0, m, n)])
+np.savez(out, **res)
+""")
+    d = tempfile.mkdtemp(dir=scratch)
+    bseqs = np.ascontiguousarray(seqs[16:16 + 840])
+    np.save(os.path.join(d, "in.npy"), bseqs)
+    p = subprocess.run([sys.executable, "-c", bchild, os.path.join(d, "in.npy"), os.path.join(d, "out.npz")],
+                       cwd=d, env=env_for("libm"), capture_output=True, text=True)
+    if p.returncode != 0:
+        raise RuntimeError(p.stderr)
+    with np.load(os.path.join(d, "out.npz")) as z:
+        np.savez_compressed(os.path.join(HERE, "rs1_batches.npz"), seqs=bseqs, **{k: z[k] for k in z.files})
+
     # ---- the weight constants themselves (CROPSR.py:161-283) as data
     wchild = ("import sys; sys.argv=['CROPSR.py','-f','x','--cas9']; sys.path.insert(0,%r); "
               "import numpy as np, CROPSR as C; "

@@ -1,0 +1,83 @@
+"""Pins the CPU oracle (oracle/) and the host-side row logic against golden
+vectors produced by the real reference (tests/golden/make_golden.py).  CPU only."""
+import ctypes
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, PROBES, golden_fasta_path, oracle_scan_provider, read_golden_csv, run_cli
+
+
+def test_weights_match_reference_constants(oracle):
+    w = np.load(os.path.join(GOLDEN, "weights.npz"))
+    f, s, c = oracle.weights()
+    assert (f == w["first"]).all() and (s == w["second"]).all()
+    assert c[0] == w["consts"][0] and c[1] == w["consts"][1]
+
+
+def test_exp_restatement_equals_host_libm(oracle):
+    """orc_exp restates glibc's FMA-variant exp; on a host whose libm picks that
+    variant (any x86-64 with FMA) it must agree on every input."""
+    flags = open("/proc/cpuinfo").read()
+    if " fma " not in flags and " fma\n" not in flags:
+        pytest.skip("host CPU has no FMA: libm uses a different exp variant")
+    libm = ctypes.CDLL("libm.so.6")
+    libm.exp.restype = ctypes.c_double
+    libm.exp.argtypes = [ctypes.c_double]
+    rng = np.random.default_rng(5)
+    x = np.concatenate([rng.uniform(-12, 20, 400000), rng.normal(0, 1e-3, 20000),
+                        np.array([0.0, -0.0, 1e-300, -1e-300, 1e-17, -1e-17, 17.3, -9.3])])
+    got = oracle.exp(x)
+    want = np.array([libm.exp(v) for v in x.tolist()])
+    assert (got.view(np.uint64) == want.view(np.uint64)).all()
+
+
+def test_rs1_vectors(oracle):
+    g = np.load(os.path.join(GOLDEN, "rs1_vectors.npz"))
+    pre, score = oracle.score30(g["seqs"])
+    assert (score.view(np.uint64) == g["libm"].view(np.uint64)).all()
+    # numpy's AVX-512 exp differs from libm by at most 2 ulp on the final score
+    ulp = np.abs(score.view(np.int64) - g["avx512"].view(np.int64))
+    assert ulp.max() <= 2
+
+
+@pytest.mark.parametrize("name", PROBES + ["sample"])
+def test_cli_rows_equal_reference_csv(name, oracle, manifest, tmp_path, monkeypatch):
+    """Oracle hits + product host logic == every byte of the reference's CSV."""
+    want = read_golden_csv(name)
+    got, stdout = run_cli(tmp_path, monkeypatch, golden_fasta_path(name, tmp_path),
+                          oracle_scan_provider(oracle), manifest["seed"])
+    assert hashlib.md5(want).hexdigest() == manifest["cases"][name]["md5_libm"]
+    assert got == want
+    assert stdout == manifest["cases"][name]["stdout"]
+
+
+def test_sample_scores_vs_committed_output(oracle, sample_fasta_text):
+    """The reference's own committed sample_data/output.csv pins everything but
+    the random id exactly and the score to <= 15 ulp."""
+    import gzip
+    with gzip.open(os.path.join(GOLDEN, "sample_output_committed.csv.gz"), "rt", newline="") as f:
+        committed = f.read().split("\r\n")[1:-1]
+    with gzip.open(os.path.join(GOLDEN, "sample_libm.csv.gz"), "rt", newline="") as f:
+        ours = f.read().split("\r\n")[1:-1]
+    assert len(committed) == len(ours) == 17314
+    worst = 0
+    for a, b in zip(committed, ours):
+        fa, fb = a.split(",", 1)[1].rsplit(",", 3), b.split(",", 1)[1].rsplit(",", 3)
+        assert fa[0] == fb[0] and fa[2:] == fb[2:]  # all columns except id and score
+        ua = np.float64(fa[1]).view(np.int64)
+        ub = np.float64(fb[1]).view(np.int64)
+        worst = max(worst, abs(int(ua) - int(ub)))
+    assert worst <= 15
+
+
+def test_sample_avx512_scores_within_2ulp(oracle, sample_fasta_text):
+    seq = "".join(sample_fasta_text.split("\n")[1:])
+    s = ("'" + seq + "')]").encode()
+    h = oracle.scan_score(s)
+    ours = np.concatenate([h["score_plus"], h["score_minus"]])
+    avx = np.load(os.path.join(GOLDEN, "sample_avx512_scores.npy"))
+    assert ours.size == avx.size
+    assert np.abs(ours.view(np.int64) - avx.view(np.int64)).max() <= 2
