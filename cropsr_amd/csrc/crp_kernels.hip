@@ -225,13 +225,13 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(const uint2 *__restrict
 }
 
 // ------------------------------------------------------- pass 3: emit + score
-// 30 bits of an LDS plane starting at bit position q (q counted from bit 0 of
-// the left halo word).
-__device__ __forceinline__ uint32_t window30(const uint64_t *plane, uint32_t q)
+// 31 bits of an LDS plane starting at bit position q (q counted from bit 0 of
+// the left halo word): the 30-character window plus the character after it.
+__device__ __forceinline__ uint32_t window31(const uint64_t *plane, uint32_t q)
 {
     const uint32_t *p32 = reinterpret_cast<const uint32_t *>(plane);
     const uint32_t i = q >> 5;
-    return __builtin_amdgcn_alignbit(p32[i + 1], p32[i], q & 31) & 0x3fffffffu;
+    return __builtin_amdgcn_alignbit(p32[i + 1], p32[i], q & 31) & 0x7fffffffu;
 }
 
 __device__ __forceinline__ uint32_t reverse30(uint32_t x) { return __brev(x) >> 2; }
@@ -298,15 +298,24 @@ __global__ __launch_bounds__(BLOCK) void emit_kernel(Planes pl, uint64_t n_words
             const uint32_t r = lo_rank + k;
             const uint32_t e = list[k];
             const bool minus = r >= n_plus;
-            // '+': long window = s[i-25 : i+5]   (CROPSR.py:421 with l = 20)
-            // '-': long window = s[j-2  : j+28]  (CROPSR.py:432)
-            const uint32_t q = 64u + e - (minus ? 2u : 25u);
+            // '+': long_sequence = T(s[i-l-5 : i+5])       (CROPSR.py:421)
+            // '-': long_sequence = T(R(s[j-2 : j+l+8]))     (CROPSR.py:432)
+            // Python clamps the slice at len(s); the row is scored iff the result
+            // has exactly 30 characters (CROPSR.py:458,466): for l = 20 a complete
+            // window, for l > 20 a window cut to 30 by the end of the string, for
+            // l < 20 never.
+            const uint32_t q = 64u + e - (minus ? 2u : (uint32_t)(l + 5));
             double pre = -1.0, score = -1.0;
-            if (l == 20) {
-                uint32_t h = window30(sh[0], q), w = window30(sh[1], q);
-                const uint32_t u = window30(sh[2], q), a = window30(sh[3], q);
-                const bool complete = (h & w & ~u & ~a) == 0;  // no void position inside
-                uint32_t valid = a | u;                         // acgtACGT, U, Z
+            if (l >= 20) {
+                uint32_t h = window31(sh[0], q), w = window31(sh[1], q);
+                uint32_t u = window31(sh[2], q), a = window31(sh[3], q);
+                const uint32_t vd = h & w & ~u & ~a;  // void positions
+                const bool complete = (vd & 0x3fffffffu) == 0 && (l == 20 || (vd >> 30));
+                h &= 0x3fffffffu;
+                w &= 0x3fffffffu;
+                u &= 0x3fffffffu;
+                a &= 0x3fffffffu;
+                uint32_t valid = a | u;  // acgtACGT, U, Z
                 if (!minus) {
                     // get_gRNA_sequence (CROPSR.py:128): complement upper-case
                     // bases only, then reverse.  Complement = flip the low code bit.

@@ -96,9 +96,11 @@ class ContigRows:
                 self.end[k], strand, -1, "", "completed")
 
 
-def flush_plan(size, chunk=CHUNK):
+def flush_plan(size, chunk=None):
     """(index_range, count) of every writerows() call CROPSR.py:451-474 makes for
     a dataset of `size` rows."""
+    if chunk is None:
+        chunk = CHUNK
     if size <= 0:
         return []
     n_full = (size + chunk - 1) // chunk - 1  # flushed while i < size-1

@@ -107,8 +107,9 @@ int crp_arena_stats(const crp_arena *arena, uint64_t *n_contigs, uint64_t *n_cha
 
 /* ---- seam 1 + 2 over a whole arena -------------------------------------- */
 /* Scan both strands of every contig, keep what CROPSR.py:419/:430 keep for
- * guide length `guide_len`, score every kept hit whose 30-character window is
- * complete (guide_len == 20 only; others get -1 like CROPSR.py:466-468), leave
+ * guide length `guide_len`, score every kept hit whose long_sequence has exactly
+ * 30 characters (guide_len == 20: complete windows; > 20: only windows the end of
+ * the string cuts to 30; < 20: none -- the others get -1 like CROPSR.py:466-468), leave
  * the tables in HBM.  Tables are ascending in arena position per strand, i.e.
  * per contig in the reference's own order.  want_pre != 0 also keeps the
  * pre-sigmoid sum (CROPSR.py:312). */

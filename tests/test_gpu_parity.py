@@ -1,0 +1,322 @@
+"""Parity tests proper: the HIP path, called through the C ABI (ctypes), against
+the CPU oracle on the same seeded inputs, against the golden fixtures made by the
+real reference, and -- at BASELINE.json's full size -- through size-independent
+properties.  Integer/index columns and float columns are all compared BIT-EXACT
+(tolerance 0 ulp) in the pinned `libm` environment; the only non-zero tolerances
+are against fixtures from other environments (<= 2 ulp numpy-AVX512 exp,
+<= 15 ulp the reference's committed sample output) and are written at the assert.
+"""
+import ctypes
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, PROBES, golden_fasta_path, read_golden_csv, run_cli
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def engine():
+    from cropsr_amd import Engine
+    eng = Engine(0)  # raises if libcropsr_hip.so or the GPU is missing: no fallback
+    yield eng
+    eng.close()
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint8)
+
+
+def assert_hits_equal(got, want, ctx=""):
+    for key, w in want.items():
+        g = got[key]
+        assert g.shape == w.shape, (ctx, key, g.shape, w.shape)
+        assert (bits(g) == bits(w)).all(), (ctx, key)
+
+
+def check_contigs(engine, oracle, contigs, l=20, pack="device"):
+    arena = engine.arena(contigs, pack=pack)
+    hits = arena.scan_score(l, want_pre=True)
+    total = 0
+    for k, c in enumerate(contigs):
+        want = oracle.scan_score(c, l)
+        assert_hits_equal(hits.contig(k), want, ctx=(k, l, pack))
+        total += want["pos_plus"].size + want["pos_minus"].size
+    assert hits.n_plus + hits.n_minus == total
+    arena.close()
+    return total
+
+
+# ------------------------------------------------------------------- seam 2
+def test_rs1_vectors_golden(engine, oracle):
+    g = np.load(os.path.join(GOLDEN, "rs1_vectors.npz"))
+    pre, score = engine.score_30mers(g["seqs"])
+    opre, oscore = oracle.score30(g["seqs"])
+    assert (bits(pre) == bits(opre)).all()
+    assert (bits(score) == bits(oscore)).all()
+    assert (bits(score) == bits(g["libm"])).all()  # the real reference, libm environment
+    assert np.abs(score.view(np.int64) - g["avx512"].view(np.int64)).max() <= 2  # ulp, numpy AVX-512 exp
+
+
+def test_rs1_score_dropin_batch_positions(engine):
+    """Engine.rs1_score reproduces the reference's batch-position-dependent BLAS
+    orders: golden vectors from the real rs1_score on batches of 1..11 rows."""
+    z = np.load(os.path.join(GOLDEN, "rs1_batches.npz"))
+    seqs = z["seqs"]
+    for key in z.files:
+        if key == "seqs":
+            continue
+        n = int(key[1:])
+        m = (len(seqs) // n) * n
+        got = np.concatenate([engine.rs1_score(seqs[k:k + n]) for k in range(0, m, n)])
+        assert (bits(got) == bits(z[key])).all(), key
+
+
+@pytest.mark.parametrize("order", [0, 1, 2])
+def test_score_orders_vs_oracle(engine, oracle, order):
+    rng = np.random.default_rng(order)
+    rows = rng.choice(np.frombuffer(b"ATCGATCGATCGN'", dtype=np.uint8), size=(5000, 30))
+    pre, score = engine.score_30mers(rows, order)
+    opre, oscore = oracle.score30_order(rows, order)
+    assert (bits(pre) == bits(opre)).all() and (bits(score) == bits(oscore)).all()
+
+
+def test_score_30mers_ragged_and_empty(engine):
+    pre, score = engine.score_30mers(np.empty((0, 30), dtype=np.uint8))
+    assert pre.size == 0 and score.size == 0
+    with pytest.raises(ValueError):
+        engine.score_30mers(np.zeros((4, 29), dtype=np.uint8))
+
+
+# ------------------------------------------------------------------- seam 1
+@pytest.mark.parametrize("name", PROBES + ["sample"])
+def test_cli_csv_bytes_equal_reference(name, manifest, tmp_path, monkeypatch):
+    """python -m cropsr_amd on the GPU == every byte of the real reference's CSV
+    (seeded ids) and every stdout line."""
+    from cropsr_amd.cli import EngineBackend
+    be = EngineBackend(0)
+    got, stdout = run_cli(tmp_path, monkeypatch, golden_fasta_path(name, tmp_path), be, manifest["seed"])
+    be.close()
+    want = read_golden_csv(name)
+    assert hashlib.md5(got).hexdigest() == manifest["cases"][name]["md5_libm"]
+    assert got == want
+    assert stdout == manifest["cases"][name]["stdout"]
+
+
+def test_sample_vs_committed_reference_output(engine, sample_fasta_text):
+    """The reference's own sample_data/output.csv: positions/strings exact, score <= 15 ulp."""
+    import gzip
+    from cropsr_amd import fasta, rows
+    table = fasta.contig_table(sample_fasta_text)
+    (name, s), = table.items()
+    arena = engine.arena([s])
+    block = rows.ContigRows(name, s, arena.scan_score(20).contig(0), 20)
+    arena.close()
+    with gzip.open(os.path.join(GOLDEN, "sample_output_committed.csv.gz"), "rt", newline="") as f:
+        committed = f.read().split("\r\n")[1:-1]
+    assert block.n == len(committed) == 17314
+    worst = 0
+    for k, line in enumerate(committed):
+        f = line.split(",")
+        # id, cas9, sequence, long, "('Chr01'", ",", start, end, cutsite, strand, score, features, status
+        assert f[2] == block.short[k] and f[3] == block.long[k]
+        assert int(f[6]) == block.start[k] and int(f[7]) == block.end[k]
+        worst = max(worst, abs(int(np.float64(f[10]).view(np.int64)) - int(np.float64(block.score[k]).view(np.int64))))
+    assert worst <= 15  # ulp
+
+
+ALPHABETS = {
+    "acgt": b"ACGT",
+    "softmask": b"ACGTACGTACGTacgtN",
+    "exotic": b"ACGTacgtNUZuzRYKM')],-",
+    "gc_rich": b"GGCC",
+}
+
+
+@pytest.mark.parametrize("alpha", sorted(ALPHABETS))
+@pytest.mark.parametrize("pack", ["device", "host"])
+def test_random_contigs_vs_oracle(engine, oracle, alpha, pack):
+    rng = np.random.default_rng(sum(ALPHABETS[alpha]))
+    a = np.frombuffer(ALPHABETS[alpha], dtype=np.uint8)
+    lens = [0, 1, 2, 3, 22, 29, 30, 31, 63, 64, 65, 127, 128, 129, 1000, 16383, 16384, 16385, 16447,
+            32768, 70001]
+    contigs = [rng.choice(a, n).tobytes() for n in lens]
+    assert check_contigs(engine, oracle, contigs, 20, pack) > 500
+
+
+def test_decorated_contig_edges_vs_oracle(engine, oracle):
+    """Contig strings as the reference builds them: quote/paren decoration at both ends,
+    PAMs hard against the ends, truncated '-' windows (score -1)."""
+    rng = np.random.default_rng(2)
+    contigs = []
+    for k in range(40):
+        n = int(rng.integers(20, 200))
+        body = rng.choice(np.frombuffer(b"ACGGCC", dtype=np.uint8), n).tobytes()
+        contigs.append(b"'" + body + (b"')," if k % 2 else b"')]"))
+    contigs.append(b"'" + b"G" * 300 + b"'),")
+    contigs.append(b"'" + b"C" * 300 + b"')]")
+    check_contigs(engine, oracle, contigs)
+    # at least one truncated window must have been exercised
+    arena = engine.arena(contigs)
+    h = arena.scan_score(20)
+    assert (h.score_minus == -1.0).any() and not (h.score_plus == -1.0).any()
+    arena.close()
+
+
+def test_every_position_a_hit_multi_round(engine, oracle):
+    """poly-G / poly-C: every position is a hit, so one tile overflows the LDS hit
+    list several times (the multi-round path of the emit kernel)."""
+    contigs = [b"G" * 40000, b"C" * 40000, b"GC" * 20000, (b"G" * 100 + b"C" * 100) * 300]
+    n = check_contigs(engine, oracle, contigs)
+    assert n > 100000
+
+
+@pytest.mark.parametrize("l", [1, 2, 7, 8, 9, 19, 21, 30, 50])
+def test_guide_lengths_vs_oracle(engine, oracle, l):
+    """-l != 20: the keep-filter moves and long_sequence is l+10 characters, so rows
+    are unscored (-1, CROPSR.py:466-468) -- except, for l > 20, a window that the end
+    of the string cuts to exactly 30 characters, which the reference does score."""
+    rng = np.random.default_rng(l)
+    a = np.frombuffer(b"ACGTacgtNGGCC", dtype=np.uint8)
+    contigs = [rng.choice(a, n).tobytes() for n in (5, 40, 64, 100, 129, 5000)]
+    contigs += [b"'" + rng.choice(a, 77).tobytes() + b"'),"]
+    # contigs whose last CC sits exactly 28 before the end: cut-to-30 windows for l > 20
+    contigs += [rng.choice(a, 60).tobytes() + b"ACCA" + rng.choice(a, 25).tobytes() for _ in range(8)]
+    contigs += [rng.choice(a, 60).tobytes() + b"AGG" + tail for tail in (b"", b"A", b"AC", b"ACG")]
+    check_contigs(engine, oracle, contigs, l)
+    arena = engine.arena(contigs)
+    h = arena.scan_score(l)
+    if l < 20:
+        assert (h.score_plus == -1.0).all() and (h.score_minus == -1.0).all()
+    if l == 21:
+        assert (h.score_minus != -1.0).any()
+    arena.close()
+
+
+def test_unsupported_and_misordered_calls(engine):
+    from cropsr_amd import CropsrHipError
+    from cropsr_amd import _native as nat
+    arena = engine.arena([b"ACGTGGCCACGT" * 10])
+    for l in (0, 51, -3):
+        with pytest.raises(CropsrHipError) as e:
+            arena.scan_score(l)
+        assert e.value.status == -7  # CRP_ERR_UNSUPPORTED
+    with pytest.raises(CropsrHipError) as e:
+        arena.fetch(1, 1)  # nothing scanned yet
+    assert e.value.status == -5  # CRP_ERR_STATE
+    arena.close()
+    L = nat.lib()
+    h = ctypes.c_void_p()
+    assert L.crp_arena_create(engine._ctx, 4, ctypes.byref(h)) == 0
+    buf = (ctypes.c_uint8 * 1000)()
+    assert L.crp_arena_add_contig_ascii(h, buf, 1000, None) == -6  # CRP_ERR_CAPACITY
+    assert L.crp_scan_score(h, 20, 0, None, None) == -5            # not sealed
+    assert L.crp_arena_destroy(h) == 0
+    with pytest.raises(CropsrHipError):
+        engine.score_30mers(np.zeros((2, 30), dtype=np.uint8), order=3)
+
+
+def test_deterministic_and_repeatable(engine):
+    rng = np.random.default_rng(12)
+    contigs = [rng.choice(np.frombuffer(b"ACGTacgtN", dtype=np.uint8), 300000).tobytes() for _ in range(3)]
+    arena = engine.arena(contigs)
+    a = arena.scan_score(20, want_pre=True)
+    b = arena.scan_score(20, want_pre=True)
+    for name in ("pos_plus", "pre_plus", "score_plus", "pos_minus", "pre_minus", "score_minus"):
+        assert (bits(getattr(a, name)) == bits(getattr(b, name))).all()
+    arena.close()
+
+
+def test_medium_genome_vs_oracle(engine, oracle):
+    """A 6 Mb multi-contig arena with soft-masked runs and N runs, compared hit by
+    hit (positions, pre, score) with the oracle."""
+    rng = np.random.default_rng(33)
+    contigs = []
+    for n in (3000000, 2000000, 700000, 250000, 50000, 999):
+        a = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, n)]
+        # soft-mask runs and N runs
+        for _ in range(n // 20000 + 1):
+            st = int(rng.integers(0, n))
+            ln = int(rng.geometric(1 / 2000.0))
+            a[st:st + ln] |= 0x20
+        for _ in range(n // 200000 + 1):
+            st = int(rng.integers(0, n))
+            a[st:st + int(rng.integers(100, 5000))] = ord("N")
+        contigs.append(b"'" + a.tobytes() + b"'),")
+    n = check_contigs(engine, oracle, contigs)
+    assert n > 500000
+
+
+def test_big_chunk_csv_md5(manifest, tmp_path, monkeypatch):
+    """> 1 000 000 hits on one contig: the reference's broken final chunk and
+    backwards ids, compared by md5 with a real reference run (fixture: checksum)."""
+    from cropsr_amd.cli import EngineBackend
+    r = np.random.default_rng(12345)
+    seq = np.frombuffer(b"ACGT", dtype=np.uint8)[r.integers(0, 4, 9000000)].tobytes().decode()
+    fa = tmp_path / "big.fa"
+    with open(fa, "w") as f:
+        f.write(">chrBig\n")
+        f.write("\n".join(seq[i:i + 80] for i in range(0, len(seq), 80)))
+        f.write("\n")
+    be = EngineBackend(0)
+    got, _ = run_cli(tmp_path, monkeypatch, str(fa), be, manifest["seed"])
+    be.close()
+    assert got.count(b"\r\n") - 1 == manifest["cases"]["big9m"]["rows"] == 1124618
+    assert hashlib.md5(got).hexdigest() == manifest["cases"]["big9m"]["md5_libm"]
+
+
+# --------------------------------------------- BASELINE-size property tests
+def _complement_reverse(a):
+    lut = np.arange(256, dtype=np.uint8)
+    for x, y in (b"AT", b"TA", b"CG", b"GC"):
+        lut[x] = y
+    return lut[a][::-1]
+
+
+def test_full_size_properties(engine):
+    """The bench workload's size (>= 1 Gb, BASELINE.json north_star) through
+    properties that need no oracle pass:
+      * counts equal a vectorised numpy count of the same predicate,
+      * positions are strictly ascending per strand,
+      * reverse-complement symmetry: the '+' hits of S are the '-' hits of rc(S)
+        at mirrored positions WITH BIT-IDENTICAL scores (and vice versa).
+    """
+    total = int(float(os.environ.get("CROPSR_TEST_BIG_BASES", "1.13e9")))
+    rng = np.random.default_rng(5)
+    n_contigs = 16
+    per = total // n_contigs
+    G, C = ord("G"), ord("C")
+    fw, rc = [], []
+    want_plus = want_minus = 0
+    for k in range(n_contigs):
+        a = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, per, dtype=np.uint8)]
+        fw.append(a)
+        rc.append(np.ascontiguousarray(_complement_reverse(a)))
+        gg = (a[1:-1] == G) & (a[2:] == G)          # i in [0, n-3]
+        want_plus += int(gg[25:].sum())               # keep i - 20 >= 5
+        cc = (a[:-2] == C) & (a[1:-1] == C)          # j in [0, n-3]
+        want_minus += int(cc[2:per - 12].sum())       # keep j >= 2 and j + 23 <= n + 10
+    af = engine.arena(fw)
+    ar = engine.arena(rc)
+    hf = af.scan_score(20, want_pre=False)
+    hr = ar.scan_score(20, want_pre=False)
+    assert hf.n_plus == want_plus and hf.n_minus == want_minus
+    assert (np.diff(hf.pos_plus.astype(np.int64)) > 0).all()
+    assert (np.diff(hf.pos_minus.astype(np.int64)) > 0).all()
+    for k in range(n_contigs):
+        f, r = hf.contig(k), hr.contig(k)
+        # '+' hit at i in S  <->  '-' hit at n-3-i in rc(S); compare where both windows are interior
+        i = f["pos_plus"].astype(np.int64)
+        keep = (i >= 25) & (i + 5 <= per) & (per - 3 - i >= 2) & (per - 3 - i + 28 <= per)
+        j = (per - 3 - i[keep])[::-1]
+        rj = r["pos_minus"].astype(np.int64)
+        sel = (rj >= 2) & (rj + 28 <= per) & (per - 3 - rj >= 25) & (per - 3 - rj + 5 <= per)
+        assert (rj[sel] == j).all()
+        assert (bits(r["score_minus"][sel]) == bits(f["score_plus"][keep][::-1])).all()
+        # unscored rows exist only where the string end cuts the window
+        assert not (f["score_plus"][i + 5 <= per] == -1.0).any()
+    af.close()
+    ar.close()

@@ -1,0 +1,233 @@
+"""CPU-only tests of the host side: the C-ABI library loads and exports what
+include/cropsr_hip.h declares, host packing, the FASTA contig table, the row /
+chunk logic.  No GPU compute is attempted here."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+from cropsr_amd import _native as nat
+from cropsr_amd import fasta, rows
+
+
+# ------------------------------------------------------------------ C ABI
+def _declared_functions():
+    text = open(os.path.join(ROOT, "include", "cropsr_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(crp_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = nat.lib()
+    declared = _declared_functions()
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(L, name), name
+    assert sorted(nat.SIGNATURES) == declared
+    assert L.crp_abi_version() == 1
+    assert b"no CPU fallback" in L.crp_strerror(nat.CRP_ERR_NO_DEVICE)
+
+
+def test_library_is_gfx950_code_object():
+    out = subprocess.run(["strings", "-n", "6", nat.LIB_PATH], capture_output=True, text=True).stdout
+    assert "gfx950" in out
+
+
+def test_no_cpu_fallback_without_gpu():
+    """Without a HIP device the product must fail loudly, not compute on the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from cropsr_amd import Engine, CropsrHipError
+    with pytest.raises(CropsrHipError) as e:
+        Engine(0)
+    assert e.value.status == nat.CRP_ERR_NO_DEVICE
+
+
+def test_product_never_imports_oracle():
+    """The oracle is test infrastructure: nothing under cropsr_amd/ may touch it."""
+    for base, _, files in os.walk(os.path.join(ROOT, "cropsr_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")) :
+                src = open(os.path.join(base, f)).read()
+                assert "liborc" not in src and "from oracle" not in src and "import oracle" not in src, f
+
+
+# ---------------------------------------------------------------- packing
+def _py_planes(b):
+    """Independent statement of the plane encoding (include/cropsr_hip.h)."""
+    code = {"A": 0, "T": 1, "C": 2, "G": 3}
+    n_words = (len(b) + 63) // 64
+    hi = [0] * n_words
+    lo = [0] * n_words
+    up = [0] * n_words
+    ac = [0] * n_words
+    for k in range(n_words * 64):
+        w, bit = divmod(k, 64)
+        if k >= len(b):
+            hi[w] |= 1 << bit
+            lo[w] |= 1 << bit
+            continue
+        ch = chr(b[k])
+        if ch == "U":
+            ch = "A"
+        if ch == "Z":
+            hi[w] |= 1 << bit
+            up[w] |= 1 << bit
+            continue
+        if ch.upper() in code and ch != "u" and ch != "z":
+            c = code[ch.upper()]
+            hi[w] |= (c >> 1) << bit
+            lo[w] |= (c & 1) << bit
+            ac[w] |= 1 << bit
+            if ch.isupper():
+                up[w] |= 1 << bit
+    return [np.array(x, dtype=np.uint64) for x in (hi, lo, up, ac)]
+
+
+@pytest.mark.parametrize("n", [0, 1, 63, 64, 65, 1000])
+def test_pack_ascii_matches_definition(n):
+    from cropsr_amd import pack_ascii
+    rng = np.random.default_rng(n)
+    b = rng.choice(np.frombuffer(b"ACGTacgtNnUuZzRY')],-*", dtype=np.uint8), n).tobytes()
+    got = pack_ascii(b)
+    want = _py_planes(b)
+    for g, w in zip(got, want):
+        assert (g == w).all()
+
+
+def test_pack_ascii_threads_equal_serial():
+    from cropsr_amd import pack_ascii
+    rng = np.random.default_rng(1)
+    b = rng.choice(np.frombuffer(b"ACGTacgtN", dtype=np.uint8), 64 * 5000 + 17).tobytes()
+    for a, c in zip(pack_ascii(b, 1), pack_ascii(b, 4)):
+        assert (a == c).all()
+
+
+def test_arena_word_arithmetic():
+    L = nat.lib()
+    assert L.crp_arena_words_for(0) == 1
+    assert L.crp_arena_words_for(64) == 2
+    assert L.crp_arena_words_for(65) == 3
+    assert L.crp_arena_words_total(10) == 11
+
+
+def test_weight_definition_matches_reference_constants():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "gen_score_terms", os.path.join(ROOT, "cropsr_amd", "csrc", "gen_score_terms.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    _, (w1, w2), consts = gen.generate(os.path.join(ROOT, "cropsr_amd", "csrc", "doench_weights.def"))
+    w = np.load(os.path.join(GOLDEN, "weights.npz"))
+    assert (np.array(w1) == w["first"]).all() and (np.array(w2) == w["second"]).all()
+    assert consts["intersect"] == w["consts"][0] and consts["low_gc"] == w["consts"][1]
+
+
+# ------------------------------------------------------------ contig table
+def test_contig_table_formatted_path():
+    t = fasta.contig_table(">c1\nACGT\nAC\n>c2\nGG\n")
+    assert list(t.items()) == [("[('c1',", "'ACGTAC'),"), ("('c2',", "'GG')]")]
+
+
+def test_contig_table_unformatted_path():
+    t = fasta.contig_table(">c1\nACGT\n>c2\nGG")
+    assert list(t.items()) == [(">c1", "ACGT"), (">c2", "GG")]
+
+
+def test_contig_table_header_with_blanks_shifts_pairs():
+    t = fasta.contig_table(">c1 some description GGCC here\nACGT\n")
+    assert list(t.items()) == [("[('c1", "some"), ("description", "GGCC"), ("here',", "'ACGT')]")]
+
+
+def test_contig_table_odd_tokens_and_duplicates():
+    t = fasta.contig_table(">a b\nACGT\n")  # 3 tokens: last key gets ""
+    assert list(t.items()) == [("[('a", "b',"), ("'ACGT')]", "")]
+    t = fasta.contig_table(">d\nAAAA\n>x\nCC\n>d\nGGGG\n")
+    assert list(t.keys()) == ["[('d',", "('x',", "('d',"]  # first key differs by its '['
+    t = fasta.contig_table(">x\nAAAA\n>d\nCC\n>d\nGGGG\n")
+    assert list(t.items()) == [("[('x',", "'AAAA'),"), ("('d',", "'GGGG')]")]
+
+
+def test_contig_table_record_without_newline():
+    t = fasta.contig_table(">lonely")  # 2*1 != 0+1 -> re-formatted, 1-tuple record
+    assert list(t.items()) == [("[('lonely',)]", "")]
+    t = fasta.contig_table(">a\nAC\n>lonely")
+    assert list(t.items()) == [("[('a',", "'AC'),"), ("('lonely',)]", "")]
+
+
+# ------------------------------------------------------- chunking / rows
+def _reference_walk(size, chunk):
+    """Literal walk of the flush conditions of CROPSR.py:451-474."""
+    plan, count, counter = [], 0, 0
+    for i in range(size):
+        count += 1
+        if (count == chunk and i < size - 1) or (count < chunk and i == size - 1):
+            plan.append((count * counter, count))
+            count = 0
+            counter += 1
+    return plan
+
+
+@pytest.mark.parametrize("chunk", [1, 2, 3, 7, 10])
+def test_flush_plan_equals_literal_walk(chunk):
+    for size in range(0, 64):
+        assert rows.flush_plan(size, chunk) == _reference_walk(size, chunk), (size, chunk)
+
+
+def test_flush_plan_documented_cases():
+    # 1 124 618 hits: the last chunk re-reads rows 124618.. instead of 1000000..
+    assert rows.flush_plan(1124618) == [(0, 1000000), (124618, 124618)]
+    # an exact multiple loses its last chunk
+    assert rows.flush_plan(1000000) == []
+    assert rows.flush_plan(2000000) == [(0, 1000000)]
+
+
+def test_string_transforms_match_oracle(oracle):
+    """rows.plus_text / minus_text against the oracle's literal replace-chain restatement,
+    including the exotic U / Z / lower-case / decoration characters."""
+    rng = np.random.default_rng(4)
+    alpha = np.frombuffer(b"ACGTacgtNUZuz')],RY", dtype=np.uint8)
+    for trial in range(20):
+        s = rng.choice(alpha, 120).tobytes()
+        st = s.decode()
+        for pos in range(0, 120, 7):
+            if pos - 25 >= 0:
+                assert rows.plus_text(st, pos - 25, pos + 5) == oracle.long_sequence(s, pos, False)
+                assert rows.plus_text(st, pos - 20, pos) == oracle.short_sequence(s, pos, False)
+            if pos - 2 >= 0:
+                assert rows.minus_text(st, pos - 2, pos + 28) == oracle.long_sequence(s, pos, True)
+                assert rows.minus_text(st, pos + 3, pos + 23) == oracle.short_sequence(s, pos, True)
+
+
+def test_small_chunk_walk_end_to_end(oracle, tmp_path, monkeypatch):
+    """The >1e6-row behaviours (wrong final chunk, lost chunk, backwards ids) on a
+    small input by shrinking the chunk size: product rows vs a literal restatement
+    of the reference's list slicing."""
+    from conftest import OracleBackend
+    monkeypatch.setattr(rows, "CHUNK", 16)
+    rng = np.random.default_rng(9)
+    s = "'" + rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), 700).tobytes().decode() + "')]"
+    be = OracleBackend(oracle)
+    hits = be.scan([s], 20)[0]
+    block = rows.ContigRows("[('q',", s, hits, 20)
+    ds = rows.Dataset()
+    ds.append(block)
+    size = len(ds)
+    assert size > 48
+    np.random.seed(3)
+    ids = rows.make_ids(size)
+    all_rows = [block.row(k, None) for k in range(size)]
+    for index_range, count in rows.flush_plan(size):
+        lesser = all_rows[index_range:index_range + count]
+        got = ds.rows(index_range, count, ids, index_range, be.rescore)
+        assert len(got) == len(lesser)
+        id_list = ids.tolist()
+        for index, (g, w) in enumerate(zip(got, lesser)):
+            assert g[0] == id_list[index_range - index - 1]
+            assert g[1:9] == w[1:9]
