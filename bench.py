@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""bench.py -- gRNAs scored / s of the MI355X PAM-scan + score path.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the hot path (crp_scan_score: count -> tile scan -> emit+score)
+over the rank's arena, with the packed genome already resident in HBM; at N > 1 the
+step also runs the path's one exchange, the RCCL gatherv of the hit tables to rank 0.
+Workload at N = 1: the >= 1 Gb crop genome BASELINE.json's target is quoted on
+("switchgrass-like", SURVEY.md 8d cfg 5, seeded synthetic).  Weak scaling: N ranks
+process N such genomes (seeds 0..N-1), contigs dealt to ranks by LPT.
+
+Rank 0 prints ONE JSON line (contract in the task statement) with `roofline`
+(HIP-event timing of the emit+score kernel on the library's stream) and, at N = 1,
+`cpu_baseline` (the reference-faithful numpy port on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="switchgrass", choices=["switchgrass", "tair10", "ecoli"])
+    ap.add_argument("--scale", type=float, default=1.0, help="shrink the switchgrass-like genome (debug)")
+    ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the RCCL gatherv (scan/score only)")
+    ap.add_argument("--cpu-sample-bases", type=int, default=1500000,
+                    help="bases of the same workload timed on the CPU port (0 = skip)")
+    return ap.parse_args()
+
+
+def make_workload(name, genome, scale):
+    import bench_workload as bw
+    if name == "switchgrass":
+        return bw.switchgrass_like(genome, scale)
+    if name == "tair10":
+        return bw.tair10_like()
+    return bw.ecoli_like()
+
+
+def cpu_baseline(sample_string, n_bases):
+    """Reference-faithful numpy port (oracle/faithful_port.py) on one core."""
+    from oracle import faithful_port as fp
+    try:
+        from threadpoolctl import threadpool_limits
+        ctx = threadpool_limits(limits=1)
+    except Exception:  # pragma: no cover
+        import contextlib
+        ctx = contextlib.nullcontext()
+    with ctx:
+        t0 = time.perf_counter()
+        rows, scores = fp.scan_score(sample_string)
+        dt = time.perf_counter() - t0
+    scored = int((scores != -1.0).sum())
+    return {"value": scored / dt, "unit": "gRNAs/s", "cores": 1, "kind": "port",
+            "sample": "first %d bases of contig 0 of the same workload, scan+score only "
+                      "(%d gRNAs in %.1f s; %.1f kb/s)" % (n_bases, scored, dt, n_bases / dt / 1e3)}
+
+
+def main():
+    args = parse_args()
+    import numpy as np
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from cropsr_amd import Engine
+    from cropsr_amd import parallel
+
+    eng = Engine(local_rank)  # raises without libcropsr_hip.so / GPU: no fallback
+
+    # ---- workload: `world` genomes, contigs dealt to ranks by LPT (weak scaling)
+    genomes = [make_workload(args.workload, g, args.scale) for g in range(world)]
+    all_specs = [(g, k) for g in range(world) for k in range(len(genomes[g].specs))]
+    lengths = [genomes[g].specs[k].length + 4 for g, k in all_specs]  # + decoration
+    owner = parallel.partition_contigs(lengths, world)
+    mine = [i for i, o in enumerate(owner) if o == rank]
+    t_gen = time.perf_counter()
+    builder = eng.arena_builder([lengths[i] for i in mine])
+    sample = None
+    my_bases = 0
+    for i in mine:
+        g, k = all_specs[i]
+        s = genomes[g].contig_string(k)
+        if sample is None and rank == 0:
+            sample = s[:args.cpu_sample_bases + 1].tobytes().decode()  # keeps the leading quote
+        builder.add(s)
+        my_bases += genomes[g].specs[k].length
+        del s
+    arena = builder.seal()
+    t_gen = time.perf_counter() - t_gen
+
+    gather = None
+    if world > 1 and not args.no_gather:
+        gather = parallel.TableGather(dst=0)
+
+    def step():
+        n_plus, n_minus = arena.scan_score_device(20, want_pre=False)
+        if gather is not None:
+            gather(parallel.device_tables_as_tensors(arena, n_plus, n_minus))
+        return n_plus, n_minus
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        n_plus, n_minus = step()
+    if args.warmup == 0:
+        n_plus, n_minus = arena.scan_score_device(20, want_pre=False)
+    # units: kept hits that got a real score (a complete 30-window)
+    t = parallel.device_tables_as_tensors(arena, n_plus, n_minus)
+    scored = int((t["score_plus"] != -1.0).sum().item() + (t["score_minus"] != -1.0).sum().item())
+    del t
+
+    eng.profile(True)
+    eng.profile_read(reset=True)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    prof = eng.profile_read(reset=True)
+    eng.profile(False)
+
+    tot = torch.tensor([dt, float(scored), float(my_bases), float(n_plus + n_minus)], dtype=torch.float64,
+                       device="cuda")
+    if dist is not None:
+        mx = tot[:1].clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = tot[1:].clone()
+        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        dt = float(mx.item())
+        scored_all, bases_all, hits_all = [float(x) for x in sm.tolist()]
+    else:
+        scored_all, bases_all, hits_all = float(scored), float(my_bases), float(n_plus + n_minus)
+
+    if rank == 0:
+        info = eng.device_info()
+        n_chars = arena.stats()["n_chars"]
+        hits = n_plus + n_minus
+        algo_bytes = (n_chars + 3) // 4 + 2 * ((n_chars + 7) // 8) + 12 * hits  # SURVEY.md 8d, rank 0's launch
+        emit = prof["emit_score"]
+        emit_ms = emit["ms"] / max(1, emit["launches"])
+        achieved = algo_bytes / (emit_ms * 1e-3) / 1e9
+        path_ms = sum(p["ms"] for p in prof.values()) / max(1, emit["launches"])
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            with open(tpath) as f:
+                tj = json.load(f)
+            if tj.get("workload") == genomes[0].name and tj.get("kernel") == "emit_kernel":
+                traffic = tj.get("hbm_bytes_per_launch")
+        line = {
+            "metric": "gRNAs scored/sec", "value": scored_all * args.steps / dt, "unit": "gRNAs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u64 bit-planes + f64 score", "data": "synthetic",
+            "config": {"workload": genomes[0].name, "genomes": world, "contigs_per_genome": len(genomes[0].specs),
+                       "bases_total": int(bases_all), "kept_hits_total": int(hits_all),
+                       "guide_len": 20, "parallelism": ("contigs by LPT over %d ranks" % world) +
+                       ("" if gather is None else " + RCCL gatherv to rank 0"),
+                       "device": info["name"].strip()},
+            "bases_per_s": bases_all * args.steps / dt,
+            "roofline": {"bound": "hbm", "kernel": "emit_kernel (scan+compact+score)", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "algorithmic_bytes_per_launch": int(algo_bytes),
+                         "kernel_ms": emit_ms, "all_kernels_ms": path_ms,
+                         "count_kernel_ms": prof["count"]["ms"] / max(1, prof["count"]["launches"]),
+                         "tile_scan_ms": prof["tile_scan"]["ms"] / max(1, prof["tile_scan"]["launches"])},
+            "setup_s": {"generate_pack_upload": t_gen},
+        }
+        if world == 1 and args.cpu_sample_bases > 0:
+            from oracle import oracle as _o
+            _o.lib()
+            line["cpu_baseline"] = cpu_baseline(sample, args.cpu_sample_bases)
+            line["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
+        print(json.dumps(line), flush=True)
+
+    arena.close()
+    eng.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

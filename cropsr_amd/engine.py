@@ -198,6 +198,11 @@ class Engine:
         self._arenas.add(a)
         return a
 
+    def arena_builder(self, lengths):
+        """Incremental upload for genomes too big to hold as one list: give the
+        contig string lengths up front, then add() each string in that order."""
+        return ArenaBuilder(self, lengths)
+
     # ---- seam 2
     def score_30mers(self, rows, order=nat.ORDER_BODY4):
         """(pre, score) for an (n,30) uint8 array; see crp_score_30mers.  `order`
@@ -238,6 +243,40 @@ class Engine:
         nat.check(nat.lib().crp_profile_read(self._ctx, ms, n, int(reset)), "crp_profile_read")
         names = ("count", "tile_scan", "emit_score")
         return {names[k]: dict(ms=ms[k], launches=int(n[k])) for k in range(3)}
+
+
+class ArenaBuilder:
+    def __init__(self, engine, lengths):
+        L = nat.lib()
+        self._engine = engine
+        self._lengths = [int(n) for n in lengths]
+        total = sum(int(L.crp_arena_words_for(n)) for n in self._lengths)
+        self._h = ctypes.c_void_p()
+        nat.check(L.crp_arena_create(engine._ctx, L.crp_arena_words_total(total), ctypes.byref(self._h)),
+                  "crp_arena_create", engine._ctx)
+        self._offsets = []
+
+    def add(self, contig):
+        b = _as_u8(contig)
+        k = len(self._offsets)
+        if k >= len(self._lengths) or b.size != self._lengths[k]:
+            raise ValueError("contig %d: length differs from the one announced" % k)
+        off = ctypes.c_uint64()
+        nat.check(nat.lib().crp_arena_add_contig_ascii(self._h, b.ctypes.data_as(nat.u8p), b.size,
+                                                       ctypes.byref(off)),
+                  "crp_arena_add_contig_ascii", self._engine._ctx)
+        self._offsets.append(off.value)
+        return off.value
+
+    def seal(self):
+        if len(self._offsets) != len(self._lengths):
+            raise ValueError("not every announced contig was added")
+        nat.check(nat.lib().crp_arena_seal(self._h), "crp_arena_seal", self._engine._ctx)
+        a = Arena(self._engine, self._h, np.array(self._offsets, dtype=np.uint64),
+                  np.array(self._lengths, dtype=np.uint64))
+        self._engine._arenas.add(a)
+        self._h = None
+        return a
 
 
 def pack_ascii(text, n_threads=1):

@@ -1,0 +1,146 @@
+"""Multi-GPU sharding of the scan/score path: one process per GPU.
+
+The reference is single-process; its only hint of data parallelism is the dead
+`parallelize` helper (cropsr_functions.py:256-273: split rows over cores, no
+exchange).  Contigs are independent in the hot loop (CROPSR.py:409 carries no
+state but the append-only list), so the path shards by contig:
+
+  * partition_contigs: longest-processing-time greedy assignment of contigs to
+    ranks by length (a contig is never split, so no halo exchange is needed);
+  * every rank scans/scores its own arena -- no collective on the data path;
+  * gather_hit_tables: the one exchange step, a gatherv of the per-rank hit
+    tables to the root.  RCCL has no gatherv primitive: an all-gather of the
+    counts, then grouped point-to-point send/recv (ncclGroupStart/End through
+    torch.distributed.batch_isend_irecv).  Each peer->root transfer rides its own
+    xGMI link, so the step is bounded by one link, not by a ring.
+
+torch.distributed is plumbing only (RCCL bootstrap, streams); backend "nccl" is
+RCCL on ROCm, and the same code runs on "gloo" with CPU tensors for the tests.
+"""
+import numpy as np
+
+COLUMNS = ("pos_plus", "score_plus", "pos_minus", "score_minus")
+
+
+def partition_contigs(lengths, world_size):
+    """LPT greedy: owner rank per contig, deterministic (ties -> lower rank)."""
+    order = np.argsort(-np.asarray(lengths, dtype=np.int64), kind="stable")
+    load = [0] * world_size
+    owner = [0] * len(lengths)
+    for k in order.tolist():
+        b = min(range(world_size), key=lambda j: (load[j], j))
+        owner[k] = b
+        load[b] += int(lengths[k])
+    return owner
+
+
+class _DeviceArray:
+    """Zero-copy view of library-owned HBM for torch (CUDA array interface v2)."""
+
+    def __init__(self, ptr, n, typestr):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": typestr,
+                                         "data": (int(ptr), False), "version": 2}
+
+
+def device_tables_as_tensors(arena, n_plus, n_minus):
+    """torch views (no copy) of the hit tables crp_scan_score left in HBM.
+
+    Positions are exposed as int32 (same bits as the library's uint32) because
+    RCCL point-to-point has no unsigned 32-bit type in torch.  Valid until the
+    next scan on this arena.
+    """
+    import torch
+    pp, sp, pm, sm = arena.device_tables()
+    dev = torch.device("cuda", torch.cuda.current_device())
+
+    def view(ptr, n, typestr, dtype):
+        if n == 0:
+            return torch.empty(0, dtype=dtype, device=dev)
+        return torch.as_tensor(_DeviceArray(ptr, n, typestr), device=dev)
+
+    return {"pos_plus": view(pp, n_plus, "<i4", torch.int32),
+            "score_plus": view(sp, n_plus, "<f8", torch.float64),
+            "pos_minus": view(pm, n_minus, "<i4", torch.int32),
+            "score_minus": view(sm, n_minus, "<f8", torch.float64)}
+
+
+class TableGather:
+    """gatherv of per-rank hit tables to `dst`; receive buffers are kept between
+    calls (same sizes every bench step)."""
+
+    def __init__(self, dst=0, group=None):
+        self.dst = dst
+        self.group = group
+        self._bufs = {}
+
+    def __call__(self, tables):
+        """tables: dict of 1-D tensors (COLUMNS).  Returns on dst a list (one entry
+        per rank, in rank order) of such dicts, elsewhere None."""
+        import torch
+        import torch.distributed as dist
+        rank = dist.get_rank(self.group)
+        world = dist.get_world_size(self.group)
+        dev = tables["pos_plus"].device
+        counts = torch.tensor([tables["pos_plus"].numel(), tables["pos_minus"].numel()],
+                              dtype=torch.int64, device=dev)
+        all_counts = [torch.empty_like(counts) for _ in range(world)]
+        dist.all_gather(all_counts, counts, group=self.group)
+        all_counts = torch.stack(all_counts).cpu().tolist()
+        ops = []
+        out = None
+        if rank == self.dst:
+            out = []
+            for r in range(world):
+                if r == rank:
+                    out.append(tables)
+                    continue
+                n = {"pos_plus": all_counts[r][0], "score_plus": all_counts[r][0],
+                     "pos_minus": all_counts[r][1], "score_minus": all_counts[r][1]}
+                got = {}
+                for c in COLUMNS:
+                    key = (r, c)
+                    buf = self._bufs.get(key)
+                    if buf is None or buf.numel() != n[c]:
+                        buf = torch.empty(n[c], dtype=tables[c].dtype, device=dev)
+                        self._bufs[key] = buf
+                    got[c] = buf
+                    if n[c]:
+                        ops.append(dist.P2POp(dist.irecv, buf, self._global(r), group=self.group))
+                out.append(got)
+        else:
+            for c in COLUMNS:
+                if tables[c].numel():
+                    ops.append(dist.P2POp(dist.isend, tables[c].contiguous(), self._global(self.dst),
+                                          group=self.group))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        return out
+
+    def _global(self, group_rank):
+        import torch.distributed as dist
+        if self.group is None:
+            return group_rank
+        return dist.get_global_rank(self.group, group_rank)
+
+
+def merge_gathered(gathered, owners, per_rank_contigs):
+    """Reassemble per-contig tables in ORIGINAL contig order on the root.
+
+    gathered[r]: dict of numpy arrays for rank r (arena positions);
+    per_rank_contigs[r]: list of (contig index, arena offset, length) in the order
+    rank r loaded them.  Returns {contig index: dict(pos_plus, score_plus,
+    pos_minus, score_minus)} with contig-local positions -- '+' before '-' per
+    contig exactly as the reference orders rows (CROPSR.py:417-434).
+    """
+    out = {}
+    for r, contigs in enumerate(per_rank_contigs):
+        t = gathered[r]
+        pp = np.asarray(t["pos_plus"]).view(np.uint32)
+        pm = np.asarray(t["pos_minus"]).view(np.uint32)
+        for (k, off, ln) in contigs:
+            a, b = np.searchsorted(pp, [off, off + ln])
+            c, d = np.searchsorted(pm, [off, off + ln])
+            out[k] = dict(pos_plus=pp[a:b] - np.uint32(off), score_plus=np.asarray(t["score_plus"])[a:b],
+                          pos_minus=pm[c:d] - np.uint32(off), score_minus=np.asarray(t["score_minus"])[c:d])
+    return out
