@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcropsr_hip.so")
+# CROPSR_HIP_LIB: load another build of the same library (kernel A/B experiments)
+LIB_PATH = os.environ.get("CROPSR_HIP_LIB") or os.path.join(_HERE, "libcropsr_hip.so")
 
 u8p = ctypes.POINTER(ctypes.c_uint8)
 u32p = ctypes.POINTER(ctypes.c_uint32)
@@ -38,6 +39,7 @@ SIGNATURES = {
     "crp_fetch_hits": (ctypes.c_int, [ctypes.c_void_p, u32p, f64p, f64p, u32p, f64p, f64p]),
     "crp_hits_device": (ctypes.c_int, [ctypes.c_void_p, voidpp, voidpp, voidpp, voidpp]),
     "crp_score_30mers": (ctypes.c_int, [ctypes.c_void_p, u8p, ctypes.c_uint64, ctypes.c_int, f64p, f64p]),
+    "crp_configure": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int64]),
     "crp_profile_enable": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "crp_profile_read": (ctypes.c_int, [ctypes.c_void_p, f64p, u64p, ctypes.c_int]),
     "crp_synchronize": (ctypes.c_int, [ctypes.c_void_p]),
@@ -45,6 +47,7 @@ SIGNATURES = {
 
 CRP_OK = 0
 ORDER_BODY4, ORDER_TAIL2, ORDER_DOT1 = 0, 1, 2
+OPT_TWO_PASS = 1
 CRP_ERR_NO_DEVICE = -2
 
 _lib = None

@@ -20,7 +20,9 @@
 
 namespace {
 
-constexpr uint64_t kMaxArenaWords = (1ull << 32) / 64 - 2 * crp::ARENA_ALIGN_WORDS;  // positions stay 32-bit
+// arena positions (and therefore per-strand hit counts) stay below 2^31: the chained-scan
+// descriptors carry two 31-bit counts in one 64-bit word
+constexpr uint64_t kMaxArenaWords = (1ull << 31) / 64 - 2 * crp::ARENA_ALIGN_WORDS;
 constexpr uint64_t kUploadChunk = 64ull << 20;  // characters per H2D + pack round (multiple of 4096)
 
 inline uint64_t round_up(uint64_t x, uint64_t m) { return (x + m - 1) / m * m; }
@@ -40,6 +42,7 @@ struct crp_ctx {
     uint8_t *d_rows = nullptr;
     double *d_rpre = nullptr, *d_rscore = nullptr;
     uint64_t d_rows_cap = 0;
+    bool two_pass = true;  // CRP_OPT_TWO_PASS
     // measurement
     bool profiling = false;
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -57,6 +60,7 @@ struct crp_arena {
     bool sealed = false;
     // per-tile scratch
     uint2 *d_tile_cnt = nullptr, *d_tile_off = nullptr;
+    uint64_t *d_chain = nullptr;  // single-pass mode: ticket, fail flag, tile descriptors
     uint64_t *d_totals = nullptr;
     uint64_t *h_totals = nullptr;  // pinned
     uint32_t n_tiles = 0;
@@ -242,6 +246,7 @@ int crp_arena_destroy(crp_arena *a)
     for (int p = 0; p < 4; ++p) (void)hipFree(a->d_plane[p]);
     (void)hipFree(a->d_tile_cnt);
     (void)hipFree(a->d_tile_off);
+    (void)hipFree(a->d_chain);
     (void)hipFree(a->d_totals);
     if (a->h_totals) (void)hipHostFree(a->h_totals);
     for (int s = 0; s < 2; ++s) {
@@ -336,8 +341,9 @@ int crp_arena_seal(crp_arena *a)
     a->n_tiles = (uint32_t)(eff / crp::TILE_WORDS);
     CRP_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&a->d_tile_cnt), a->n_tiles * sizeof(uint2)));
     CRP_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&a->d_tile_off), a->n_tiles * sizeof(uint2)));
+    CRP_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&a->d_chain), crp::chain_bytes(a->n_tiles)));
     CRP_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&a->d_totals), 2 * sizeof(uint64_t)));
-    CRP_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&a->h_totals), 2 * sizeof(uint64_t), hipHostMallocDefault));
+    CRP_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&a->h_totals), 4 * sizeof(uint64_t), hipHostMallocDefault));
     CRP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     a->sealed = true;
     return CRP_OK;
@@ -374,27 +380,9 @@ static void prof_end(crp_ctx *ctx, int k)
     if (ctx->profiling) (void)hipEventRecord(ctx->ev[2 * k + 1], ctx->stream);
 }
 
-int crp_scan_score(crp_arena *a, int guide_len, int want_pre, uint64_t *n_plus, uint64_t *n_minus)
+static int reserve_tables(crp_arena *a, const uint64_t n[2], int want_pre)
 {
-    if (!a) return CRP_ERR_INVALID;
-    if (!a->sealed) return CRP_ERR_STATE;
-    if (guide_len < 1 || guide_len > 50) return CRP_ERR_UNSUPPORTED;
     crp_ctx *ctx = a->ctx;
-    CRP_HIP(ctx, hipSetDevice(ctx->device));
-    a->have_hits = false;
-    const uint64_t eff_words = (uint64_t)a->n_tiles * crp::TILE_WORDS;
-    crp::Planes pl{{a->d_plane[0], a->d_plane[1], a->d_plane[2], a->d_plane[3]}};
-
-    prof_begin(ctx, 0);
-    CRP_HIP(ctx, crp::launch_count(ctx->stream, pl, eff_words, guide_len, a->d_tile_cnt));
-    prof_end(ctx, 0);
-    prof_begin(ctx, 1);
-    CRP_HIP(ctx, crp::launch_tile_scan(ctx->stream, a->d_tile_cnt, a->n_tiles, a->d_tile_off, a->d_totals));
-    prof_end(ctx, 1);
-    CRP_HIP(ctx, hipMemcpyAsync(a->h_totals, a->d_totals, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-    CRP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    const uint64_t n[2] = {a->h_totals[0], a->h_totals[1]};
-
     for (int s = 0; s < 2; ++s) {
         uint64_t cap_pos = a->tab_cap[s], cap_score = a->tab_cap[s];
         int rc = grow(ctx, reinterpret_cast<void **>(&a->d_pos[s]), &cap_pos, n[s], sizeof(uint32_t));
@@ -406,21 +394,114 @@ int crp_scan_score(crp_arena *a, int guide_len, int want_pre, uint64_t *n_plus, 
             if (rc != CRP_OK) return rc;
         }
     }
-    crp::HitTables out{a->d_pos[0], a->d_score[0], want_pre ? a->d_pre[0] : nullptr,
-                       a->d_pos[1], a->d_score[1], want_pre ? a->d_pre[1] : nullptr};
-    prof_begin(ctx, 2);
-    CRP_HIP(ctx, crp::launch_emit(ctx->stream, pl, eff_words, guide_len, a->d_tile_off, out));
-    prof_end(ctx, 2);
-    CRP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (ctx->profiling) {
-        for (int k = 0; k < 3; ++k) {
-            float ms = 0.f;
-            if (hipEventElapsedTime(&ms, ctx->ev[2 * k], ctx->ev[2 * k + 1]) == hipSuccess) {
-                ctx->ms[k] += ms;
-                ctx->launches[k] += 1;
-            }
-        }
+    return CRP_OK;
+}
+
+static crp::HitTables table_args(const crp_arena *a, int want_pre)
+{
+    return crp::HitTables{a->d_pos[0], a->d_score[0], want_pre ? a->d_pre[0] : nullptr,
+                          a->d_pos[1], a->d_score[1], want_pre ? a->d_pre[1] : nullptr,
+                          want_pre ? std::min(a->tab_cap[0], a->pre_cap[0]) : a->tab_cap[0],
+                          want_pre ? std::min(a->tab_cap[1], a->pre_cap[1]) : a->tab_cap[1]};
+}
+
+static void prof_collect(crp_ctx *ctx, int k)
+{
+    float ms = 0.f;
+    if (ctx->profiling && hipEventElapsedTime(&ms, ctx->ev[2 * k], ctx->ev[2 * k + 1]) == hipSuccess) {
+        ctx->ms[k] += ms;
+        ctx->launches[k] += 1;
     }
+}
+
+// count -> tile scan -> emit: three launches, exact table sizes known before the emit pass
+static int scan_two_pass(crp_arena *a, const crp::Planes &pl, uint64_t eff_words, int guide_len, int want_pre,
+                         uint64_t n[2])
+{
+    crp_ctx *ctx = a->ctx;
+    prof_begin(ctx, 0);
+    CRP_HIP(ctx, crp::launch_count(ctx->stream, pl, eff_words, guide_len, a->d_tile_cnt));
+    prof_end(ctx, 0);
+    prof_begin(ctx, 1);
+    CRP_HIP(ctx, crp::launch_tile_scan(ctx->stream, a->d_tile_cnt, a->n_tiles, a->d_tile_off, a->d_totals));
+    prof_end(ctx, 1);
+    CRP_HIP(ctx, hipMemcpyAsync(a->h_totals, a->d_totals, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    // The totals are needed to size the tables.  Once this arena has been scanned
+    // the tables exist, so the emit pass is queued straight behind the scan (no
+    // host round trip in between); its stores are bounds-checked and the totals
+    // are compared with the capacities afterwards.
+    const bool speculative = a->tab_cap[0] && a->tab_cap[1] && (!want_pre || (a->pre_cap[0] && a->pre_cap[1]));
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if (!speculative || attempt == 1) {
+            if (attempt == 0) CRP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            n[0] = a->h_totals[0];
+            n[1] = a->h_totals[1];
+            int rc = reserve_tables(a, n, want_pre);
+            if (rc != CRP_OK) return rc;
+        }
+        const crp::HitTables out = table_args(a, want_pre);
+        prof_begin(ctx, 2);
+        CRP_HIP(ctx, crp::launch_emit(ctx->stream, pl, eff_words, guide_len, a->d_tile_off, out));
+        prof_end(ctx, 2);
+        CRP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        n[0] = a->h_totals[0];
+        n[1] = a->h_totals[1];
+        if (n[0] <= out.cap_plus && n[1] <= out.cap_minus) break;  // everything was stored
+    }
+    for (int k = 0; k < 3; ++k) prof_collect(ctx, k);
+    return CRP_OK;
+}
+
+// one launch: table offsets come from a chained scan inside the emit kernel.  The
+// tables are sized from the previous scan of this arena (hit counts are a
+// property of the sealed arena) or, the first time, from a density guess; a scan
+// that finds more hits than fit writes nothing out of bounds and is repeated once
+// with the exact sizes.
+static int scan_single_pass(crp_arena *a, const crp::Planes &pl, uint64_t eff_words, int guide_len, int want_pre,
+                            uint64_t n[2])
+{
+    crp_ctx *ctx = a->ctx;
+    uint64_t want[2] = {std::max<uint64_t>(a->tab_cap[0], a->n_chars / 8 + 1024),
+                        std::max<uint64_t>(a->tab_cap[1], a->n_chars / 8 + 1024)};
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        int rc = reserve_tables(a, want, want_pre);
+        if (rc != CRP_OK) return rc;
+        const crp::HitTables out = table_args(a, want_pre);
+        prof_begin(ctx, 2);
+        CRP_HIP(ctx, crp::launch_emit_chained(ctx->stream, pl, eff_words, guide_len, a->d_chain, a->d_totals, out));
+        prof_end(ctx, 2);
+        CRP_HIP(ctx, hipMemcpyAsync(a->h_totals, a->d_totals, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+        CRP_HIP(ctx, hipMemcpyAsync(a->h_totals + 2, a->d_chain, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+        CRP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (a->h_totals[2] >> 32) {  // fail flag: a look-back spin ran out
+            ctx->last_error = "emit kernel: chained-scan look-back timed out";
+            return CRP_ERR_HIP;
+        }
+        prof_collect(ctx, 2);
+        n[0] = a->h_totals[0];
+        n[1] = a->h_totals[1];
+        if (n[0] <= out.cap_plus && n[1] <= out.cap_minus) return CRP_OK;
+        want[0] = n[0];
+        want[1] = n[1];
+    }
+    ctx->last_error = "emit kernel: tables still too small after resizing";
+    return CRP_ERR_STATE;
+}
+
+int crp_scan_score(crp_arena *a, int guide_len, int want_pre, uint64_t *n_plus, uint64_t *n_minus)
+{
+    if (!a) return CRP_ERR_INVALID;
+    if (!a->sealed) return CRP_ERR_STATE;
+    if (guide_len < 1 || guide_len > 50) return CRP_ERR_UNSUPPORTED;
+    crp_ctx *ctx = a->ctx;
+    CRP_HIP(ctx, hipSetDevice(ctx->device));
+    a->have_hits = false;
+    const uint64_t eff_words = (uint64_t)a->n_tiles * crp::TILE_WORDS;
+    crp::Planes pl{{a->d_plane[0], a->d_plane[1], a->d_plane[2], a->d_plane[3]}};
+    uint64_t n[2] = {0, 0};
+    const int rc = ctx->two_pass ? scan_two_pass(a, pl, eff_words, guide_len, want_pre, n)
+                                 : scan_single_pass(a, pl, eff_words, guide_len, want_pre, n);
+    if (rc != CRP_OK) return rc;
     a->n_hits[0] = n[0];
     a->n_hits[1] = n[1];
     a->have_hits = true;
@@ -512,6 +593,15 @@ int crp_profile_read(crp_ctx *ctx, double ms[3], uint64_t launches[3], int reset
         }
     }
     return CRP_OK;
+}
+
+int crp_configure(crp_ctx *ctx, int option, int64_t value)
+{
+    if (!ctx) return CRP_ERR_INVALID;
+    switch (option) {
+        case CRP_OPT_TWO_PASS: ctx->two_pass = value != 0; return CRP_OK;
+        default: return CRP_ERR_INVALID;
+    }
 }
 
 int crp_synchronize(crp_ctx *ctx)

@@ -21,6 +21,8 @@ struct HitTables {
     uint32_t *pos_minus;
     double *score_minus;
     double *pre_minus;  // may be null
+    uint64_t cap_plus;  // table capacities in elements (single-pass mode checks them)
+    uint64_t cap_minus;
 };
 
 hipError_t launch_count(hipStream_t s, const Planes &pl, uint64_t n_words_padded, int l, uint2 *tile_cnt);
@@ -28,6 +30,10 @@ hipError_t launch_tile_scan(hipStream_t s, const uint2 *tile_cnt, uint32_t n_til
                             uint64_t *totals);
 hipError_t launch_emit(hipStream_t s, const Planes &pl, uint64_t n_words_padded, int l, const uint2 *tile_off,
                        const HitTables &out);
+// single-pass mode: `chain` = chain_bytes(n_tiles) bytes of device scratch, zeroed by the launcher
+size_t chain_bytes(uint32_t n_tiles);
+hipError_t launch_emit_chained(hipStream_t s, const Planes &pl, uint64_t n_words_padded, int l, uint64_t *chain,
+                               uint64_t *totals, const HitTables &out);
 hipError_t launch_score30(hipStream_t s, const uint8_t *rows, uint64_t n, int order, double *pre, double *score);
 hipError_t launch_pack(hipStream_t s, const uint8_t *text, uint64_t len, uint64_t n_words, uint64_t *hi,
                        uint64_t *lo, uint64_t *up, uint64_t *ac);

@@ -154,31 +154,72 @@ __device__ __forceinline__ void thread_masks(uint64_t (*sh)[TW + 2], int l, uint
 }
 
 // -------------------------------------------------------------- pass 1: count
-template <int WPT>
+// Pure streaming pass: no LDS staging, no barrier before the loads.  A wavefront
+// covers 128 consecutive words (two per lane, one 16-byte load per plane and lane
+// = 64 bytes in flight per lane); the words a lane does not own come from its
+// neighbours by wave shuffles of the DERIVED G / C / void masks, and only lanes 0
+// and 63 touch memory for the words just outside the wave.  A workgroup of four
+// waves produces the counts of two emit tiles (TILE_WORDS = 256 words each).
+__device__ __forceinline__ void derive(uint64_t hi, uint64_t lo, uint64_t up, uint64_t ac, uint64_t &g,
+                                       uint64_t &c, uint64_t &v)
+{
+    g = hi & lo & up & ac;
+    c = hi & ~lo & up & ac;
+    v = hi & lo & ~up & ~ac;
+}
+
+__device__ __forceinline__ uint64_t counts_of(uint64_t g_c, uint64_t g_n, uint64_t c_c, uint64_t c_n,
+                                              uint64_t v_p, uint64_t v_c, uint64_t v_n, int l)
+{
+    const uint64_t mplus = ahead(g_c, g_n, 1) & ahead(g_c, g_n, 2) & ~behind(v_p, v_c, l + 5);
+    uint64_t m = c_c & ahead(c_c, c_n, 1) & ~ahead(v_c, v_n, 2) & ~behind(v_p, v_c, 2);
+    if (l > 8) m &= ~ahead(v_c, v_n, l - 8);
+    return (uint64_t)__popcll(mplus) | ((uint64_t)__popcll(m) << 32);
+}
+
 __global__ __launch_bounds__(BLOCK) void count_kernel(Planes pl, uint64_t n_words_padded, int l,
                                                        uint2 *__restrict__ tile_cnt)
 {
-    constexpr int TW = BLOCK * WPT;
-    __shared__ uint64_t sh[4][TW + 2];
+    static_assert(TILE_WORDS == 256 && BLOCK == 256, "two waves per emit tile");
     __shared__ uint64_t wave_tot[BLOCK / 64];
-    const uint64_t t0 = (uint64_t)blockIdx.x * TW;
-    stage_tile<TW>(pl, t0, n_words_padded, sh);
-    __syncthreads();
-    uint64_t mp[WPT], mm[WPT];
-    thread_masks<WPT, TW>(sh, l, mp, mm);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t w0 = ((uint64_t)blockIdx.x * (BLOCK / 64) + wave) * 128;  // first word of this wave
     uint64_t c = 0;
+    if (w0 < n_words_padded) {
+        const uint64_t wa = w0 + 2 * lane;  // this lane owns words wa, wa+1
+        ulonglong2 q[4];
 #pragma unroll
-    for (int k = 0; k < WPT; ++k) c += (uint64_t)__popcll(mp[k]) | ((uint64_t)__popcll(mm[k]) << 32);
-    // wave reduce, then one LDS round
+        for (int p = 0; p < 4; ++p) q[p] = *reinterpret_cast<const ulonglong2 *>(pl.plane[p] + wa);
+        // words just outside the wave: void beyond the arena
+        uint64_t e[4] = {ALL, ALL, 0, 0};
+        if (lane == 0 && w0 > 0) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) e[p] = pl.plane[p][w0 - 1];
+        } else if (lane == 63 && w0 + 128 < n_words_padded) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) e[p] = pl.plane[p][w0 + 128];
+        }
+        uint64_t ga, ca, va, gb, cb, vb, ge, ce, ve;
+        derive(q[0].x, q[1].x, q[2].x, q[3].x, ga, ca, va);
+        derive(q[0].y, q[1].y, q[2].y, q[3].y, gb, cb, vb);
+        derive(e[0], e[1], e[2], e[3], ge, ce, ve);
+        // left neighbour's second word, right neighbour's first word
+        uint64_t v_left = __shfl_up(vb, 1, 64);
+        uint64_t g_right = __shfl_down(ga, 1, 64), c_right = __shfl_down(ca, 1, 64), v_right = __shfl_down(va, 1, 64);
+        if (lane == 0) v_left = ve;
+        if (lane == 63) { g_right = ge; c_right = ce; v_right = ve; }
+        c = counts_of(ga, gb, ca, cb, v_left, va, vb, l) + counts_of(gb, g_right, cb, c_right, va, vb, v_right, l);
+    }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d, 64);
-    if ((threadIdx.x & 63) == 0) wave_tot[threadIdx.x >> 6] = c;
+    if (lane == 0) wave_tot[wave] = c;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        uint64_t t = 0;
-#pragma unroll
-        for (int w = 0; w < BLOCK / 64; ++w) t += wave_tot[w];
-        tile_cnt[blockIdx.x] = make_uint2((uint32_t)t, (uint32_t)(t >> 32));
+    if (threadIdx.x < 2) {
+        const uint64_t tile = (uint64_t)blockIdx.x * 2 + threadIdx.x;
+        if (tile * TILE_WORDS < n_words_padded) {
+            const uint64_t t = wave_tot[2 * threadIdx.x] + wave_tot[2 * threadIdx.x + 1];
+            tile_cnt[tile] = make_uint2((uint32_t)t, (uint32_t)(t >> 32));
+        }
     }
 }
 
@@ -188,39 +229,62 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(const uint2 *__restrict
                                                           uint2 *__restrict__ tile_off,
                                                           uint64_t *__restrict__ totals)
 {
+    // Chunks of 8192 tiles go through LDS: coalesced load, every thread scans its 8
+    // consecutive entries, one scan of the 1024 thread sums, coalesced store.
+    // Per-strand totals stay below 2^31, so the packed halves never carry into
+    // each other.
+    constexpr int PER = 8, CHUNK = 1024 * PER;
+    __shared__ uint64_t buf[CHUNK];
     __shared__ uint64_t wave_tot[16];
-    __shared__ uint64_t carry_s;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) carry_s = 0;
-    __syncthreads();
-    for (uint32_t base = 0; base < n_tiles; base += 1024) {
-        const uint32_t i = base + threadIdx.x;
-        uint64_t v = 0;
-        if (i < n_tiles) {
-            const uint2 c = tile_cnt[i];
-            v = (uint64_t)c.x | ((uint64_t)c.y << 32);
+    uint64_t carry = 0;
+    for (uint32_t base = 0; base < n_tiles; base += CHUNK) {
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const uint32_t i = base + k * 1024 + threadIdx.x;
+            uint64_t v = 0;
+            if (i < n_tiles) {
+                const uint2 c = tile_cnt[i];
+                v = (uint64_t)c.x | ((uint64_t)c.y << 32);
+            }
+            buf[k * 1024 + threadIdx.x] = v;
         }
-        const uint64_t inc = wave_inclusive_scan(v);
+        __syncthreads();
+        uint64_t loc[PER], sum = 0;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            loc[k] = buf[threadIdx.x * PER + k];
+            sum += loc[k];
+        }
+        const uint64_t inc = wave_inclusive_scan(sum);
         if (lane == 63) wave_tot[wave] = inc;
         __syncthreads();
-        uint64_t pre = carry_s, tot = 0;
+        uint64_t pre = carry, tot = 0;
 #pragma unroll
         for (int w = 0; w < 16; ++w) {
             const uint64_t t = wave_tot[w];
             if (w < wave) pre += t;
             tot += t;
         }
-        const uint64_t ex = pre + inc - v;
-        if (i < n_tiles) tile_off[i] = make_uint2((uint32_t)ex, (uint32_t)(ex >> 32));
+        uint64_t ex = pre + inc - sum;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            buf[threadIdx.x * PER + k] = ex;
+            ex += loc[k];
+        }
+        carry += tot;
         __syncthreads();
-        // Per-strand totals stay below 2^32 (arena positions are 32-bit), so the
-        // packed halves never carry into each other.
-        if (threadIdx.x == 0) carry_s += tot;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const uint32_t i = base + k * 1024 + threadIdx.x;
+            const uint64_t v = buf[k * 1024 + threadIdx.x];
+            if (i < n_tiles) tile_off[i] = make_uint2((uint32_t)v, (uint32_t)(v >> 32));
+        }
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        totals[0] = carry_s & 0xffffffffull;
-        totals[1] = carry_s >> 32;
+        totals[0] = carry & 0xffffffffull;
+        totals[1] = carry >> 32;
     }
 }
 
@@ -236,19 +300,121 @@ __device__ __forceinline__ uint32_t window31(const uint64_t *plane, uint32_t q)
 
 __device__ __forceinline__ uint32_t reverse30(uint32_t x) { return __brev(x) >> 2; }
 
-template <int WPT>
+// Chained-scan descriptors (single-pass mode): one 64-bit word per tile,
+//   bits 63..62 status (0 = not ready, 1 = tile aggregate, 2 = inclusive prefix),
+//   bits 61..31 '-' count, bits 30..0 '+' count.
+// The word is the whole message (value and flag travel in ONE relaxed agent-scope
+// 8-byte store / load), so no fence is needed around it.
+static constexpr uint64_t DESC_AGG = 1ull << 62, DESC_PREFIX = 2ull << 62, DESC_VALUE = (1ull << 62) - 1;
+
+__device__ __forceinline__ uint64_t desc_pack(uint64_t packed32)  // plus | minus << 32  ->  31-bit fields
+{
+    return (packed32 & 0x7fffffffull) | ((packed32 >> 32) << 31);
+}
+__device__ __forceinline__ uint64_t desc_unpack(uint64_t v)
+{
+    return (v & 0x7fffffffull) | (((v >> 31) & 0x7fffffffull) << 32);
+}
+
+// Exclusive prefix of this tile's (plus | minus << 32) counts over all earlier
+// tiles, by decoupled look-back; called by wave 0 only, returns in every lane.
+// Tiles are numbered in dispatch order (atomic ticket), so every tile this one
+// waits for is already running.  Spins are bounded: on timeout *fail is set and
+// the (wrong) prefix 0 is returned so the grid still drains.
+__device__ __forceinline__ uint64_t lookback_exclusive(uint64_t *desc, uint32_t tile, uint64_t total,
+                                                       uint32_t *fail)
+{
+    const int lane = threadIdx.x & 63;
+    if (tile == 0) {
+        if (lane == 0) __hip_atomic_store(&desc[0], DESC_PREFIX | desc_pack(total), __ATOMIC_RELAXED,
+                                          __HIP_MEMORY_SCOPE_AGENT);
+        return 0;
+    }
+    if (lane == 0) __hip_atomic_store(&desc[tile], DESC_AGG | desc_pack(total), __ATOMIC_RELAXED,
+                                      __HIP_MEMORY_SCOPE_AGENT);
+    // Each round inspects the LB_DEPTH*64 tiles before `base` (lane k, slot j looks at
+    // tile base - k - 64*j) with all loads in flight together: about as many tiles as
+    // are resident without a published prefix, so one round usually suffices.
+    constexpr int LB_DEPTH = 8;
+    uint64_t excl = 0;
+    int64_t base = (int64_t)tile - 1;
+    uint32_t spins = 0;
+    while (true) {
+        uint64_t v[LB_DEPTH];
+#pragma unroll
+        for (int j = 0; j < LB_DEPTH; ++j) {
+            const int64_t idx = base - lane - 64 * j;
+            v[j] = DESC_PREFIX;  // before tile 0: an empty prefix
+            if (idx >= 0) v[j] = __hip_atomic_load(&desc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        uint64_t contrib = 0;
+        bool found = false, stall = false;
+#pragma unroll
+        for (int j = 0; j < LB_DEPTH; ++j) {
+            const uint64_t st = v[j] >> 62;
+            const uint64_t not_ready = __ballot(st == 0);
+            const uint64_t is_prefix = __ballot(st == 2);
+            // slots nearer than the nearest prefix must all be ready
+            const int p = is_prefix ? __builtin_ctzll(is_prefix) : 64;
+            const uint64_t need = p >= 64 ? ~0ull : ((1ull << p) - 1);
+            if (!found && !stall) {
+                if (not_ready & need) {
+                    stall = true;
+                } else {
+                    if (lane <= p) contrib += desc_unpack(v[j] & DESC_VALUE);
+                    found = p < 64;
+                }
+            }
+        }
+        if (stall) {  // some nearer tile has not published yet: look again
+            if (++spins > (1u << 20)) {
+                if (lane == 0) atomicExch(fail, 1u);
+                return 0;
+            }
+            __builtin_amdgcn_s_sleep(4);
+            continue;
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) contrib += __shfl_xor(contrib, d, 64);
+        excl += contrib;
+        if (found) break;
+        base -= 64 * LB_DEPTH;
+    }
+    if (lane == 0) __hip_atomic_store(&desc[tile], DESC_PREFIX | desc_pack(excl + total), __ATOMIC_RELAXED,
+                                      __HIP_MEMORY_SCOPE_AGENT);
+    return excl;
+}
+
+// CHAINED = true : single pass.  Tile ids come from an atomic ticket, table
+//                  offsets from the decoupled look-back above; `chain` holds
+//                  [0] ticket (u32) [1] fail flag (u32), then one descriptor per
+//                  tile from byte 16; all zeroed before every launch.  Stores
+//                  are bounds-checked against the table capacities, totals are
+//                  published by the last tile.
+// CHAINED = false: third pass of the count / scan / emit sequence (offsets from
+//                  tile_off); kept as the cross-check for the single-pass mode.
+template <int WPT, bool CHAINED>
 __global__ __launch_bounds__(BLOCK) void emit_kernel(Planes pl, uint64_t n_words_padded, int l,
-                                                      const uint2 *__restrict__ tile_off, HitTables out)
+                                                      const uint2 *__restrict__ tile_off, uint64_t *chain,
+                                                      uint64_t *__restrict__ totals, HitTables out)
 {
     constexpr int TW = BLOCK * WPT;
     constexpr int CAP = 2048 * WPT;  // list entries per round; typical tiles need one round
     __shared__ uint64_t sh[4][TW + 2];
     __shared__ uint64_t exp_tab[256];
     __shared__ uint64_t wave_tot[BLOCK / 64];
+    __shared__ uint64_t s_excl;
+    __shared__ uint32_t s_tile;
     __shared__ uint16_t list[CAP];
 
     const int tid = threadIdx.x;
-    const uint64_t t0 = (uint64_t)blockIdx.x * TW;
+    uint32_t tile = blockIdx.x;
+    if (CHAINED) {
+        if (tid == 0) s_tile = atomicAdd(reinterpret_cast<uint32_t *>(chain), 1u);
+        __syncthreads();
+        tile = s_tile;
+    }
+    const uint64_t t0 = (uint64_t)tile * TW;
     stage_tile<TW>(pl, t0, n_words_padded, sh);
     exp_tab[tid] = CRP_EXP_TAB[tid];
     __syncthreads();
@@ -262,8 +428,29 @@ __global__ __launch_bounds__(BLOCK) void emit_kernel(Planes pl, uint64_t n_words
     const uint64_t ex = block_exclusive_scan(c, wave_tot, total);
     const uint32_t n_plus = (uint32_t)total, n_minus = (uint32_t)(total >> 32);
     const uint32_t n_all = n_plus + n_minus;
+    uint64_t off_plus, off_minus;
+    if (CHAINED) {
+        if (tid < 64) {
+            uint32_t *fail = reinterpret_cast<uint32_t *>(chain) + 1;
+            const uint64_t e = lookback_exclusive(chain + 2, tile, total, fail);
+            if (tid == 0) {
+                s_excl = e;
+                if (tile == gridDim.x - 1) {
+                    const uint64_t all = e + total;
+                    totals[0] = all & 0xffffffffull;
+                    totals[1] = all >> 32;
+                }
+            }
+        }
+        __syncthreads();
+        off_plus = s_excl & 0xffffffffull;
+        off_minus = s_excl >> 32;
+    } else {
+        const uint2 off = tile_off[tile];
+        off_plus = off.x;
+        off_minus = off.y;
+    }
     if (n_all == 0) return;
-    const uint2 off = tile_off[blockIdx.x];
     const uint32_t tile_pos = (uint32_t)(t0 * 64);
 
     for (uint32_t lo_rank = 0; lo_rank < n_all; lo_rank += CAP) {
@@ -326,20 +513,28 @@ __global__ __launch_bounds__(BLOCK) void emit_kernel(Planes pl, uint64_t n_words
                 if (complete) {
                     const uint32_t mG = h & w & valid, mC = h & ~w & valid;
                     const uint32_t mT = ~h & w & valid, mA = ~h & ~w & valid;
+#if defined(CRP_EXPERIMENT_NO_SCORE)
+                    score = __hiloint2double((int)(mA ^ mT), (int)(mC ^ mG));
+#else
                     crp_score_masks(mA, mT, mC, mG, exp_tab, pre, score);
+#endif
                 }
             }
             const uint32_t pos = tile_pos + e;
             if (minus) {
-                const uint64_t o = (uint64_t)off.y + (r - n_plus);
-                out.pos_minus[o] = pos;
-                out.score_minus[o] = score;
-                if (out.pre_minus) out.pre_minus[o] = pre;
+                const uint64_t o = off_minus + (r - n_plus);
+                if (o < out.cap_minus) {
+                    out.pos_minus[o] = pos;
+                    out.score_minus[o] = score;
+                    if (out.pre_minus) out.pre_minus[o] = pre;
+                }
             } else {
-                const uint64_t o = (uint64_t)off.x + r;
-                out.pos_plus[o] = pos;
-                out.score_plus[o] = score;
-                if (out.pre_plus) out.pre_plus[o] = pre;
+                const uint64_t o = off_plus + r;
+                if (o < out.cap_plus) {
+                    out.pos_plus[o] = pos;
+                    out.score_plus[o] = score;
+                    if (out.pre_plus) out.pre_plus[o] = pre;
+                }
             }
         }
     }
@@ -474,7 +669,7 @@ hipError_t launch_count(hipStream_t s, const Planes &pl, uint64_t n_words_padded
 {
     constexpr int TW = BLOCK * TILE_WPT;
     const uint32_t n_tiles = (uint32_t)(n_words_padded / TW);
-    hipLaunchKernelGGL(count_kernel<TILE_WPT>, dim3(n_tiles), dim3(BLOCK), 0, s, pl, n_words_padded, l, tile_cnt);
+    hipLaunchKernelGGL(count_kernel, dim3((n_tiles + 1) / 2), dim3(BLOCK), 0, s, pl, n_words_padded, l, tile_cnt);
     return hipGetLastError();
 }
 
@@ -490,7 +685,22 @@ hipError_t launch_emit(hipStream_t s, const Planes &pl, uint64_t n_words_padded,
 {
     constexpr int TW = BLOCK * TILE_WPT;
     const uint32_t n_tiles = (uint32_t)(n_words_padded / TW);
-    hipLaunchKernelGGL(emit_kernel<TILE_WPT>, dim3(n_tiles), dim3(BLOCK), 0, s, pl, n_words_padded, l, tile_off, out);
+    hipLaunchKernelGGL((emit_kernel<TILE_WPT, false>), dim3(n_tiles), dim3(BLOCK), 0, s, pl, n_words_padded, l,
+                       tile_off, (uint64_t *)nullptr, (uint64_t *)nullptr, out);
+    return hipGetLastError();
+}
+
+size_t chain_bytes(uint32_t n_tiles) { return 16 + (size_t)n_tiles * sizeof(uint64_t); }
+
+hipError_t launch_emit_chained(hipStream_t s, const Planes &pl, uint64_t n_words_padded, int l, uint64_t *chain,
+                               uint64_t *totals, const HitTables &out)
+{
+    constexpr int TW = BLOCK * TILE_WPT;
+    const uint32_t n_tiles = (uint32_t)(n_words_padded / TW);
+    hipError_t e = hipMemsetAsync(chain, 0, chain_bytes(n_tiles), s);  // ticket, fail flag, descriptors
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((emit_kernel<TILE_WPT, true>), dim3(n_tiles), dim3(BLOCK), 0, s, pl, n_words_padded, l,
+                       (const uint2 *)nullptr, chain, totals, out);
     return hipGetLastError();
 }
 

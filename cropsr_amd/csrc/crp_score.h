@@ -64,5 +64,9 @@ __device__ __forceinline__ void crp_score_masks(uint32_t mA, uint32_t mT, uint32
     const double s1 = (fA + fC) + (fT + fG);
     const double s2 = (sA + sC) + (sT + sG);
     pre = (((s1 + s2) + CRP_INTERSECT) + CRP_LOW_GC) * -1.0;
+#if defined(CRP_EXPERIMENT_NO_EXP)
+    score = pre;
+#else
     score = 1.0 / (1.0 + crp_exp(pre, exp_tab));
+#endif
 }

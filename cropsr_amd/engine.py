@@ -233,6 +233,12 @@ class Engine:
             score[base:base + 2] = self.score_30mers(sequences[base:base + 2], nat.ORDER_TAIL2)[1]
         return score
 
+    def configure(self, two_pass=None):
+        """two_pass=True: count / scan / emit launches instead of the single chained
+        kernel (same results; cross-check)."""
+        if two_pass is not None:
+            nat.check(nat.lib().crp_configure(self._ctx, nat.OPT_TWO_PASS, int(bool(two_pass))), "crp_configure")
+
     # ---- measurement
     def profile(self, on=True):
         nat.check(nat.lib().crp_profile_enable(self._ctx, int(on)), "crp_profile_enable")

@@ -142,12 +142,22 @@ int crp_hits_device(crp_arena *arena, void **pos_plus, void **score_plus,
  * NULL. */
 int crp_score_30mers(crp_ctx *ctx, const uint8_t *rows, uint64_t n, int order, double *pre, double *score);
 
+/* ---- options -------------------------------------------------------------- */
+/* CRP_OPT_TWO_PASS (value 0/1, default 1): crp_scan_score runs the count / tile-scan
+ * / emit+score launch sequence.  With 0 it runs ONE kernel that takes the table
+ * offsets from a chained scan across workgroups (decoupled look-back); results
+ * are identical, but on MI355X each in-kernel hand-off costs more than the extra
+ * pass over the packed planes, so it is kept as a cross-check only. */
+#define CRP_OPT_TWO_PASS 1
+int crp_configure(crp_ctx *ctx, int option, int64_t value);
+
 /* ---- measurement --------------------------------------------------------- */
 /* When enabled, every kernel launched by crp_scan_score is bracketed by HIP
  * events on the library's stream. */
 int crp_profile_enable(crp_ctx *ctx, int on);
 /* Sum of durations (ms) and launch count per kernel since the last reset:
- * index 0 = count pass, 1 = tile-offset scan, 2 = emit+score pass. */
+ * index 0 = count pass, 1 = tile-offset scan (both only with CRP_OPT_TWO_PASS),
+ * 2 = emit+score pass. */
 int crp_profile_read(crp_ctx *ctx, double ms[3], uint64_t launches[3], int reset);
 /* Blocks until everything queued on the library's stream has finished. */
 int crp_synchronize(crp_ctx *ctx);

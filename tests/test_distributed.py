@@ -1,0 +1,97 @@
+"""The N > 1 path on CPU: contig partitioning + the gatherv of per-rank hit tables
+(cropsr_amd.parallel) with torch.distributed's gloo backend, world_size 2 and 3.
+Per-rank tables come from the oracle here (no GPU in this suite); on the GPU the
+same code moves the HIP tables over RCCL."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _make_contigs():
+    rng = np.random.default_rng(21)
+    lens = [5000, 120, 90000, 31, 2500, 2500, 0, 40000, 777]
+    a = np.frombuffer(b"ACGTacgtNGGCC", dtype=np.uint8)
+    return [b"'" + rng.choice(a, n).tobytes() + b"')," for n in lens]
+
+
+def _worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    from cropsr_amd import parallel
+    from oracle import oracle
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    contigs = _make_contigs()
+    owner = parallel.partition_contigs([len(c) for c in contigs], world)
+    mine = [k for k, o in enumerate(owner) if o == rank]
+    # a rank-local "arena": contigs at 64-aligned offsets separated like the device arena
+    layout, off = [], 64
+    cols = {c: [] for c in parallel.COLUMNS}
+    for k in mine:
+        h = oracle.scan_score(contigs[k])
+        layout.append((k, off, len(contigs[k])))
+        cols["pos_plus"].append(h["pos_plus"] + np.uint32(off))
+        cols["score_plus"].append(h["score_plus"])
+        cols["pos_minus"].append(h["pos_minus"] + np.uint32(off))
+        cols["score_minus"].append(h["score_minus"])
+        off += ((len(contigs[k]) + 63) // 64 + 1) * 64
+    cat = lambda xs, dt: np.concatenate(xs).astype(dt) if xs else np.empty(0, dtype=dt)
+    tables = {"pos_plus": torch.from_numpy(cat(cols["pos_plus"], np.uint32).view(np.int32)),
+              "score_plus": torch.from_numpy(cat(cols["score_plus"], np.float64)),
+              "pos_minus": torch.from_numpy(cat(cols["pos_minus"], np.uint32).view(np.int32)),
+              "score_minus": torch.from_numpy(cat(cols["score_minus"], np.float64))}
+    layouts = [None] * world
+    dist.all_gather_object(layouts, layout)
+    gather = parallel.TableGather(dst=0)
+    for _ in range(2):  # twice: the receive buffers are reused
+        got = gather(tables)
+    if rank == 0:
+        merged = parallel.merge_gathered(
+            [{c: t[c].numpy() for c in parallel.COLUMNS} for t in got], owner, layouts)
+        ok = len(merged) == len(contigs)
+        for k, c in enumerate(contigs):
+            want = oracle.scan_score(c)
+            for col in parallel.COLUMNS:
+                w = want[col]
+                g = merged[k][col]
+                ok = ok and g.shape == w.shape and bool((g.view(np.uint8) == w.view(np.uint8)).all())
+        with open(out_path, "w") as f:
+            f.write("ok" if ok else "mismatch")
+    else:
+        assert got is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_gatherv_over_gloo(world, tmp_path, oracle):
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "result.txt")
+    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert open(out).read() == "ok"
+
+
+def test_partition_is_balanced_and_deterministic():
+    from cropsr_amd import parallel
+    lens = [81, 70, 66, 64, 62, 61, 59, 58, 57, 55] + [1] * 857
+    a = parallel.partition_contigs(lens, 8)
+    assert a == parallel.partition_contigs(lens, 8)
+    load = [sum(n for n, o in zip(lens, a) if o == r) for r in range(8)]
+    assert max(load) - min(load) <= max(lens)
+    assert parallel.partition_contigs([5, 4, 3], 1) == [0, 0, 0]
+    assert sorted(set(parallel.partition_contigs([1] * 16, 4))) == [0, 1, 2, 3]

@@ -230,6 +230,30 @@ def test_deterministic_and_repeatable(engine):
     arena.close()
 
 
+def test_single_pass_equals_two_pass(engine):
+    """crp_scan_score's one-kernel mode (chained scan across workgroups) and the
+    count / scan / emit sequence must produce identical tables; poly-G forces the
+    'tables too small, repeat with exact sizes' path of the one-kernel mode."""
+    rng = np.random.default_rng(77)
+    contigs = [rng.choice(np.frombuffer(b"ACGTacgtNGGCC", dtype=np.uint8), n).tobytes()
+               for n in (1, 70000, 16384 * 3, 500000, 123)]
+    contigs.append(b"G" * 200000)
+    results = []
+    for two_pass in (False, True, False):
+        engine.configure(two_pass=two_pass)
+        arena = engine.arena(contigs)
+        results.append(arena.scan_score(20, want_pre=True))
+        again = arena.scan_score(20, want_pre=True)  # second scan: sizes now known
+        for name in ("pos_plus", "pre_plus", "score_plus", "pos_minus", "pre_minus", "score_minus"):
+            assert (bits(getattr(results[-1], name)) == bits(getattr(again, name))).all()
+        arena.close()
+    engine.configure(two_pass=True)  # the default
+    for name in ("pos_plus", "pre_plus", "score_plus", "pos_minus", "pre_minus", "score_minus"):
+        assert (bits(getattr(results[0], name)) == bits(getattr(results[1], name))).all(), name
+        assert (bits(getattr(results[0], name)) == bits(getattr(results[2], name))).all(), name
+    assert results[0].n_plus > 200000
+
+
 def test_medium_genome_vs_oracle(engine, oracle):
     """A 6 Mb multi-contig arena with soft-masked runs and N runs, compared hit by
     hit (positions, pre, score) with the oracle."""
@@ -320,3 +344,55 @@ def test_full_size_properties(engine):
         assert not (f["score_plus"][i + 5 <= per] == -1.0).any()
     af.close()
     ar.close()
+
+
+# ------------------------------------------------------- multi-GPU plumbing
+def test_device_table_views_are_zero_copy(engine):
+    """parallel.device_tables_as_tensors: torch views of the library's HBM tables."""
+    import torch
+    from cropsr_amd import parallel
+    rng = np.random.default_rng(8)
+    arena = engine.arena([rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), 200000).tobytes()])
+    n_plus, n_minus = arena.scan_score_device(20)
+    t = parallel.device_tables_as_tensors(arena, n_plus, n_minus)
+    cols = arena.fetch(n_plus, n_minus)
+    assert t["pos_plus"].is_cuda and t["pos_plus"].data_ptr() == arena.device_tables()[0]
+    assert (t["pos_plus"].cpu().numpy().view(np.uint32) == cols[0]).all()
+    assert (bits(t["score_plus"].cpu().numpy()) == bits(cols[2])).all()
+    assert (t["pos_minus"].cpu().numpy().view(np.uint32) == cols[3]).all()
+    assert (bits(t["score_minus"].cpu().numpy()) == bits(cols[5])).all()
+    arena.close()
+
+
+def _nccl_world1(out_path):
+    import torch
+    import torch.distributed as dist
+    from cropsr_amd import Engine, parallel
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    eng = Engine(0)
+    arena = eng.arena([b"ACGGTCCAGGTTCCAAGG" * 500])
+    n_plus, n_minus = arena.scan_score_device(20)
+    got = parallel.TableGather(dst=0)(parallel.device_tables_as_tensors(arena, n_plus, n_minus))
+    ok = len(got) == 1 and got[0]["pos_plus"].numel() == n_plus and got[0]["score_minus"].numel() == n_minus
+    dist.barrier()
+    dist.destroy_process_group()
+    arena.close()
+    eng.close()
+    with open(out_path, "w") as f:
+        f.write("ok" if ok else "bad")
+
+
+def test_gather_runs_on_rccl_backend(tmp_path):
+    """The bench's N > 1 code path on the real backend (RCCL), as far as one GPU allows:
+    world_size 1, in a child process."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "r.txt")
+    ctx = mp.get_context("spawn")
+    p = ctx.Process(target=_nccl_world1, args=(out,))
+    p.start()
+    p.join(300)
+    assert p.exitcode == 0
+    assert open(out).read() == "ok"

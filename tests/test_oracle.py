@@ -81,3 +81,18 @@ def test_sample_avx512_scores_within_2ulp(oracle, sample_fasta_text):
     avx = np.load(os.path.join(GOLDEN, "sample_avx512_scores.npy"))
     assert ours.size == avx.size
     assert np.abs(ours.view(np.int64) - avx.view(np.int64)).max() <= 2
+
+
+def test_big_chunk_csv_md5_cpu(oracle, manifest, tmp_path, monkeypatch):
+    """> 1 000 000 hits on one contig (reference quirks B.4/B.5: broken final chunk,
+    backwards ids): oracle hits + product host logic == md5 of a real reference run."""
+    r = np.random.default_rng(12345)
+    seq = np.frombuffer(b"ACGT", dtype=np.uint8)[r.integers(0, 4, 9000000)].tobytes().decode()
+    fa = tmp_path / "big.fa"
+    with open(fa, "w") as f:
+        f.write(">chrBig\n")
+        f.write("\n".join(seq[i:i + 80] for i in range(0, len(seq), 80)))
+        f.write("\n")
+    got, _ = run_cli(tmp_path, monkeypatch, str(fa), oracle_scan_provider(oracle), manifest["seed"])
+    assert got.count(b"\r\n") - 1 == manifest["cases"]["big9m"]["rows"]
+    assert hashlib.md5(got).hexdigest() == manifest["cases"]["big9m"]["md5_libm"]
