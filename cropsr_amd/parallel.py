@@ -16,6 +16,12 @@ state but the append-only list), so the path shards by contig:
 
 torch.distributed is plumbing only (RCCL bootstrap, streams); backend "nccl" is
 RCCL on ROCm, and the same code runs on "gloo" with CPU tensors for the tests.
+
+Process set-up note: PyTorch-ROCm wheels bundle their own HIP/HSA runtime.  A
+process that uses both PyTorch and libcropsr_hip.so must `import torch` BEFORE the
+first cropsr_amd.Engine is created, so that one runtime (torch's) serves both;
+the other order leaves torch without a visible GPU.  Without PyTorch the library
+simply uses the system ROCm runtime.
 """
 import numpy as np
 
@@ -50,6 +56,9 @@ def device_tables_as_tensors(arena, n_plus, n_minus):
     next scan on this arena.
     """
     import torch
+    if not torch.cuda.is_available():
+        raise RuntimeError("torch sees no GPU: import torch before creating the cropsr_amd Engine "
+                           "(see the process set-up note in cropsr_amd/parallel.py)")
     pp, sp, pm, sm = arena.device_tables()
     dev = torch.device("cuda", torch.cuda.current_device())
 

@@ -12,6 +12,8 @@ import os
 
 import numpy as np
 import pytest
+import torch  # noqa: F401  -- before libcropsr_hip.so: PyTorch-ROCm bundles its own HIP
+#                runtime, and the one that initialises first must be torch's (parallel.py)
 
 from conftest import GOLDEN, PROBES, golden_fasta_path, read_golden_csv, run_cli
 
