@@ -43,6 +43,7 @@ struct crp_ctx {
     double *d_rpre = nullptr, *d_rscore = nullptr;
     uint64_t d_rows_cap = 0;
     bool two_pass = true;  // CRP_OPT_TWO_PASS
+    int emit_blocks = 0;   // CRP_OPT_PERSISTENT_EMIT: workgroups of the persistent emit kernel (0 = one per tile)
     // measurement
     bool profiling = false;
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -127,6 +128,7 @@ int crp_init(int device_id, crp_ctx **out)
             crp_destroy(ctx);
             return CRP_ERR_HIP;
         }
+    ctx->emit_blocks = 0;  // one workgroup per tile: measured faster than the persistent form
     *out = ctx;
     return CRP_OK;
 }
@@ -441,7 +443,7 @@ static int scan_two_pass(crp_arena *a, const crp::Planes &pl, uint64_t eff_words
         }
         const crp::HitTables out = table_args(a, want_pre);
         prof_begin(ctx, 2);
-        CRP_HIP(ctx, crp::launch_emit(ctx->stream, pl, eff_words, guide_len, a->d_tile_off, out));
+        CRP_HIP(ctx, crp::launch_emit(ctx->stream, pl, eff_words, guide_len, a->d_tile_off, out, ctx->emit_blocks));
         prof_end(ctx, 2);
         CRP_HIP(ctx, hipStreamSynchronize(ctx->stream));
         n[0] = a->h_totals[0];
@@ -600,6 +602,10 @@ int crp_configure(crp_ctx *ctx, int option, int64_t value)
     if (!ctx) return CRP_ERR_INVALID;
     switch (option) {
         case CRP_OPT_TWO_PASS: ctx->two_pass = value != 0; return CRP_OK;
+        case CRP_OPT_PERSISTENT_EMIT:
+            if (value < 0) return CRP_ERR_INVALID;
+            ctx->emit_blocks = value == 1 ? ctx->n_cu * crp::emit_stream_blocks_per_cu() : (int)value;
+            return CRP_OK;
         default: return CRP_ERR_INVALID;
     }
 }

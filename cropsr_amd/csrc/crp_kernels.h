@@ -28,8 +28,11 @@ struct HitTables {
 hipError_t launch_count(hipStream_t s, const Planes &pl, uint64_t n_words_padded, int l, uint2 *tile_cnt);
 hipError_t launch_tile_scan(hipStream_t s, const uint2 *tile_cnt, uint32_t n_tiles, uint2 *tile_off,
                             uint64_t *totals);
+// persistent_blocks > 0: the software-pipelined persistent kernel with that many workgroups;
+// 0: one workgroup per tile
 hipError_t launch_emit(hipStream_t s, const Planes &pl, uint64_t n_words_padded, int l, const uint2 *tile_off,
-                       const HitTables &out);
+                       const HitTables &out, int persistent_blocks);
+int emit_stream_blocks_per_cu();
 // single-pass mode: `chain` = chain_bytes(n_tiles) bytes of device scratch, zeroed by the launcher
 size_t chain_bytes(uint32_t n_tiles);
 hipError_t launch_emit_chained(hipStream_t s, const Planes &pl, uint64_t n_words_padded, int l, uint64_t *chain,

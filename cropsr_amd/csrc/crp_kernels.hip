@@ -121,10 +121,34 @@ __device__ __forceinline__ uint64_t wave_inclusive_scan(uint64_t v)
 // Block-wide exclusive scan of a packed (plus | minus << 32) count.
 // `wave_tot` is LDS scratch of BLOCK/64 entries.  Returns the exclusive prefix,
 // sets `total` to the block total.
+// The per-lane counts are small (<= 64*WPT per strand), so both fit one 32-bit
+// word as 16-bit fields and the wave scan is six DPP adds (row_shr 1,2,4,8 inside
+// each row of 16 lanes, then row_bcast:15 / row_bcast:31 across rows) instead of
+// twelve 64-bit shuffles through the LDS crossbar.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_add(uint32_t v)
+{
+    // lanes without a source (or outside ROW_MASK) contribute 0
+    return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, true);
+}
+
+__device__ __forceinline__ uint32_t wave_inclusive_scan_u32(uint32_t v)
+{
+    v = dpp_add<0x111, 0xf>(v);  // row_shr:1
+    v = dpp_add<0x112, 0xf>(v);  // row_shr:2
+    v = dpp_add<0x114, 0xf>(v);  // row_shr:4
+    v = dpp_add<0x118, 0xf>(v);  // row_shr:8
+    v = dpp_add<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+    v = dpp_add<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
 __device__ __forceinline__ uint64_t block_exclusive_scan(uint64_t v, uint64_t *wave_tot, uint64_t &total)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint64_t inc = wave_inclusive_scan(v);
+    const uint32_t v16 = (uint32_t)v | ((uint32_t)(v >> 32) << 16);  // plus | minus << 16
+    const uint32_t inc16 = wave_inclusive_scan_u32(v16);
+    const uint64_t inc = (uint64_t)(inc16 & 0xffffu) | ((uint64_t)(inc16 >> 16) << 32);
     if (lane == 63) wave_tot[wave] = inc;
     __syncthreads();
     uint64_t base = 0, tot = 0;
@@ -224,7 +248,10 @@ __global__ __launch_bounds__(BLOCK) void count_kernel(Planes pl, uint64_t n_word
 }
 
 // ------------------------------------------------- pass 2: tile offset scan
-// One workgroup; exclusive scan of the per-tile counts, totals as 64-bit.
+// Exclusive scan of the per-tile counts, one workgroup per chunk of 8192 tiles.
+// A workgroup first sums the counts of all EARLIER chunks itself (a few hundred KB
+// of L2-resident reads) instead of waiting for other workgroups, so the chunks run
+// in parallel with no hand-off; the last workgroup also publishes the totals.
 __global__ __launch_bounds__(1024) void tile_scan_kernel(const uint2 *__restrict__ tile_cnt, uint32_t n_tiles,
                                                           uint2 *__restrict__ tile_off,
                                                           uint64_t *__restrict__ totals)
@@ -237,8 +264,31 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(const uint2 *__restrict
     __shared__ uint64_t buf[CHUNK];
     __shared__ uint64_t wave_tot[16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t base = blockIdx.x * CHUNK;
     uint64_t carry = 0;
-    for (uint32_t base = 0; base < n_tiles; base += CHUNK) {
+    {
+        uint64_t acc = 0;
+        // `base` is a multiple of 8192: eight independent 16-byte loads in flight per thread
+        const ulonglong2 *cnt2 = reinterpret_cast<const ulonglong2 *>(tile_cnt);
+        for (uint32_t i = threadIdx.x; i < base / 2; i += 4096) {
+            ulonglong2 c[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) c[k] = cnt2[i + k * 1024];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                // each 64-bit element is one uint2 {plus, minus}: already the packed form
+                acc += c[k].x + c[k].y;
+            }
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) acc += __shfl_xor(acc, d, 64);
+        if (lane == 0) wave_tot[wave] = acc;
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < 16; ++w) carry += wave_tot[w];
+        __syncthreads();
+    }
+    {
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
             const uint32_t i = base + k * 1024 + threadIdx.x;
@@ -280,9 +330,8 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(const uint2 *__restrict
             const uint64_t v = buf[k * 1024 + threadIdx.x];
             if (i < n_tiles) tile_off[i] = make_uint2((uint32_t)v, (uint32_t)(v >> 32));
         }
-        __syncthreads();
     }
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && blockIdx.x == gridDim.x - 1) {
         totals[0] = carry & 0xffffffffull;
         totals[1] = carry >> 32;
     }
@@ -385,6 +434,12 @@ __device__ __forceinline__ uint64_t lookback_exclusive(uint64_t *desc, uint32_t 
     return excl;
 }
 
+template <int WPT, int TW, int CAP>
+__device__ __forceinline__ void emit_rounds(uint64_t (*sh)[TW + 2], uint16_t *list, const uint64_t *exp_tab,
+                                            const uint64_t (&mp)[WPT], const uint64_t (&mm)[WPT], uint64_t ex,
+                                            uint32_t n_plus, uint32_t n_minus, int l, uint32_t tile_pos,
+                                            uint64_t off_plus, uint64_t off_minus, const HitTables &out);
+
 // CHAINED = true : single pass.  Tile ids come from an atomic ticket, table
 //                  offsets from the decoupled look-back above; `chain` holds
 //                  [0] ticket (u32) [1] fail flag (u32), then one descriptor per
@@ -451,8 +506,19 @@ __global__ __launch_bounds__(BLOCK) void emit_kernel(Planes pl, uint64_t n_words
         off_minus = off.y;
     }
     if (n_all == 0) return;
-    const uint32_t tile_pos = (uint32_t)(t0 * 64);
+    emit_rounds<WPT, TW, CAP>(sh, list, exp_tab, mp, mm, ex, n_plus, n_minus, l, (uint32_t)(t0 * 64), off_plus,
+                              off_minus, out);
+}
 
+// Compact the kept hits of one staged tile and score them, CAP list entries per round.
+template <int WPT, int TW, int CAP>
+__device__ __forceinline__ void emit_rounds(uint64_t (*sh)[TW + 2], uint16_t *list, const uint64_t *exp_tab,
+                                            const uint64_t (&mp)[WPT], const uint64_t (&mm)[WPT], uint64_t ex,
+                                            uint32_t n_plus, uint32_t n_minus, int l, uint32_t tile_pos,
+                                            uint64_t off_plus, uint64_t off_minus, const HitTables &out)
+{
+    const int tid = threadIdx.x;
+    const uint32_t n_all = n_plus + n_minus;
     for (uint32_t lo_rank = 0; lo_rank < n_all; lo_rank += CAP) {
         if (lo_rank) __syncthreads();  // previous round's readers are done
         // ---- compact: rank -> tile-local position, '+' hits first, then '-'
@@ -462,19 +528,27 @@ __global__ __launch_bounds__(BLOCK) void emit_kernel(Planes pl, uint64_t n_words
 #pragma unroll
             for (int k = 0; k < WPT; ++k) {
                 const uint32_t wbase = (uint32_t)(tid * WPT + k) * 64u;
-                uint64_t m = mp[k];
-                while (m) {
-                    const int b = __builtin_ctzll(m);
-                    m &= m - 1;
-                    if (rp < (uint32_t)CAP) list[rp] = (uint16_t)(wbase + b);
-                    ++rp;
+                // 32-bit halves: find-first-bit, clear-lowest and the compare are one
+                // VALU instruction each instead of two
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    uint32_t m = (uint32_t)(mp[k] >> (32 * half));
+                    while (m) {
+                        const uint32_t b = __builtin_ctz(m);
+                        m &= m - 1;
+                        if (rp < (uint32_t)CAP) list[rp] = (uint16_t)(wbase + 32 * half + b);
+                        ++rp;
+                    }
                 }
-                m = mm[k];
-                while (m) {
-                    const int b = __builtin_ctzll(m);
-                    m &= m - 1;
-                    if (rm < (uint32_t)CAP) list[rm] = (uint16_t)(wbase + b);
-                    ++rm;
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    uint32_t m = (uint32_t)(mm[k] >> (32 * half));
+                    while (m) {
+                        const uint32_t b = __builtin_ctz(m);
+                        m &= m - 1;
+                        if (rm < (uint32_t)CAP) list[rm] = (uint16_t)(wbase + 32 * half + b);
+                        ++rm;
+                    }
                 }
             }
         }
@@ -537,6 +611,81 @@ __global__ __launch_bounds__(BLOCK) void emit_kernel(Planes pl, uint64_t n_words
                 }
             }
         }
+    }
+}
+
+// Persistent, software-pipelined form of the emit pass (offsets from tile_off).
+// A workgroup walks tiles blockIdx.x, +gridDim.x, ...; the global loads of the NEXT
+// tile are issued into registers before the current tile is compacted and scored,
+// and land in LDS when that is done -- so the HBM latency of every tile but the
+// first hides under ~10 us of VALU work instead of depending on how the phases of
+// co-resident workgroups happen to interleave.
+template <int WPT>
+__global__ __launch_bounds__(BLOCK) void emit_stream_kernel(Planes pl, uint64_t n_words_padded, uint32_t n_tiles,
+                                                             int l, const uint2 *__restrict__ tile_off,
+                                                             HitTables out)
+{
+    static_assert(WPT == 1, "register prefetch below is written for 256-word tiles");
+    constexpr int TW = BLOCK * WPT;
+    constexpr int CAP = 2048 * WPT;
+    __shared__ uint64_t sh[4][TW + 2];
+    __shared__ uint64_t exp_tab[256];
+    __shared__ uint64_t wave_tot[BLOCK / 64];
+    __shared__ uint16_t list[CAP];
+    const int tid = threadIdx.x;
+    exp_tab[tid] = CRP_EXP_TAB[tid];
+
+    // prefetch registers: two 16-byte body loads per thread + one halo word for tid < 8
+    constexpr int PAIRS = TW / 2;
+    ulonglong2 body[2];
+    uint64_t halo = 0;
+    auto fetch = [&](uint32_t tile) {
+        const uint64_t t0 = (uint64_t)tile * TW;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int q = tid + it * BLOCK;
+            body[it] = *reinterpret_cast<const ulonglong2 *>(pl.plane[q / PAIRS] + t0 + 2 * (q % PAIRS));
+        }
+        if (tid < 8) {
+            const int p = tid >> 1;
+            const uint64_t voidw = (p < 2) ? ALL : 0ull;
+            if (tid & 1) {
+                const uint64_t idx = t0 + TW;
+                halo = idx < n_words_padded ? pl.plane[p][idx] : voidw;
+            } else {
+                halo = t0 > 0 ? pl.plane[p][t0 - 1] : voidw;
+            }
+        }
+    };
+    auto commit = [&]() {  // prefetched registers -> LDS tile image
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int q = tid + it * BLOCK;
+            sh[q / PAIRS][1 + 2 * (q % PAIRS)] = body[it].x;
+            sh[q / PAIRS][2 + 2 * (q % PAIRS)] = body[it].y;
+        }
+        if (tid < 8) sh[tid >> 1][(tid & 1) ? TW + 1 : 0] = halo;
+    };
+
+    uint32_t tile = blockIdx.x;
+    if (tile < n_tiles) fetch(tile);
+    for (; tile < n_tiles; tile += gridDim.x) {
+        commit();
+        __syncthreads();
+        const uint32_t next = tile + gridDim.x;
+        if (next < n_tiles) fetch(next);  // in flight while this tile is processed
+
+        uint64_t mp[WPT], mm[WPT];
+        thread_masks<WPT, TW>(sh, l, mp, mm);
+        uint64_t c = 0;
+#pragma unroll
+        for (int k = 0; k < WPT; ++k) c += (uint64_t)__popcll(mp[k]) | ((uint64_t)__popcll(mm[k]) << 32);
+        uint64_t total;
+        const uint64_t ex = block_exclusive_scan(c, wave_tot, total);
+        const uint2 off = tile_off[tile];
+        emit_rounds<WPT, TW, CAP>(sh, list, exp_tab, mp, mm, ex, (uint32_t)total, (uint32_t)(total >> 32), l,
+                                  (uint32_t)((uint64_t)tile * TW * 64), off.x, off.y, out);
+        __syncthreads();  // everyone is done with sh / list / wave_tot before the next tile lands
     }
 }
 
@@ -676,18 +825,34 @@ hipError_t launch_count(hipStream_t s, const Planes &pl, uint64_t n_words_padded
 hipError_t launch_tile_scan(hipStream_t s, const uint2 *tile_cnt, uint32_t n_tiles, uint2 *tile_off,
                             uint64_t *totals)
 {
-    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, s, tile_cnt, n_tiles, tile_off, totals);
+    hipLaunchKernelGGL(tile_scan_kernel, dim3((n_tiles + 8191) / 8192), dim3(1024), 0, s, tile_cnt, n_tiles, tile_off,
+                       totals);
     return hipGetLastError();
 }
 
 hipError_t launch_emit(hipStream_t s, const Planes &pl, uint64_t n_words_padded, int l, const uint2 *tile_off,
-                       const HitTables &out)
+                       const HitTables &out, int persistent_blocks)
 {
     constexpr int TW = BLOCK * TILE_WPT;
     const uint32_t n_tiles = (uint32_t)(n_words_padded / TW);
-    hipLaunchKernelGGL((emit_kernel<TILE_WPT, false>), dim3(n_tiles), dim3(BLOCK), 0, s, pl, n_words_padded, l,
-                       tile_off, (uint64_t *)nullptr, (uint64_t *)nullptr, out);
+    if (persistent_blocks > 0) {
+        const uint32_t grid = n_tiles < (uint32_t)persistent_blocks ? n_tiles : (uint32_t)persistent_blocks;
+        hipLaunchKernelGGL((emit_stream_kernel<TILE_WPT>), dim3(grid), dim3(BLOCK), 0, s, pl, n_words_padded, n_tiles,
+                           l, tile_off, out);
+    } else {
+        hipLaunchKernelGGL((emit_kernel<TILE_WPT, false>), dim3(n_tiles), dim3(BLOCK), 0, s, pl, n_words_padded, l,
+                           tile_off, (uint64_t *)nullptr, (uint64_t *)nullptr, out);
+    }
     return hipGetLastError();
+}
+
+// Workgroups of the persistent emit kernel that are resident on one CU.
+int emit_stream_blocks_per_cu()
+{
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, emit_stream_kernel<TILE_WPT>, BLOCK, 0) != hipSuccess || n < 1)
+        n = 4;
+    return n;
 }
 
 size_t chain_bytes(uint32_t n_tiles) { return 16 + (size_t)n_tiles * sizeof(uint64_t); }

@@ -23,8 +23,24 @@ __device__ const uint64_t CRP_EXP_TAB[256] = {
 #include "exp_table.inc"
 };
 
+// Pre-scaled weights in evaluation order.  As literals they cost two s_mov_b32 per
+// term on the CU's shared scalar ALU; fetching them from constant memory with wide
+// scalar loads (CRP_WEIGHTS_IN_CONSTANT_MEMORY) was measured SLOWER (0.79 vs 0.65 ms
+// for the emit kernel: s_waitcnt lgkmcnt(0) also drains the LDS reads), so literals
+// are the default.
+#if defined(CRP_WEIGHTS_IN_CONSTANT_MEMORY)
+__constant__ double CRP_WS_MEM[CRP_WS_COUNT] = CRP_WS_TABLE;
+#define CRP_WS(i) (CRP_WS_MEM[i])
+#else
+static constexpr double CRP_WS_LIT[CRP_WS_COUNT] = CRP_WS_TABLE;
+#define CRP_WS(i) (CRP_WS_LIT[i])
+#endif
+
 #define CRP_TERM(acc, copy, bit, wc) \
     acc = __builtin_fma(__hiloint2double((int)((copy) & (1u << (bit))), 0), (wc), acc);
+// second order: both bases tested in the gate (three-input AND = one v_bitop3_b32)
+#define CRP_TERM2(acc, copy1, copy2, bit, wc) \
+    acc = __builtin_fma(__hiloint2double((int)((copy1) & (copy2) & (1u << (bit))), 0), (wc), acc);
 
 // exp(x) for |x| < 512.  `tab` points at a copy of CRP_EXP_TAB (LDS).
 __device__ __forceinline__ double crp_exp(double x, const uint64_t *tab)

@@ -233,11 +233,16 @@ class Engine:
             score[base:base + 2] = self.score_30mers(sequences[base:base + 2], nat.ORDER_TAIL2)[1]
         return score
 
-    def configure(self, two_pass=None):
-        """two_pass=True: count / scan / emit launches instead of the single chained
-        kernel (same results; cross-check)."""
+    def configure(self, two_pass=None, persistent_emit=None):
+        """two_pass=False: one chained-scan kernel instead of count / scan / emit;
+        persistent_emit=0: one workgroup per tile instead of the pipelined persistent
+        emit kernel (1 = default sizing, n > 1 = that many workgroups).  Same results
+        either way; the options exist for cross-checks and A/B timing."""
         if two_pass is not None:
             nat.check(nat.lib().crp_configure(self._ctx, nat.OPT_TWO_PASS, int(bool(two_pass))), "crp_configure")
+        if persistent_emit is not None:
+            nat.check(nat.lib().crp_configure(self._ctx, nat.OPT_PERSISTENT_EMIT, int(persistent_emit)),
+                      "crp_configure")
 
     # ---- measurement
     def profile(self, on=True):

@@ -149,6 +149,12 @@ int crp_score_30mers(crp_ctx *ctx, const uint8_t *rows, uint64_t n, int order, d
  * are identical, but on MI355X each in-kernel hand-off costs more than the extra
  * pass over the packed planes, so it is kept as a cross-check only. */
 #define CRP_OPT_TWO_PASS 1
+/* CRP_OPT_PERSISTENT_EMIT (default 0 = one workgroup per tile): with 1 the emit+score
+ * pass runs as a persistent, software-pipelined kernel (one grid that fills the
+ * chip, next tile prefetched while the current one is scored); a value > 1 sets the
+ * number of workgroups explicitly.  Results are identical; the per-tile form
+ * balances the uneven hit counts of tiles better and measured faster. */
+#define CRP_OPT_PERSISTENT_EMIT 2
 int crp_configure(crp_ctx *ctx, int option, int64_t value);
 
 /* ---- measurement --------------------------------------------------------- */
