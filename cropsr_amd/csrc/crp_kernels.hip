@@ -201,9 +201,13 @@ __device__ __forceinline__ uint64_t counts_of(uint64_t g_c, uint64_t g_n, uint64
     return (uint64_t)__popcll(mplus) | ((uint64_t)__popcll(m) << 32);
 }
 
-__global__ __launch_bounds__(BLOCK) void count_kernel(Planes pl, uint64_t n_words_padded, int l,
+// LFIX > 0: guide length known at compile time (20, the reference's default), so
+// every funnel shift has a constant amount and becomes one v_alignbit_b32 per half.
+template <int LFIX>
+__global__ __launch_bounds__(BLOCK) void count_kernel(Planes pl, uint64_t n_words_padded, int l_arg,
                                                        uint2 *__restrict__ tile_cnt)
 {
+    const int l = LFIX > 0 ? LFIX : l_arg;
     static_assert(TILE_WORDS == 256 && BLOCK == 256, "two waves per emit tile");
     __shared__ uint64_t wave_tot[BLOCK / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -448,11 +452,12 @@ __device__ __forceinline__ void emit_rounds(uint64_t (*sh)[TW + 2], uint16_t *li
 //                  published by the last tile.
 // CHAINED = false: third pass of the count / scan / emit sequence (offsets from
 //                  tile_off); kept as the cross-check for the single-pass mode.
-template <int WPT, bool CHAINED>
-__global__ __launch_bounds__(BLOCK) void emit_kernel(Planes pl, uint64_t n_words_padded, int l,
+template <int WPT, bool CHAINED, int LFIX>
+__global__ __launch_bounds__(BLOCK) void emit_kernel(Planes pl, uint64_t n_words_padded, int l_arg,
                                                       const uint2 *__restrict__ tile_off, uint64_t *chain,
                                                       uint64_t *__restrict__ totals, HitTables out)
 {
+    const int l = LFIX > 0 ? LFIX : l_arg;
     constexpr int TW = BLOCK * WPT;
     constexpr int CAP = 2048 * WPT;  // list entries per round; typical tiles need one round
     __shared__ uint64_t sh[4][TW + 2];
@@ -620,11 +625,12 @@ __device__ __forceinline__ void emit_rounds(uint64_t (*sh)[TW + 2], uint16_t *li
 // and land in LDS when that is done -- so the HBM latency of every tile but the
 // first hides under ~10 us of VALU work instead of depending on how the phases of
 // co-resident workgroups happen to interleave.
-template <int WPT>
+template <int WPT, int LFIX>
 __global__ __launch_bounds__(BLOCK) void emit_stream_kernel(Planes pl, uint64_t n_words_padded, uint32_t n_tiles,
-                                                             int l, const uint2 *__restrict__ tile_off,
+                                                             int l_arg, const uint2 *__restrict__ tile_off,
                                                              HitTables out)
 {
+    const int l = LFIX > 0 ? LFIX : l_arg;
     static_assert(WPT == 1, "register prefetch below is written for 256-word tiles");
     constexpr int TW = BLOCK * WPT;
     constexpr int CAP = 2048 * WPT;
@@ -818,7 +824,10 @@ hipError_t launch_count(hipStream_t s, const Planes &pl, uint64_t n_words_padded
 {
     constexpr int TW = BLOCK * TILE_WPT;
     const uint32_t n_tiles = (uint32_t)(n_words_padded / TW);
-    hipLaunchKernelGGL(count_kernel, dim3((n_tiles + 1) / 2), dim3(BLOCK), 0, s, pl, n_words_padded, l, tile_cnt);
+    if (l == 20)
+        hipLaunchKernelGGL(count_kernel<20>, dim3((n_tiles + 1) / 2), dim3(BLOCK), 0, s, pl, n_words_padded, l, tile_cnt);
+    else
+        hipLaunchKernelGGL(count_kernel<0>, dim3((n_tiles + 1) / 2), dim3(BLOCK), 0, s, pl, n_words_padded, l, tile_cnt);
     return hipGetLastError();
 }
 
@@ -837,10 +846,17 @@ hipError_t launch_emit(hipStream_t s, const Planes &pl, uint64_t n_words_padded,
     const uint32_t n_tiles = (uint32_t)(n_words_padded / TW);
     if (persistent_blocks > 0) {
         const uint32_t grid = n_tiles < (uint32_t)persistent_blocks ? n_tiles : (uint32_t)persistent_blocks;
-        hipLaunchKernelGGL((emit_stream_kernel<TILE_WPT>), dim3(grid), dim3(BLOCK), 0, s, pl, n_words_padded, n_tiles,
-                           l, tile_off, out);
+        if (l == 20)
+            hipLaunchKernelGGL((emit_stream_kernel<TILE_WPT, 20>), dim3(grid), dim3(BLOCK), 0, s, pl, n_words_padded,
+                               n_tiles, l, tile_off, out);
+        else
+            hipLaunchKernelGGL((emit_stream_kernel<TILE_WPT, 0>), dim3(grid), dim3(BLOCK), 0, s, pl, n_words_padded,
+                               n_tiles, l, tile_off, out);
+    } else if (l == 20) {
+        hipLaunchKernelGGL((emit_kernel<TILE_WPT, false, 20>), dim3(n_tiles), dim3(BLOCK), 0, s, pl, n_words_padded, l,
+                           tile_off, (uint64_t *)nullptr, (uint64_t *)nullptr, out);
     } else {
-        hipLaunchKernelGGL((emit_kernel<TILE_WPT, false>), dim3(n_tiles), dim3(BLOCK), 0, s, pl, n_words_padded, l,
+        hipLaunchKernelGGL((emit_kernel<TILE_WPT, false, 0>), dim3(n_tiles), dim3(BLOCK), 0, s, pl, n_words_padded, l,
                            tile_off, (uint64_t *)nullptr, (uint64_t *)nullptr, out);
     }
     return hipGetLastError();
@@ -850,7 +866,7 @@ hipError_t launch_emit(hipStream_t s, const Planes &pl, uint64_t n_words_padded,
 int emit_stream_blocks_per_cu()
 {
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, emit_stream_kernel<TILE_WPT>, BLOCK, 0) != hipSuccess || n < 1)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, emit_stream_kernel<TILE_WPT, 20>, BLOCK, 0) != hipSuccess || n < 1)
         n = 4;
     return n;
 }
@@ -864,7 +880,7 @@ hipError_t launch_emit_chained(hipStream_t s, const Planes &pl, uint64_t n_words
     const uint32_t n_tiles = (uint32_t)(n_words_padded / TW);
     hipError_t e = hipMemsetAsync(chain, 0, chain_bytes(n_tiles), s);  // ticket, fail flag, descriptors
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((emit_kernel<TILE_WPT, true>), dim3(n_tiles), dim3(BLOCK), 0, s, pl, n_words_padded, l,
+    hipLaunchKernelGGL((emit_kernel<TILE_WPT, true, 0>), dim3(n_tiles), dim3(BLOCK), 0, s, pl, n_words_padded, l,
                        (const uint2 *)nullptr, chain, totals, out);
     return hipGetLastError();
 }

@@ -24,10 +24,10 @@ __device__ const uint64_t CRP_EXP_TAB[256] = {
 };
 
 // Pre-scaled weights in evaluation order.  As literals they cost two s_mov_b32 per
-// term on the CU's shared scalar ALU; fetching them from constant memory with wide
-// scalar loads (CRP_WEIGHTS_IN_CONSTANT_MEMORY) was measured SLOWER (0.79 vs 0.65 ms
-// for the emit kernel: s_waitcnt lgkmcnt(0) also drains the LDS reads), so literals
-// are the default.
+// term on the CU's shared scalar ALU.  Measured alternatives, both SLOWER for the emit
+// kernel (0.64 ms with literals): wide scalar loads from constant memory 0.79 ms
+// (CRP_WEIGHTS_IN_CONSTANT_MEMORY; s_waitcnt lgkmcnt(0) also drains the LDS reads),
+// uniform ds_read_b64 from LDS 1.11 ms.  Literals are the default.
 #if defined(CRP_WEIGHTS_IN_CONSTANT_MEMORY)
 __constant__ double CRP_WS_MEM[CRP_WS_COUNT] = CRP_WS_TABLE;
 #define CRP_WS(i) (CRP_WS_MEM[i])
