@@ -438,7 +438,7 @@ __device__ __forceinline__ uint64_t lookback_exclusive(uint64_t *desc, uint32_t 
     return excl;
 }
 
-template <int WPT, int TW, int CAP>
+template <int WPT, int TW, int CAP, bool PAM>
 __device__ __forceinline__ void emit_rounds(uint64_t (*sh)[TW + 2], uint16_t *list, const uint64_t *exp_tab,
                                             const uint64_t (&mp)[WPT], const uint64_t (&mm)[WPT], uint64_t ex,
                                             uint32_t n_plus, uint32_t n_minus, int l, uint32_t tile_pos,
@@ -511,12 +511,12 @@ __global__ __launch_bounds__(BLOCK) void emit_kernel(Planes pl, uint64_t n_words
         off_minus = off.y;
     }
     if (n_all == 0) return;
-    emit_rounds<WPT, TW, CAP>(sh, list, exp_tab, mp, mm, ex, n_plus, n_minus, l, (uint32_t)(t0 * 64), off_plus,
+    emit_rounds<WPT, TW, CAP, LFIX == 20>(sh, list, exp_tab, mp, mm, ex, n_plus, n_minus, l, (uint32_t)(t0 * 64), off_plus,
                               off_minus, out);
 }
 
 // Compact the kept hits of one staged tile and score them, CAP list entries per round.
-template <int WPT, int TW, int CAP>
+template <int WPT, int TW, int CAP, bool PAM>
 __device__ __forceinline__ void emit_rounds(uint64_t (*sh)[TW + 2], uint16_t *list, const uint64_t *exp_tab,
                                             const uint64_t (&mp)[WPT], const uint64_t (&mm)[WPT], uint64_t ex,
                                             uint32_t n_plus, uint32_t n_minus, int l, uint32_t tile_pos,
@@ -595,7 +595,7 @@ __device__ __forceinline__ void emit_rounds(uint64_t (*sh)[TW + 2], uint16_t *li
 #if defined(CRP_EXPERIMENT_NO_SCORE)
                     score = __hiloint2double((int)(mA ^ mT), (int)(mC ^ mG));
 #else
-                    crp_score_masks(mA, mT, mC, mG, exp_tab, pre, score);
+                    crp_score_masks<PAM>(mA, mT, mC, mG, exp_tab, pre, score);
 #endif
                 }
             }
@@ -689,7 +689,7 @@ __global__ __launch_bounds__(BLOCK) void emit_stream_kernel(Planes pl, uint64_t 
         uint64_t total;
         const uint64_t ex = block_exclusive_scan(c, wave_tot, total);
         const uint2 off = tile_off[tile];
-        emit_rounds<WPT, TW, CAP>(sh, list, exp_tab, mp, mm, ex, (uint32_t)total, (uint32_t)(total >> 32), l,
+        emit_rounds<WPT, TW, CAP, LFIX == 20>(sh, list, exp_tab, mp, mm, ex, (uint32_t)total, (uint32_t)(total >> 32), l,
                                   (uint32_t)((uint64_t)tile * TW * 64), off.x, off.y, out);
         __syncthreads();  // everyone is done with sh / list / wave_tot before the next tile lands
     }
@@ -717,7 +717,7 @@ __global__ __launch_bounds__(BLOCK) void score30_kernel(const uint8_t *__restric
             mG |= (uint32_t)(ch == 'G') << p;
         }
         double pre, score;
-        crp_score_masks(mA, mT, mC, mG, exp_tab, pre, score);
+        crp_score_masks<false>(mA, mT, mC, mG, exp_tab, pre, score);
         if (pre_out) pre_out[i] = pre;
         score_out[i] = score;
     }

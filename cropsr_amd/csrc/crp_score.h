@@ -71,12 +71,22 @@ __device__ __forceinline__ double crp_exp(double x, const uint64_t *tab)
 }
 
 // pre = -(s1 + s2 + intersect + low_gc)  (CROPSR.py:312), score = 1/(1+exp(pre)) (:313)
+// PAM = true: the row is a window found by the PAM scan with guide length 20, whose
+// characters 3 and 4 are always 'C' (SURVEY.md A.3); the four terms that test those
+// positions are folded into the chain start values / dropped by the generator.
+template <bool PAM>
 __device__ __forceinline__ void crp_score_masks(uint32_t mA, uint32_t mT, uint32_t mC, uint32_t mG,
                                                 const uint64_t *exp_tab, double &pre, double &score)
 {
-    double fA = 0.0, fT = 0.0, fC = 0.0, fG = 0.0;
-    double sA = 0.0, sT = 0.0, sC = 0.0, sG = 0.0;
-    CRP_SCORE_BODY(mA, mT, mC, mG)
+    double fA = PAM ? CRP_PAM_INIT_fA : 0.0, fT = PAM ? CRP_PAM_INIT_fT : 0.0;
+    double fC = PAM ? CRP_PAM_INIT_fC : 0.0, fG = PAM ? CRP_PAM_INIT_fG : 0.0;
+    double sA = PAM ? CRP_PAM_INIT_sA : 0.0, sT = PAM ? CRP_PAM_INIT_sT : 0.0;
+    double sC = PAM ? CRP_PAM_INIT_sC : 0.0, sG = PAM ? CRP_PAM_INIT_sG : 0.0;
+    if (PAM) {
+        CRP_SCORE_BODY_PAM(mA, mT, mC, mG)
+    } else {
+        CRP_SCORE_BODY(mA, mT, mC, mG)
+    }
     const double s1 = (fA + fC) + (fT + fG);
     const double s2 = (sA + sC) + (sT + sG);
     pre = (((s1 + s2) + CRP_INTERSECT) + CRP_LOW_GC) * -1.0;
