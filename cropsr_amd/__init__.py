@@ -4,7 +4,7 @@ Drop-in accelerator for the inner loop of H2muller/CROPSR (CROPSR.py:409-474):
 hand-written HIP kernels for gfx950 behind a C ABI (include/cropsr_hip.h),
 bound here with ctypes.  See DESIGN.md and INTEGRATION.md.
 """
-from .engine import Arena, Engine, Hits, pack_ascii  # noqa: F401
+from .engine import Arena, Engine, Genome, Hits, pack_ascii  # noqa: F401
 from ._native import CropsrHipError  # noqa: F401
 
-__all__ = ["Engine", "Arena", "Hits", "pack_ascii", "CropsrHipError"]
+__all__ = ["Engine", "Arena", "Genome", "Hits", "pack_ascii", "CropsrHipError"]

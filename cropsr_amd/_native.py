@@ -27,6 +27,7 @@ SIGNATURES = {
                                        ctypes.POINTER(ctypes.c_int), u64p]),
     "crp_arena_words_for": (ctypes.c_uint64, [ctypes.c_uint64]),
     "crp_arena_words_total": (ctypes.c_uint64, [ctypes.c_uint64]),
+    "crp_arena_max_words": (ctypes.c_uint64, []),
     "crp_pack_ascii": (ctypes.c_int, [u8p, ctypes.c_uint64, u64p, u64p, u64p, u64p, ctypes.c_int]),
     "crp_arena_create": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, voidpp]),
     "crp_arena_destroy": (ctypes.c_int, [ctypes.c_void_p]),

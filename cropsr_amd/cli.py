@@ -93,10 +93,10 @@ class EngineBackend:
 
     def scan(self, contig_strings, guide_len):
         """One arena pass on the GPU for all contig strings (seam 1 + 2)."""
-        arena = self.engine.arena(contig_strings)
-        hits = arena.scan_score(guide_len, want_pre=False)
+        genome = self.engine.genome(contig_strings)  # as many arenas as the genome needs
+        hits = genome.scan_score(guide_len, want_pre=False)
         out = [hits.contig(k) for k in range(len(contig_strings))]
-        arena.close()
+        genome.close()
         return out
 
     def rescore(self, rows_u8, order):

@@ -166,6 +166,7 @@ int crp_device_info(const crp_ctx *ctx, char *name, int name_cap, int *n_cu, uin
 // ---------------------------------------------------------------- host pack
 uint64_t crp_arena_words_for(uint64_t len) { return (len + 63) / 64 + 1; }
 uint64_t crp_arena_words_total(uint64_t sum) { return sum + 1; }
+uint64_t crp_arena_max_words(void) { return kMaxArenaWords; }
 
 static void pack_range(const uint8_t *text, uint64_t len, uint64_t w0, uint64_t w1, const uint8_t *lut,
                        uint64_t *hi, uint64_t *lo, uint64_t *up, uint64_t *ac)

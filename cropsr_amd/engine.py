@@ -198,6 +198,10 @@ class Engine:
         self._arenas.add(a)
         return a
 
+    def genome(self, contigs, max_words=None, pack="device"):
+        """Like arena(), for inputs that may exceed one arena (2^31 characters)."""
+        return Genome(self, contigs, max_words, pack)
+
     def arena_builder(self, lengths):
         """Incremental upload for genomes too big to hold as one list: give the
         contig string lengths up front, then add() each string in that order."""
@@ -288,6 +292,54 @@ class ArenaBuilder:
         self._engine._arenas.add(a)
         self._h = None
         return a
+
+
+class Genome:
+    """Any number of contigs spread over as many arenas as needed (one arena holds
+    fewer than 2^31 characters).  Contigs keep their order; a contig never spans
+    two arenas."""
+
+    def __init__(self, engine, contigs, max_words=None, pack="device"):
+        L = nat.lib()
+        limit = int(max_words) if max_words else int(L.crp_arena_max_words())
+        bufs = [_as_u8(c) for c in contigs]
+        groups, cur, used = [], [], 1
+        for k, b in enumerate(bufs):
+            need = int(L.crp_arena_words_for(b.size))
+            if need + 1 > limit:
+                raise ValueError("contig %d (%d characters) does not fit one arena" % (k, b.size))
+            if used + need > limit and cur:
+                groups.append(cur)
+                cur, used = [], 1
+            cur.append(k)
+            used += need
+        if cur or not groups:
+            groups.append(cur)
+        self.arenas = [engine.arena([bufs[k] for k in g], pack=pack) for g in groups]
+        self._where = {}
+        for a, g in enumerate(groups):
+            for j, k in enumerate(g):
+                self._where[k] = (a, j)
+        self.n_contigs = len(bufs)
+
+    def scan_score(self, guide_len=20, want_pre=False):
+        return GenomeHits(self, [a.scan_score(guide_len, want_pre) for a in self.arenas])
+
+    def close(self):
+        for a in self.arenas:
+            a.close()
+
+
+class GenomeHits:
+    def __init__(self, genome, per_arena):
+        self._genome = genome
+        self.per_arena = per_arena
+        self.n_plus = sum(h.n_plus for h in per_arena)
+        self.n_minus = sum(h.n_minus for h in per_arena)
+
+    def contig(self, k):
+        a, j = self._genome._where[k]
+        return self.per_arena[a].contig(j)
 
 
 def pack_ascii(text, n_threads=1):

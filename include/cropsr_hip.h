@@ -74,6 +74,9 @@ uint64_t crp_arena_words_for(uint64_t len);
 /* Arena words needed for contigs whose crp_arena_words_for() sum is `sum`
  * (adds the leading and trailing separator words). */
 uint64_t crp_arena_words_total(uint64_t sum);
+/* Largest capacity_words crp_arena_create accepts (arena positions stay below 2^31);
+ * a bigger genome is spread over several arenas, contig by contig. */
+uint64_t crp_arena_max_words(void);
 /* Classify `len` characters into the four bit-planes the kernels read, 64
  * characters per word, bit k of word w = character 64*w + k:
  *   hi,lo  2-bit base code, alphabet order of CROPSR.py:300 (A=00 T=01 C=10 G=11)

@@ -348,6 +348,27 @@ def test_full_size_properties(engine):
     ar.close()
 
 
+def test_genome_spread_over_several_arenas(engine, oracle):
+    """Inputs beyond one arena (2^31 characters) are split contig by contig; forced here
+    with a tiny per-arena limit.  Results must not depend on the split."""
+    rng = np.random.default_rng(55)
+    a = np.frombuffer(b"ACGTacgtNGGCC", dtype=np.uint8)
+    contigs = [rng.choice(a, n).tobytes() for n in (3000, 10, 0, 7000, 6400, 64, 129, 5000)]
+    one = engine.genome(contigs)
+    many = engine.genome(contigs, max_words=120)  # 120 words = 7680 characters per arena
+    assert len(one.arenas) == 1 and len(many.arenas) >= 4
+    h1, hm = one.scan_score(20, want_pre=True), many.scan_score(20, want_pre=True)
+    assert (h1.n_plus, h1.n_minus) == (hm.n_plus, hm.n_minus)
+    for k, c in enumerate(contigs):
+        want = oracle.scan_score(c, 20)
+        assert_hits_equal(h1.contig(k), want, ctx=("one", k))
+        assert_hits_equal(hm.contig(k), want, ctx=("many", k))
+    with pytest.raises(ValueError):
+        engine.genome([b"A" * 10000], max_words=100)
+    one.close()
+    many.close()
+
+
 # ------------------------------------------------------- multi-GPU plumbing
 def test_device_table_views_are_zero_copy(engine):
     """parallel.device_tables_as_tensors: torch views of the library's HBM tables."""
