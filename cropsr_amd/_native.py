@@ -40,6 +40,8 @@ SIGNATURES = {
     "crp_fetch_hits": (ctypes.c_int, [ctypes.c_void_p, u32p, f64p, f64p, u32p, f64p, f64p]),
     "crp_hits_device": (ctypes.c_int, [ctypes.c_void_p, voidpp, voidpp, voidpp, voidpp]),
     "crp_score_30mers": (ctypes.c_int, [ctypes.c_void_p, u8p, ctypes.c_uint64, ctypes.c_int, f64p, f64p]),
+    "crp_format_rows": (ctypes.c_int, [u8p, ctypes.c_uint64, u8p, ctypes.c_uint64, ctypes.c_int, u32p, u8p, f64p,
+                                       u8p, ctypes.c_uint64, u8p, ctypes.c_uint64, u64p, ctypes.c_int]),
     "crp_configure": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int64]),
     "crp_profile_enable": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "crp_profile_read": (ctypes.c_int, [ctypes.c_void_p, f64p, u64p, ctypes.c_int]),

@@ -59,6 +59,8 @@ def build_parser():
     eng.add_argument("--device", type=int, default=0, help="HIP device index, default = 0")
     eng.add_argument("--seed", type=int, default=None,
                      help="seed numpy's global RNG so crispr_id is reproducible (reference: unseeded)")
+    eng.add_argument("--csv-writer", choices=["native", "python"], default="native",
+                     help="native: multi-threaded C++ row formatter (same bytes); python: csv module like the reference")
     eng.add_argument("--reference-sleep", action="store_true",
                      help="also reproduce the reference's 5 s pause per contig")
     return p
@@ -171,11 +173,12 @@ def run(args, backend=None, out=sys.stdout):
         backend = EngineBackend(getattr(args, "device", 0))
     all_hits = backend.scan(strings, args.l)  # seam 1 + 2 for every contig, one GPU pass
 
-    dataset = rows.Dataset()  # Complete_dataset, CROPSR.py:407
+    native = getattr(args, "csv_writer", "native") == "native"
+    dataset = rows.NativeDataset() if native else rows.Dataset()  # Complete_dataset, CROPSR.py:407
     for name, s, hits in zip(names, strings, all_hits):
         print("Searching on Chromosome: ", name[:25], file=out)  # CROPSR.py:410-411
         print("With start of sequence: ", s[:25], file=out)
-        block = rows.ContigRows(name, s, hits, args.l)
+        block = (rows.ContigTable if native else rows.ContigRows)(name, s, hits, args.l)
         dataset.append(block)
         if verbose:
             # CROPSR.py:436-439 counts regex matches BEFORE the keep-filter; the
@@ -185,7 +188,7 @@ def run(args, backend=None, out=sys.stdout):
             print(f"""
                 {n_sites:n} Cas9 PAM sites were found on {name[1::]}
                 """, file=out)
-        rows.write_pass(args.o, dataset, backend.rescore)  # CROPSR.py:442-474
+        (rows.write_pass_native if native else rows.write_pass)(args.o, dataset, backend.rescore)  # CROPSR.py:442-474
         end = time.time()
         timing.write("Total runtime of the program is " + str(end - begin))  # CROPSR.py:477
         if getattr(args, "reference_sleep", False):

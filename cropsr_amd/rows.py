@@ -16,6 +16,7 @@ Reference behaviours preserved on purpose:
   B.7  CRLF line ends, minimal quoting, shortest-repr floats.
 """
 import csv
+import ctypes
 
 import numpy as np
 
@@ -195,3 +196,121 @@ def write_pass(path, dataset, rescore):
         ids = make_ids(size)
         for index_range, count in flush_plan(size):
             writer.writerows(dataset.rows(index_range, count, ids, index_range, rescore))
+
+
+# ----------------------------------------------------------------------------
+# Native output path: the same bytes without a Python object per
+# row.  ContigTable keeps a contig's rows as arrays; NativeDataset formats each
+# written chunk with crp_format_rows (cropsr_amd/csrc/crp_format.cpp).  The tuple
+# path above stays as the executable specification the native one is tested against.
+class ContigTable:
+    """Array form of ContigRows: same rows, same order, no per-row Python objects."""
+
+    def __init__(self, name_token, s, hits, guide_len):
+        self.guide_len = guide_len
+        self.chrom = name_token[1:].encode("utf-8")
+        self.s = s
+        self.text = np.frombuffer(s.encode("ascii", "replace"), dtype=np.uint8)
+        self.n_plus = int(hits["pos_plus"].size)
+        self.pos = np.ascontiguousarray(np.concatenate([hits["pos_plus"], hits["pos_minus"]]), dtype=np.uint32)
+        self.minus = np.zeros(self.pos.size, dtype=np.uint8)
+        self.minus[self.n_plus:] = 1
+        self.score = np.ascontiguousarray(np.concatenate([hits["score_plus"], hits["score_minus"]]), dtype=np.float64)
+        self.n = int(self.pos.size)
+
+    def long_text(self, k):
+        l, p = self.guide_len, int(self.pos[k])
+        if self.minus[k]:
+            return minus_text(self.s, p + 3 - 5, p + 3 + l + 5)
+        return plus_text(self.s, p - l - 5, p + 5)
+
+
+class NativeDataset:
+    """Complete_dataset over ContigTables + the chunk formatter."""
+
+    def __init__(self, n_threads=8):
+        self.blocks = []
+        self.starts = [0]
+        self.n_threads = n_threads
+
+    def append(self, block):
+        self.blocks.append(block)
+        self.starts.append(self.starts[-1] + block.n)
+
+    def __len__(self):
+        return self.starts[-1]
+
+    def chunk_bytes(self, lo, count, ids_u8, index_range, rescore):
+        """CSV bytes of dataset[lo:lo+count], one rs1_score batch of the reference
+        (ids consumed backwards, tail rows re-scored: see Dataset.rows)."""
+        from . import _native as nat
+        L = nat.lib()
+        size = len(self)
+        hi = min(lo + count, size)
+        n = hi - lo
+        if n <= 0:
+            return b""
+        sel = ids_u8[index_range - np.arange(n) - 1]  # negative indices wrap like Python's
+        if n == 1:
+            special, order = [0], ORDER_DOT1
+        elif n % 4 >= 2:
+            special, order = [4 * (n // 4), 4 * (n // 4) + 1], ORDER_TAIL2
+        else:
+            special, order = [], ORDER_BODY4
+        out = []
+        b = int(np.searchsorted(self.starts, lo, "right") - 1)
+        g = lo
+        while g < hi:
+            blk = self.blocks[b]
+            base = self.starts[b]
+            k0, k1 = g - base, min(hi - base, blk.n)
+            m = k1 - k0
+            if m > 0:
+                score = blk.score[k0:k1]
+                fix = [(i - (g - lo)) for i in special if g - lo <= i < g - lo + m]
+                fix = [j for j in fix if len(blk.long_text(k0 + j)) == 30]
+                if fix:
+                    score = score.copy()
+                    seqs = np.empty((len(fix), 30), dtype=np.uint8)
+                    for r, j in enumerate(fix):
+                        t = blk.long_text(k0 + j).replace("U", "T").upper()  # CROPSR.py:458
+                        seqs[r] = np.frombuffer(t.encode("ascii", "replace"), dtype=np.uint8)
+                    score[fix] = rescore(seqs, order)
+                ids_part = np.ascontiguousarray(sel[g - lo:g - lo + m])
+                pos = blk.pos[k0:k1]
+                minus = blk.minus[k0:k1]
+                cap = m * (170 + 2 * len(blk.chrom)) + 64
+                while True:
+                    buf = np.empty(cap, dtype=np.uint8)
+                    used = ctypes.c_uint64()
+                    st = L.crp_format_rows(
+                        blk.text.ctypes.data_as(nat.u8p), blk.text.size,
+                        ctypes.cast(ctypes.c_char_p(blk.chrom), nat.u8p), len(blk.chrom), blk.guide_len,
+                        pos.ctypes.data_as(nat.u32p), minus.ctypes.data_as(nat.u8p),
+                        score.ctypes.data_as(nat.f64p), ids_part.ctypes.data_as(nat.u8p), m,
+                        buf.ctypes.data_as(nat.u8p), cap, ctypes.byref(used), self.n_threads)
+                    if st == -6 and used.value > cap:  # CRP_ERR_CAPACITY: retry with the size it asked for
+                        cap = int(used.value)
+                        continue
+                    nat.check(st, "crp_format_rows")
+                    break
+                out.append(buf[:used.value].tobytes())
+            g = base + blk.n
+            b += 1
+        return b"".join(out)
+
+
+def ids_as_bytes(ids_u1):
+    """(size,7) '<U1' array from np.random.choice -> (size,7) uint8."""
+    a = np.ascontiguousarray(ids_u1)
+    return a.view(np.uint32).astype(np.uint8).reshape(a.shape[0], 7) if a.size else np.empty((0, 7), np.uint8)
+
+
+def write_pass_native(path, dataset, rescore):
+    """write_pass with the native formatter: same RNG draws, same chunk walk, same bytes."""
+    size = len(dataset)
+    alphanum = np.array(list("ABCDEFGHIJKLMNOPQRSTUVWXYZ0123456789"), dtype="|U1")
+    ids_u8 = ids_as_bytes(np.random.choice(alphanum, [size, 7]))
+    with open(path, "ab") as f:
+        for index_range, count in flush_plan(size):
+            f.write(dataset.chunk_bytes(index_range, count, ids_u8, index_range, rescore))

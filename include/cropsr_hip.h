@@ -145,6 +145,22 @@ int crp_hits_device(crp_arena *arena, void **pos_plus, void **score_plus,
  * NULL. */
 int crp_score_30mers(crp_ctx *ctx, const uint8_t *rows, uint64_t n, int order, double *pre, double *score);
 
+/* ---- output side: native CSV rows (host code, no GPU needed) ---------------- */
+/* Formats n_rows rows of ONE contig exactly as the reference's row tuples go through
+ * csv.writer.writerows (CROPSR.py:463-474; strings as at :420-421 / :431-432):
+ *   contig_text/contig_len  the contig string (1 byte per character)
+ *   chrom/chrom_len         the chromosome column text (CROPSR.py:422 chromosome[1::])
+ *   pos[r], minus[r]        regex match index and strand (0 '+', 1 '-') of row r
+ *   score[r]                on_site_score of row r (ignored when long_sequence != 30 chars)
+ *   ids                     n_rows x 7 bytes, the crispr_id of each row
+ * Output: the CSV bytes ("\r\n" line ends, minimal quoting, repr() floats, 11-field rows
+ * with -1 where the reference writes them).  Returns CRP_ERR_CAPACITY with the needed size
+ * in *out_len when out_cap is too small. */
+int crp_format_rows(const uint8_t *contig_text, uint64_t contig_len, const uint8_t *chrom, uint64_t chrom_len,
+                    int guide_len, const uint32_t *pos, const uint8_t *minus, const double *score,
+                    const uint8_t *ids, uint64_t n_rows, uint8_t *out, uint64_t out_cap, uint64_t *out_len,
+                    int n_threads);
+
 /* ---- options -------------------------------------------------------------- */
 /* CRP_OPT_TWO_PASS (value 0/1, default 1): crp_scan_score runs the count / tile-scan
  * / emit+score launch sequence.  With 0 it runs ONE kernel that takes the table

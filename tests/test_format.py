@@ -1,0 +1,95 @@
+"""crp_format_rows (native CSV row formatter) against Python's csv
+module fed with the reference-style row tuples (rows.ContigRows, itself pinned by
+the golden CSVs).  CPU only: the formatter is host code."""
+import csv
+import io
+import struct
+
+import numpy as np
+import pytest
+
+from cropsr_amd import rows
+
+
+def _python_csv(block, ids):
+    buf = io.StringIO(newline="")
+    csv.writer(buf).writerows([block.row(k, ids[k]) for k in range(block.n)])
+    return buf.getvalue().encode("utf-8")
+
+
+def _native_csv(table, ids_u8, threads=1):
+    ds = rows.NativeDataset(n_threads=threads)
+    ds.append(table)
+    # identity id order: chunk_bytes uses ids[index_range - index - 1]; feed it reversed
+    rev = ids_u8[::-1].copy()
+    return ds.chunk_bytes(0, table.n, rev, table.n, lambda seqs, order: pytest.fail("no tail rows expected"))
+
+
+def _ids(n, rng):
+    alpha = np.frombuffer(b"ABCDEFGHIJKLMNOPQRSTUVWXYZ0123456789", dtype=np.uint8)
+    u8 = rng.choice(alpha, (n, 7))
+    return u8, ["".join(map(chr, r)) for r in u8.tolist()]
+
+
+@pytest.mark.parametrize("alphabet", [b"ACGT", b"ACGTacgtNUZ", b"ACGT,\"'\r\n)]\\ "])
+@pytest.mark.parametrize("l", [20, 21, 5])
+def test_native_rows_equal_python_csv(oracle, alphabet, l):
+    rng = np.random.default_rng(len(alphabet) * 100 + l)
+    for n in (0, 40, 400, 5000):
+        s = rng.choice(np.frombuffer(alphabet, dtype=np.uint8), n).tobytes().decode("latin-1")
+        for name in ("[('c1',", ">plain", '("we"ird,'):
+            hits = oracle.scan_score(s.encode("latin-1"), l)
+            block = rows.ContigRows(name, s, hits, l)
+            table = rows.ContigTable(name, s, hits, l)
+            if block.n % 4 in (2, 3) or block.n == 1:  # keep clear of the tail-rescoring rule here
+                continue
+            ids_u8, ids = _ids(block.n, rng)
+            assert _native_csv(table, ids_u8) == _python_csv(block, ids)
+
+
+def test_float_repr_matches_python():
+    """put_repr == repr(float) over the whole double range, not just (0, 1)."""
+    rng = np.random.default_rng(3)
+    vals = [0.0, -0.0, 1.0, -1.0, 0.1, 1e-4, 9.999e-5, 1e-5, 1e15, 1e16, 9.999999999999999e15, 1e17, 1e22, 1e23,
+            5e-324, 2.2250738585072014e-308, 1.7976931348623157e308, 0.3, 2 / 3, 1 / 3, 123456789.125, 3e-8,
+            0.039739367071031644, 1.0000000000000002, 4.35e-5, 100.0, 1e100, 1.5e-100]
+    vals += [struct.unpack("<d", struct.pack("<Q", int(b)))[0]
+             for b in rng.integers(1, 0x7FEFFFFFFFFFFFFF, 20000, dtype=np.int64)]
+    vals += list(np.exp(rng.uniform(-40, 40, 5000)))
+    vals += list(1 / (1 + np.exp(rng.uniform(-10, 18, 5000))))
+    vals = [v for v in vals if v == v]
+    s = "A" * 25 + "GG" + "A" * 40  # one '+' hit at i = 24 ... make windows complete: build a contig with a known hit
+    s = "ACGTACGTACGTACGTACGTACGTAAGGACGTACGT"
+    # one row per value: reuse a single real hit position for every row
+    hits_pos = 25  # (?=.GG) at index 25: s[26:28] == 'GG'
+    assert s[26:28] == "GG"
+    n = len(vals)
+    table = rows.ContigTable(">x", s, dict(pos_plus=np.full(n, hits_pos, np.uint32), pos_minus=np.empty(0, np.uint32),
+                                           score_plus=np.array(vals), score_minus=np.empty(0)), 20)
+    ids_u8 = np.full((n, 7), ord("A"), dtype=np.uint8)
+    out = _native_csv(table, ids_u8, threads=4).decode().split("\r\n")[:-1]
+    assert len(out) == n
+    for line, v in zip(out, vals):
+        assert line.split(",")[9] == repr(float(v)), (line, v)
+
+
+def test_threads_do_not_change_bytes(oracle):
+    rng = np.random.default_rng(6)
+    s = "'" + rng.choice(np.frombuffer(b"ACGTacgtN", dtype=np.uint8), 400000).tobytes().decode() + "'),"
+    hits = oracle.scan_score(s.encode(), 20)
+    table = rows.ContigTable("[('c',", s, hits, 20)
+    if table.n % 4 in (2, 3):
+        table.pos, table.minus, table.score, table.n = table.pos[:-2], table.minus[:-2], table.score[:-2], table.n - 2
+    ids_u8, _ = _ids(table.n, rng)
+    one = _native_csv(table, ids_u8, threads=1)
+    assert one == _native_csv(table, ids_u8, threads=7)
+    assert one.count(b"\r\n") == table.n
+
+
+@pytest.mark.parametrize("writer", ["native", "python"])
+def test_cli_writers_agree_on_golden(writer, oracle, manifest, tmp_path, monkeypatch):
+    from conftest import golden_fasta_path, oracle_scan_provider, read_golden_csv, run_cli
+    for name in ("tiny", "rightend", "mixed"):
+        got, _ = run_cli(tmp_path, monkeypatch, golden_fasta_path(name, tmp_path), oracle_scan_provider(oracle),
+                         manifest["seed"], extra=("--csv-writer", writer))
+        assert got == read_golden_csv(name), (writer, name)
