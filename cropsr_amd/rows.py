@@ -309,8 +309,11 @@ def ids_as_bytes(ids_u1):
 def write_pass_native(path, dataset, rescore):
     """write_pass with the native formatter: same RNG draws, same chunk walk, same bytes."""
     size = len(dataset)
-    alphanum = np.array(list("ABCDEFGHIJKLMNOPQRSTUVWXYZ0123456789"), dtype="|U1")
-    ids_u8 = ids_as_bytes(np.random.choice(alphanum, [size, 7]))
+    # np.random.choice(alphanum, [size, 7]) IS alphanum[np.random.randint(0, 36, [size, 7])]
+    # (legacy RandomState.choice, uniform, with replacement): same draws, same RNG state
+    # afterwards (tests/test_format.py), without building a UCS-4 string array.
+    lut = np.frombuffer(b"ABCDEFGHIJKLMNOPQRSTUVWXYZ0123456789", dtype=np.uint8)
+    ids_u8 = lut[np.random.randint(0, 36, size=[size, 7])]
     with open(path, "ab") as f:
         for index_range, count in flush_plan(size):
             f.write(dataset.chunk_bytes(index_range, count, ids_u8, index_range, rescore))

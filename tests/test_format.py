@@ -93,3 +93,18 @@ def test_cli_writers_agree_on_golden(writer, oracle, manifest, tmp_path, monkeyp
         got, _ = run_cli(tmp_path, monkeypatch, golden_fasta_path(name, tmp_path), oracle_scan_provider(oracle),
                          manifest["seed"], extra=("--csv-writer", writer))
         assert got == read_golden_csv(name), (writer, name)
+
+
+def test_id_draws_equal_reference_choice():
+    """write_pass_native draws ids with randint + LUT; that must be the reference's
+    np.random.choice(alphanum, [size, 7]) (CROPSR.py:316-318) draw for draw."""
+    alphanum = np.array(list("ABCDEFGHIJKLMNOPQRSTUVWXYZ0123456789"), dtype="|U1")
+    lut = np.frombuffer(b"ABCDEFGHIJKLMNOPQRSTUVWXYZ0123456789", dtype=np.uint8)
+    for size in (0, 1, 2, 37, 10000):
+        np.random.seed(size + 5)
+        a = np.random.choice(alphanum, [size, 7])
+        after_a = np.random.random()
+        np.random.seed(size + 5)
+        b = lut[np.random.randint(0, 36, size=[size, 7])]
+        after_b = np.random.random()
+        assert (rows.ids_as_bytes(a) == b).all() and after_a == after_b
