@@ -13,6 +13,12 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # a fresh checkout has no binaries: build them once (hipcc cross-compiles without a GPU)
+    so = os.path.join(ROOT, "cropsr_amd", "libcropsr_hip.so")
+    orc = os.path.join(ROOT, "oracle", "liborc.so")
+    if not (os.path.exists(so) and os.path.exists(orc)):
+        import __graft_entry__
+        __graft_entry__.build()
 
 
 @pytest.fixture(scope="session")
