@@ -24,6 +24,7 @@ namespace {
 // descriptors carry two 31-bit counts in one 64-bit word
 constexpr uint64_t kMaxArenaWords = (1ull << 31) / 64 - 2 * crp::ARENA_ALIGN_WORDS;
 constexpr uint64_t kUploadChunk = 64ull << 20;  // characters per H2D + pack round (multiple of 4096)
+constexpr int kMaxSlices = 8;
 
 inline uint64_t round_up(uint64_t x, uint64_t m) { return (x + m - 1) / m * m; }
 
@@ -45,8 +46,11 @@ struct crp_ctx {
     bool two_pass = true;  // CRP_OPT_TWO_PASS
     int emit_blocks = 0;   // CRP_OPT_PERSISTENT_EMIT: workgroups of the persistent emit kernel (0 = one per tile)
     // measurement
-    bool profiling = false;
-    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    int profiling = 0;  // 0 off, 1 emit kernel only, 2 all kernels
+    hipStream_t stream2 = nullptr;             // count + scan of the next slice (CRP_OPT_SLICES)
+    int slices = 1;
+    hipEvent_t ev[6 * 8] = {};                 // profiling: (slice, kind) start/stop pairs
+    hipEvent_t ev_slice[8] = {};               // "counts and offsets of slice k are ready"
     double ms[3] = {0, 0, 0};
     uint64_t launches[3] = {0, 0, 0};
 };
@@ -123,8 +127,17 @@ int crp_init(int device_id, crp_ctx **out)
         delete ctx;
         return CRP_ERR_HIP;
     }
+    if (hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess) {
+        crp_destroy(ctx);
+        return CRP_ERR_HIP;
+    }
     for (auto &e : ctx->ev)
         if (hipEventCreate(&e) != hipSuccess) {
+            crp_destroy(ctx);
+            return CRP_ERR_HIP;
+        }
+    for (auto &e : ctx->ev_slice)
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
             crp_destroy(ctx);
             return CRP_ERR_HIP;
         }
@@ -138,8 +151,12 @@ int crp_destroy(crp_ctx *ctx)
     if (!ctx) return CRP_OK;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
     for (auto &e : ctx->ev)
         if (e) (void)hipEventDestroy(e);
+    for (auto &e : ctx->ev_slice)
+        if (e) (void)hipEventDestroy(e);
+    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     (void)hipFree(ctx->d_text);
     (void)hipFree(ctx->d_rows);
     (void)hipFree(ctx->d_rpre);
@@ -374,13 +391,26 @@ static int grow(crp_ctx *ctx, void **p, uint64_t *cap, uint64_t need, size_t ele
     return CRP_OK;
 }
 
-static void prof_begin(crp_ctx *ctx, int k)
+// event pair (kind, slice): kind 0 = count, 1 = tile scan, 2 = emit
+// profiling level 1 brackets only the emit kernel (the one the roofline is quoted on; two event
+// records per step), level 2 all three kernels
+static bool prof_on(const crp_ctx *ctx, int kind) { return ctx->profiling >= 2 || (ctx->profiling == 1 && kind == 2); }
+static void prof_begin(crp_ctx *ctx, int kind, int slice, hipStream_t s)
 {
-    if (ctx->profiling) (void)hipEventRecord(ctx->ev[2 * k], ctx->stream);
+    if (prof_on(ctx, kind)) (void)hipEventRecord(ctx->ev[(slice * 3 + kind) * 2], s);
 }
-static void prof_end(crp_ctx *ctx, int k)
+static void prof_end(crp_ctx *ctx, int kind, int slice, hipStream_t s)
 {
-    if (ctx->profiling) (void)hipEventRecord(ctx->ev[2 * k + 1], ctx->stream);
+    if (prof_on(ctx, kind)) (void)hipEventRecord(ctx->ev[(slice * 3 + kind) * 2 + 1], s);
+}
+static void prof_collect(crp_ctx *ctx, int kind, int slice)
+{
+    float ms = 0.f;
+    if (prof_on(ctx, kind) &&
+        hipEventElapsedTime(&ms, ctx->ev[(slice * 3 + kind) * 2], ctx->ev[(slice * 3 + kind) * 2 + 1]) == hipSuccess) {
+        ctx->ms[kind] += ms;
+        ctx->launches[kind] += 1;
+    }
 }
 
 static int reserve_tables(crp_arena *a, const uint64_t n[2], int want_pre)
@@ -408,50 +438,67 @@ static crp::HitTables table_args(const crp_arena *a, int want_pre)
                           want_pre ? std::min(a->tab_cap[1], a->pre_cap[1]) : a->tab_cap[1]};
 }
 
-static void prof_collect(crp_ctx *ctx, int k)
-{
-    float ms = 0.f;
-    if (ctx->profiling && hipEventElapsedTime(&ms, ctx->ev[2 * k], ctx->ev[2 * k + 1]) == hipSuccess) {
-        ctx->ms[k] += ms;
-        ctx->launches[k] += 1;
-    }
-}
-
-// count -> tile scan -> emit: three launches, exact table sizes known before the emit pass
+// count -> tile scan -> emit.  The tile range is cut into `slices` contiguous slices (whole scan
+// chunks); count + scan of slice k+1 run on a second stream while slice k is emitted on the main
+// one, because the count pass is HBM-bound and the emit pass is VALU-bound.  The table sizes must
+// be known before the first emit: once an arena has been scanned the tables exist and the emits
+// are queued speculatively (stores are bounds-checked, totals compared afterwards); the very
+// first scan of an arena waits for the totals instead.
 static int scan_two_pass(crp_arena *a, const crp::Planes &pl, uint64_t eff_words, int guide_len, int want_pre,
                          uint64_t n[2])
 {
     crp_ctx *ctx = a->ctx;
-    prof_begin(ctx, 0);
-    CRP_HIP(ctx, crp::launch_count(ctx->stream, pl, eff_words, guide_len, a->d_tile_cnt));
-    prof_end(ctx, 0);
-    prof_begin(ctx, 1);
-    CRP_HIP(ctx, crp::launch_tile_scan(ctx->stream, a->d_tile_cnt, a->n_tiles, a->d_tile_off, a->d_totals));
-    prof_end(ctx, 1);
-    CRP_HIP(ctx, hipMemcpyAsync(a->h_totals, a->d_totals, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-    // The totals are needed to size the tables.  Once this arena has been scanned
-    // the tables exist, so the emit pass is queued straight behind the scan (no
-    // host round trip in between); its stores are bounds-checked and the totals
-    // are compared with the capacities afterwards.
+    const uint32_t n_tiles = a->n_tiles;
+    const uint32_t n_chunks = (n_tiles + crp::SCAN_CHUNK_TILES - 1) / crp::SCAN_CHUNK_TILES;
     const bool speculative = a->tab_cap[0] && a->tab_cap[1] && (!want_pre || (a->pre_cap[0] && a->pre_cap[1]));
-    for (int attempt = 0; attempt < 2; ++attempt) {
-        if (!speculative || attempt == 1) {
-            if (attempt == 0) CRP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    int slices = speculative ? ctx->slices : 1;
+    if ((uint32_t)slices > n_chunks) slices = (int)n_chunks;
+    if (slices > kMaxSlices) slices = kMaxSlices;
+    if (slices < 1) slices = 1;
+    hipStream_t s_count = slices > 1 ? ctx->stream2 : ctx->stream;
+
+    crp::HitTables out = table_args(a, want_pre);
+    for (int k = 0; k < slices; ++k) {
+        const uint32_t c0 = (uint32_t)((uint64_t)n_chunks * k / slices), c1 = (uint32_t)((uint64_t)n_chunks * (k + 1) / slices);
+        const uint32_t t0 = c0 * crp::SCAN_CHUNK_TILES, t1 = std::min(n_tiles, c1 * crp::SCAN_CHUNK_TILES);
+        prof_begin(ctx, 0, k, s_count);
+        CRP_HIP(ctx, crp::launch_count(s_count, pl, eff_words, guide_len, a->d_tile_cnt, t0, t1 - t0));
+        prof_end(ctx, 0, k, s_count);
+        prof_begin(ctx, 1, k, s_count);
+        CRP_HIP(ctx, crp::launch_tile_scan(s_count, a->d_tile_cnt, n_tiles, a->d_tile_off, a->d_totals, c0, c1 - c0));
+        prof_end(ctx, 1, k, s_count);
+        if (slices > 1) {
+            CRP_HIP(ctx, hipEventRecord(ctx->ev_slice[k], s_count));
+            CRP_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_slice[k], 0));
+        }
+        if (!speculative) {
+            CRP_HIP(ctx, hipMemcpyAsync(a->h_totals, a->d_totals, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+            CRP_HIP(ctx, hipStreamSynchronize(ctx->stream));
             n[0] = a->h_totals[0];
             n[1] = a->h_totals[1];
             int rc = reserve_tables(a, n, want_pre);
             if (rc != CRP_OK) return rc;
+            out = table_args(a, want_pre);
         }
-        const crp::HitTables out = table_args(a, want_pre);
-        prof_begin(ctx, 2);
-        CRP_HIP(ctx, crp::launch_emit(ctx->stream, pl, eff_words, guide_len, a->d_tile_off, out, ctx->emit_blocks));
-        prof_end(ctx, 2);
-        CRP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        n[0] = a->h_totals[0];
-        n[1] = a->h_totals[1];
-        if (n[0] <= out.cap_plus && n[1] <= out.cap_minus) break;  // everything was stored
+        prof_begin(ctx, 2, k, ctx->stream);
+        CRP_HIP(ctx, crp::launch_emit(ctx->stream, pl, eff_words, guide_len, a->d_tile_off, out, ctx->emit_blocks, t0, t1 - t0));
+        prof_end(ctx, 2, k, ctx->stream);
     }
-    for (int k = 0; k < 3; ++k) prof_collect(ctx, k);
+    CRP_HIP(ctx, hipMemcpyAsync(a->h_totals, a->d_totals, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    CRP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < slices; ++k)
+        for (int kind = 0; kind < 3; ++kind) prof_collect(ctx, kind, k);
+    n[0] = a->h_totals[0];
+    n[1] = a->h_totals[1];
+    if (n[0] > out.cap_plus || n[1] > out.cap_minus) {
+        // a speculative run met more hits than the tables hold (e.g. another guide length):
+        // nothing was written out of bounds; size exactly and emit again
+        int rc = reserve_tables(a, n, want_pre);
+        if (rc != CRP_OK) return rc;
+        out = table_args(a, want_pre);
+        CRP_HIP(ctx, crp::launch_emit(ctx->stream, pl, eff_words, guide_len, a->d_tile_off, out, ctx->emit_blocks, 0, n_tiles));
+        CRP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
     return CRP_OK;
 }
 
@@ -470,9 +517,9 @@ static int scan_single_pass(crp_arena *a, const crp::Planes &pl, uint64_t eff_wo
         int rc = reserve_tables(a, want, want_pre);
         if (rc != CRP_OK) return rc;
         const crp::HitTables out = table_args(a, want_pre);
-        prof_begin(ctx, 2);
+        prof_begin(ctx, 2, 0, ctx->stream);
         CRP_HIP(ctx, crp::launch_emit_chained(ctx->stream, pl, eff_words, guide_len, a->d_chain, a->d_totals, out));
-        prof_end(ctx, 2);
+        prof_end(ctx, 2, 0, ctx->stream);
         CRP_HIP(ctx, hipMemcpyAsync(a->h_totals, a->d_totals, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
         CRP_HIP(ctx, hipMemcpyAsync(a->h_totals + 2, a->d_chain, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
         CRP_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -480,7 +527,7 @@ static int scan_single_pass(crp_arena *a, const crp::Planes &pl, uint64_t eff_wo
             ctx->last_error = "emit kernel: chained-scan look-back timed out";
             return CRP_ERR_HIP;
         }
-        prof_collect(ctx, 2);
+        prof_collect(ctx, 2, 0);
         n[0] = a->h_totals[0];
         n[1] = a->h_totals[1];
         if (n[0] <= out.cap_plus && n[1] <= out.cap_minus) return CRP_OK;
@@ -580,7 +627,7 @@ int crp_score_30mers(crp_ctx *ctx, const uint8_t *rows, uint64_t n, int order, d
 int crp_profile_enable(crp_ctx *ctx, int on)
 {
     if (!ctx) return CRP_ERR_INVALID;
-    ctx->profiling = on != 0;
+    ctx->profiling = on < 0 ? 0 : (on > 2 ? 2 : on);
     return CRP_OK;
 }
 
@@ -603,6 +650,10 @@ int crp_configure(crp_ctx *ctx, int option, int64_t value)
     if (!ctx) return CRP_ERR_INVALID;
     switch (option) {
         case CRP_OPT_TWO_PASS: ctx->two_pass = value != 0; return CRP_OK;
+        case CRP_OPT_SLICES:
+            if (value < 1 || value > kMaxSlices) return CRP_ERR_INVALID;
+            ctx->slices = (int)value;
+            return CRP_OK;
         case CRP_OPT_PERSISTENT_EMIT:
             if (value < 0) return CRP_ERR_INVALID;
             ctx->emit_blocks = value == 1 ? ctx->n_cu * crp::emit_stream_blocks_per_cu() : (int)value;

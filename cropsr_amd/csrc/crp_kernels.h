@@ -25,13 +25,18 @@ struct HitTables {
     uint64_t cap_minus;
 };
 
-hipError_t launch_count(hipStream_t s, const Planes &pl, uint64_t n_words_padded, int l, uint2 *tile_cnt);
+// The three passes can be launched on slices of the tile range (tile_first even, scan in chunks of
+// SCAN_CHUNK_TILES), so that the memory-bound count pass of slice k+1 overlaps the VALU-bound emit
+// pass of slice k on another stream.
+constexpr uint32_t SCAN_CHUNK_TILES = 8192;
+hipError_t launch_count(hipStream_t s, const Planes &pl, uint64_t n_words_padded, int l, uint2 *tile_cnt,
+                        uint32_t tile_first, uint32_t tile_count);
 hipError_t launch_tile_scan(hipStream_t s, const uint2 *tile_cnt, uint32_t n_tiles, uint2 *tile_off,
-                            uint64_t *totals);
+                            uint64_t *totals, uint32_t chunk_first, uint32_t chunk_count);
 // persistent_blocks > 0: the software-pipelined persistent kernel with that many workgroups;
 // 0: one workgroup per tile
 hipError_t launch_emit(hipStream_t s, const Planes &pl, uint64_t n_words_padded, int l, const uint2 *tile_off,
-                       const HitTables &out, int persistent_blocks);
+                       const HitTables &out, int persistent_blocks, uint32_t tile_first, uint32_t tile_count);
 int emit_stream_blocks_per_cu();
 // single-pass mode: `chain` = chain_bytes(n_tiles) bytes of device scratch, zeroed by the launcher
 size_t chain_bytes(uint32_t n_tiles);

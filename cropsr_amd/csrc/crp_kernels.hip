@@ -205,13 +205,14 @@ __device__ __forceinline__ uint64_t counts_of(uint64_t g_c, uint64_t g_n, uint64
 // every funnel shift has a constant amount and becomes one v_alignbit_b32 per half.
 template <int LFIX>
 __global__ __launch_bounds__(BLOCK) void count_kernel(Planes pl, uint64_t n_words_padded, int l_arg,
-                                                       uint2 *__restrict__ tile_cnt)
+                                                       uint2 *__restrict__ tile_cnt, uint32_t pair_first)
 {
     const int l = LFIX > 0 ? LFIX : l_arg;
+    const uint32_t pair = blockIdx.x + pair_first;  // this workgroup counts tiles 2*pair and 2*pair+1
     static_assert(TILE_WORDS == 256 && BLOCK == 256, "two waves per emit tile");
     __shared__ uint64_t wave_tot[BLOCK / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint64_t w0 = ((uint64_t)blockIdx.x * (BLOCK / 64) + wave) * 128;  // first word of this wave
+    const uint64_t w0 = ((uint64_t)pair * (BLOCK / 64) + wave) * 128;  // first word of this wave
     uint64_t c = 0;
     if (w0 < n_words_padded) {
         const uint64_t wa = w0 + 2 * lane;  // this lane owns words wa, wa+1
@@ -243,7 +244,7 @@ __global__ __launch_bounds__(BLOCK) void count_kernel(Planes pl, uint64_t n_word
     if (lane == 0) wave_tot[wave] = c;
     __syncthreads();
     if (threadIdx.x < 2) {
-        const uint64_t tile = (uint64_t)blockIdx.x * 2 + threadIdx.x;
+        const uint64_t tile = (uint64_t)pair * 2 + threadIdx.x;
         if (tile * TILE_WORDS < n_words_padded) {
             const uint64_t t = wave_tot[2 * threadIdx.x] + wave_tot[2 * threadIdx.x + 1];
             tile_cnt[tile] = make_uint2((uint32_t)t, (uint32_t)(t >> 32));
@@ -258,8 +259,9 @@ __global__ __launch_bounds__(BLOCK) void count_kernel(Planes pl, uint64_t n_word
 // in parallel with no hand-off; the last workgroup also publishes the totals.
 __global__ __launch_bounds__(1024) void tile_scan_kernel(const uint2 *__restrict__ tile_cnt, uint32_t n_tiles,
                                                           uint2 *__restrict__ tile_off,
-                                                          uint64_t *__restrict__ totals)
+                                                          uint64_t *__restrict__ totals, uint32_t chunk_first)
 {
+    const uint32_t chunk = blockIdx.x + chunk_first;
     // Chunks of 8192 tiles go through LDS: coalesced load, every thread scans its 8
     // consecutive entries, one scan of the 1024 thread sums, coalesced store.
     // Per-strand totals stay below 2^31, so the packed halves never carry into
@@ -268,7 +270,7 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(const uint2 *__restrict
     __shared__ uint64_t buf[CHUNK];
     __shared__ uint64_t wave_tot[16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t base = blockIdx.x * CHUNK;
+    const uint32_t base = chunk * CHUNK;
     uint64_t carry = 0;
     {
         uint64_t acc = 0;
@@ -335,7 +337,7 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(const uint2 *__restrict
             if (i < n_tiles) tile_off[i] = make_uint2((uint32_t)v, (uint32_t)(v >> 32));
         }
     }
-    if (threadIdx.x == 0 && blockIdx.x == gridDim.x - 1) {
+    if (threadIdx.x == 0 && base + CHUNK >= n_tiles) {  // the chunk that holds the last tile
         totals[0] = carry & 0xffffffffull;
         totals[1] = carry >> 32;
     }
@@ -455,7 +457,8 @@ __device__ __forceinline__ void emit_rounds(uint64_t (*sh)[TW + 2], uint16_t *li
 template <int WPT, bool CHAINED, int LFIX>
 __global__ __launch_bounds__(BLOCK) void emit_kernel(Planes pl, uint64_t n_words_padded, int l_arg,
                                                       const uint2 *__restrict__ tile_off, uint64_t *chain,
-                                                      uint64_t *__restrict__ totals, HitTables out)
+                                                      uint64_t *__restrict__ totals, HitTables out,
+                                                      uint32_t tile_first)
 {
     const int l = LFIX > 0 ? LFIX : l_arg;
     constexpr int TW = BLOCK * WPT;
@@ -468,7 +471,7 @@ __global__ __launch_bounds__(BLOCK) void emit_kernel(Planes pl, uint64_t n_words
     __shared__ uint16_t list[CAP];
 
     const int tid = threadIdx.x;
-    uint32_t tile = blockIdx.x;
+    uint32_t tile = blockIdx.x + tile_first;
     if (CHAINED) {
         if (tid == 0) s_tile = atomicAdd(reinterpret_cast<uint32_t *>(chain), 1u);
         __syncthreads();
@@ -820,31 +823,37 @@ __global__ __launch_bounds__(BLOCK) void pack_kernel(const uint8_t *__restrict__
 }
 
 // ------------------------------------------------------------ launch wrappers
-hipError_t launch_count(hipStream_t s, const Planes &pl, uint64_t n_words_padded, int l, uint2 *tile_cnt)
+// tile_first (even) .. tile_first + tile_count: the slice of tiles this launch covers
+hipError_t launch_count(hipStream_t s, const Planes &pl, uint64_t n_words_padded, int l, uint2 *tile_cnt,
+                        uint32_t tile_first, uint32_t tile_count)
 {
-    constexpr int TW = BLOCK * TILE_WPT;
-    const uint32_t n_tiles = (uint32_t)(n_words_padded / TW);
+    if (tile_count == 0) return hipSuccess;
+    const dim3 grid((tile_count + 1) / 2);
     if (l == 20)
-        hipLaunchKernelGGL(count_kernel<20>, dim3((n_tiles + 1) / 2), dim3(BLOCK), 0, s, pl, n_words_padded, l, tile_cnt);
+        hipLaunchKernelGGL(count_kernel<20>, grid, dim3(BLOCK), 0, s, pl, n_words_padded, l, tile_cnt, tile_first / 2);
     else
-        hipLaunchKernelGGL(count_kernel<0>, dim3((n_tiles + 1) / 2), dim3(BLOCK), 0, s, pl, n_words_padded, l, tile_cnt);
+        hipLaunchKernelGGL(count_kernel<0>, grid, dim3(BLOCK), 0, s, pl, n_words_padded, l, tile_cnt, tile_first / 2);
     return hipGetLastError();
 }
 
+// scan chunks (8192 tiles each) chunk_first .. chunk_first + chunk_count; the counts of all earlier
+// tiles must already be in tile_cnt
 hipError_t launch_tile_scan(hipStream_t s, const uint2 *tile_cnt, uint32_t n_tiles, uint2 *tile_off,
-                            uint64_t *totals)
+                            uint64_t *totals, uint32_t chunk_first, uint32_t chunk_count)
 {
-    hipLaunchKernelGGL(tile_scan_kernel, dim3((n_tiles + 8191) / 8192), dim3(1024), 0, s, tile_cnt, n_tiles, tile_off,
-                       totals);
+    if (chunk_count == 0) return hipSuccess;
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(chunk_count), dim3(1024), 0, s, tile_cnt, n_tiles, tile_off, totals,
+                       chunk_first);
     return hipGetLastError();
 }
 
 hipError_t launch_emit(hipStream_t s, const Planes &pl, uint64_t n_words_padded, int l, const uint2 *tile_off,
-                       const HitTables &out, int persistent_blocks)
+                       const HitTables &out, int persistent_blocks, uint32_t tile_first, uint32_t tile_count)
 {
     constexpr int TW = BLOCK * TILE_WPT;
     const uint32_t n_tiles = (uint32_t)(n_words_padded / TW);
-    if (persistent_blocks > 0) {
+    if (tile_count == 0) return hipSuccess;
+    if (persistent_blocks > 0 && tile_first == 0 && tile_count == n_tiles) {
         const uint32_t grid = n_tiles < (uint32_t)persistent_blocks ? n_tiles : (uint32_t)persistent_blocks;
         if (l == 20)
             hipLaunchKernelGGL((emit_stream_kernel<TILE_WPT, 20>), dim3(grid), dim3(BLOCK), 0, s, pl, n_words_padded,
@@ -853,11 +862,11 @@ hipError_t launch_emit(hipStream_t s, const Planes &pl, uint64_t n_words_padded,
             hipLaunchKernelGGL((emit_stream_kernel<TILE_WPT, 0>), dim3(grid), dim3(BLOCK), 0, s, pl, n_words_padded,
                                n_tiles, l, tile_off, out);
     } else if (l == 20) {
-        hipLaunchKernelGGL((emit_kernel<TILE_WPT, false, 20>), dim3(n_tiles), dim3(BLOCK), 0, s, pl, n_words_padded, l,
-                           tile_off, (uint64_t *)nullptr, (uint64_t *)nullptr, out);
+        hipLaunchKernelGGL((emit_kernel<TILE_WPT, false, 20>), dim3(tile_count), dim3(BLOCK), 0, s, pl, n_words_padded,
+                           l, tile_off, (uint64_t *)nullptr, (uint64_t *)nullptr, out, tile_first);
     } else {
-        hipLaunchKernelGGL((emit_kernel<TILE_WPT, false, 0>), dim3(n_tiles), dim3(BLOCK), 0, s, pl, n_words_padded, l,
-                           tile_off, (uint64_t *)nullptr, (uint64_t *)nullptr, out);
+        hipLaunchKernelGGL((emit_kernel<TILE_WPT, false, 0>), dim3(tile_count), dim3(BLOCK), 0, s, pl, n_words_padded,
+                           l, tile_off, (uint64_t *)nullptr, (uint64_t *)nullptr, out, tile_first);
     }
     return hipGetLastError();
 }
@@ -881,7 +890,7 @@ hipError_t launch_emit_chained(hipStream_t s, const Planes &pl, uint64_t n_words
     hipError_t e = hipMemsetAsync(chain, 0, chain_bytes(n_tiles), s);  // ticket, fail flag, descriptors
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((emit_kernel<TILE_WPT, true, 0>), dim3(n_tiles), dim3(BLOCK), 0, s, pl, n_words_padded, l,
-                       (const uint2 *)nullptr, chain, totals, out);
+                       (const uint2 *)nullptr, chain, totals, out, 0u);
     return hipGetLastError();
 }
 

@@ -237,7 +237,7 @@ class Engine:
             score[base:base + 2] = self.score_30mers(sequences[base:base + 2], nat.ORDER_TAIL2)[1]
         return score
 
-    def configure(self, two_pass=None, persistent_emit=None):
+    def configure(self, two_pass=None, persistent_emit=None, slices=None):
         """two_pass=False: one chained-scan kernel instead of count / scan / emit;
         persistent_emit=0: one workgroup per tile instead of the pipelined persistent
         emit kernel (1 = default sizing, n > 1 = that many workgroups).  Same results
@@ -247,10 +247,14 @@ class Engine:
         if persistent_emit is not None:
             nat.check(nat.lib().crp_configure(self._ctx, nat.OPT_PERSISTENT_EMIT, int(persistent_emit)),
                       "crp_configure")
+        if slices is not None:  # count/scan of slice k+1 overlap the emit of slice k on a second stream
+            nat.check(nat.lib().crp_configure(self._ctx, nat.OPT_SLICES, int(slices)), "crp_configure")
 
     # ---- measurement
-    def profile(self, on=True):
-        nat.check(nat.lib().crp_profile_enable(self._ctx, int(on)), "crp_profile_enable")
+    def profile(self, on=2):
+        """0 off, 1 HIP events around the emit+score kernel only, 2 (or True) around all three kernels."""
+        level = 2 if on is True else int(on)
+        nat.check(nat.lib().crp_profile_enable(self._ctx, level), "crp_profile_enable")
 
     def profile_read(self, reset=True):
         ms = (ctypes.c_double * 3)()

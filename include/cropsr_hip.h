@@ -174,11 +174,16 @@ int crp_format_rows(const uint8_t *contig_text, uint64_t contig_len, const uint8
  * number of workgroups explicitly.  Results are identical; the per-tile form
  * balances the uneven hit counts of tiles better and measured faster. */
 #define CRP_OPT_PERSISTENT_EMIT 2
+/* CRP_OPT_SLICES (1..8, default 1): cut the tile range into that many slices and run
+ * count + scan of slice k+1 on a second HIP stream while slice k is emitted (the
+ * count pass is HBM-bound, the emit pass VALU-bound).  Results are identical; measured
+ * slower than 1 on MI355X (the emit pass already fills the issue slots), kept for A/B. */
+#define CRP_OPT_SLICES 3
 int crp_configure(crp_ctx *ctx, int option, int64_t value);
 
 /* ---- measurement --------------------------------------------------------- */
-/* When enabled, every kernel launched by crp_scan_score is bracketed by HIP
- * events on the library's stream. */
+/* on = 1: the emit+score kernel of every crp_scan_score is bracketed by HIP events
+ * on the stream it is launched on; on = 2: all three kernels; 0: off. */
 int crp_profile_enable(crp_ctx *ctx, int on);
 /* Sum of durations (ms) and launch count per kernel since the last reset:
  * index 0 = count pass, 1 = tile-offset scan (both only with CRP_OPT_TWO_PASS),
