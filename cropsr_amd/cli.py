@@ -61,6 +61,10 @@ def build_parser():
                      help="seed numpy's global RNG so crispr_id is reproducible (reference: unseeded)")
     eng.add_argument("--csv-writer", choices=["native", "python"], default="native",
                      help="native: multi-threaded C++ row formatter (same bytes); python: csv module like the reference")
+    eng.add_argument("--each-contig-once", action="store_true",
+                     help="NOT reference behaviour: write every contig's rows once instead of re-writing all "
+                          "earlier contigs on every pass (the reference never clears Complete_dataset, "
+                          "CROPSR.py:407, which makes multi-contig genomes quadratic)")
     eng.add_argument("--reference-sleep", action="store_true",
                      help="also reproduce the reference's 5 s pause per contig")
     return p
@@ -179,6 +183,8 @@ def run(args, backend=None, out=sys.stdout):
         print("Searching on Chromosome: ", name[:25], file=out)  # CROPSR.py:410-411
         print("With start of sequence: ", s[:25], file=out)
         block = (rows.ContigTable if native else rows.ContigRows)(name, s, hits, args.l)
+        if getattr(args, "each_contig_once", False):
+            dataset = rows.NativeDataset() if native else rows.Dataset()  # opt-in fix of CROPSR.py:407
         dataset.append(block)
         if verbose:
             # CROPSR.py:436-439 counts regex matches BEFORE the keep-filter; the

@@ -108,3 +108,21 @@ def test_id_draws_equal_reference_choice():
         b = lut[np.random.randint(0, 36, size=[size, 7])]
         after_b = np.random.random()
         assert (rows.ids_as_bytes(a) == b).all() and after_a == after_b
+
+
+def test_each_contig_once_option(oracle, manifest, tmp_path, monkeypatch):
+    """--each-contig-once (opt-in, not reference behaviour): the rows of every contig, once,
+    in contig order == the LAST pass of the reference's own output (which re-emits contigs
+    1..K), up to the random id and the batch-position-dependent last bits of the score."""
+    from conftest import golden_fasta_path, oracle_scan_provider, read_golden_csv, run_cli
+    got, _ = run_cli(tmp_path, monkeypatch, golden_fasta_path("multi", tmp_path), oracle_scan_provider(oracle),
+                     manifest["seed"], extra=("--each-contig-once",))
+    ours = got.decode().split("\r\n")[1:-1]
+    ref = read_golden_csv("multi").decode().split("\r\n")[1:-1]
+    assert len(ref) == 169 and len(ours) == 76  # 33 + 60 + 76 rows in the reference, 33 + 27 + 16 here
+    last_pass = ref[-len(ours):]
+    for a, b in zip(ours, last_pass):
+        fa, fb = a.split(",", 1)[1].rsplit(",", 3), b.split(",", 1)[1].rsplit(",", 3)
+        assert fa[0] == fb[0] and fa[2:] == fb[2:]
+        ulp = abs(int(np.float64(fa[1]).view(np.int64)) - int(np.float64(fb[1]).view(np.int64)))
+        assert ulp <= 4
