@@ -419,3 +419,26 @@ def test_gather_runs_on_rccl_backend(tmp_path):
     p.join(300)
     assert p.exitcode == 0
     assert open(out).read() == "ok"
+
+
+def test_bench_line_contract():
+    """bench.py prints ONE JSON line with the contract's keys (tiny workload)."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--scale", "0.01", "--steps", "2", "--warmup", "1",
+                        "--cpu-sample-bases", "20000"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["vs_baseline"] is None and d["value"] > 0
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and "sample" in c
+    assert "workload" in d["config"] and "model" not in d["config"]
