@@ -226,7 +226,7 @@ def main():
             "metric": "gRNAs scored/sec", "value": scored_all * args.steps / dt, "unit": "gRNAs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u64 bit-planes + f64 score", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": genomes[0].name, "genomes": world, "contigs_per_genome": len(genomes[0].specs),
                        "bases_total": int(bases_all), "kept_hits_total": int(hits_all),
                        "guide_len": 20, "parallelism": ("contigs by LPT over %d ranks" % world) +
