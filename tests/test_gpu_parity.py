@@ -442,3 +442,24 @@ def test_bench_line_contract():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and "sample" in c
     assert "workload" in d["config"] and "model" not in d["config"]
+
+
+def test_randomised_arenas_vs_oracle(engine, oracle):
+    """Seeded fuzz: arenas with random contig counts, lengths clustered around word (64) and
+    tile (16384) boundaries, random alphabets / decoration / guide lengths / packers."""
+    rng = np.random.default_rng(20261003)
+    alphabets = [b"ACGT", b"ACGTacgtN", b"GGCC", b"ACGTUZuzN')],", b"GGGGGGCCCCCCAT"]
+    anchors = [0, 1, 30, 63, 64, 65, 16383, 16384, 16385, 2 * 16384 - 1, 2 * 16384, 3 * 16384 + 7]
+    total_hits = 0
+    for trial in range(60):
+        contigs = []
+        for _ in range(int(rng.integers(1, 9))):
+            n = max(0, int(anchors[rng.integers(len(anchors))] + rng.integers(-40, 41)))
+            if rng.random() < 0.3:
+                n = int(rng.integers(0, 4000))
+            body = rng.choice(np.frombuffer(alphabets[rng.integers(len(alphabets))], dtype=np.uint8), n).tobytes()
+            deco = rng.integers(3)
+            contigs.append(body if deco == 0 else b"'" + body + (b"')," if deco == 1 else b"')]"))
+        l = 20 if rng.random() < 0.7 else int(rng.integers(1, 51))
+        total_hits += check_contigs(engine, oracle, contigs, l, "device" if trial % 2 else "host")
+    assert total_hits > 50000
