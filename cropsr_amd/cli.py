@@ -143,16 +143,15 @@ def run(args, backend=None, out=sys.stdout):
 
     timing = open("time.txt", "w")  # CROPSR.py:371 (CWD side effect, kept)
 
-    # CROPSR.py:374, 54-74
-    with open(args.f, "r") as f:
-        text = f.read()
+    # CROPSR.py:374, 54-74 -- read as text mode would (universal newlines), kept as bytes
+    data = fasta.read_text_bytes(args.f)
     if verbose:
         print(f"Genome file {args.f} successfully imported", file=out)
-        if fasta.needs_formatting(text):
+        if 2 * data.count(b">") != data.count(b"\n") + 1:
             print("formatting genome", file=out)
             print(f"Genome file {args.f} successfully formatted", file=out)
-    contigs = fasta.contig_table(text)
-    del text
+    table = fasta.table_from_bytes(data)  # == fasta.contig_table(text).items(), without printing the genome
+    del data
     if verbose:
         print("The genome was successfully converted to a dictionary", file=out)
     import_gff_file(args.g, verbose)  # CROPSR.py:375 (raises like the reference if -g is missing)
@@ -170,8 +169,8 @@ def run(args, backend=None, out=sys.stdout):
 
     rows.write_header(args.o)  # CROPSR.py:402-405
 
-    names = list(contigs.keys())
-    strings = [contigs[k] for k in names]
+    names = [k for k, _ in table]
+    strings = [v for _, v in table]  # contig strings as bytes, one byte per character
     own_backend = backend is None
     if own_backend:
         backend = EngineBackend(getattr(args, "device", 0))
@@ -181,8 +180,8 @@ def run(args, backend=None, out=sys.stdout):
     dataset = rows.NativeDataset() if native else rows.Dataset()  # Complete_dataset, CROPSR.py:407
     for name, s, hits in zip(names, strings, all_hits):
         print("Searching on Chromosome: ", name[:25], file=out)  # CROPSR.py:410-411
-        print("With start of sequence: ", s[:25], file=out)
-        block = (rows.ContigTable if native else rows.ContigRows)(name, s, hits, args.l)
+        print("With start of sequence: ", s[:25].decode("latin-1"), file=out)
+        block = rows.ContigTable(name, s, hits, args.l) if native else rows.ContigRows(name, s.decode("latin-1"), hits, args.l)
         if getattr(args, "each_contig_once", False):
             dataset = rows.NativeDataset() if native else rows.Dataset()  # opt-in fix of CROPSR.py:407
         dataset.append(block)
@@ -190,7 +189,7 @@ def run(args, backend=None, out=sys.stdout):
             # CROPSR.py:436-439 counts regex matches BEFORE the keep-filter; the
             # engine reports kept hits, so re-count only for this message.
             import re
-            n_sites = sum(1 for _ in re.finditer(r"(?=.GG)", s)) + sum(1 for _ in re.finditer(r"(?=CC.)", s))
+            n_sites = sum(1 for _ in re.finditer(rb"(?=.GG)", s)) + sum(1 for _ in re.finditer(rb"(?=CC.)", s))
             print(f"""
                 {n_sites:n} Cas9 PAM sites were found on {name[1::]}
                 """, file=out)

@@ -57,3 +57,71 @@ def contig_table(text):
 def load(path):
     with open(path, "r") as f:
         return contig_table(f.read())
+
+
+# ----------------------------------------------------------------------------
+# Fast loader (SURVEY.md section 8, row f2): the same table without printing a
+# Python list of the whole genome.  For the common shape -- every header and every
+# sequence is "plain" (printable ASCII without blank, quote or backslash) and every
+# record has a header line and a body -- the printed form is predictable:
+#     key   = "[('" + header + "',"      (first record)   "('" + header + "',"   (others)
+#     value = "'" + body + "'),"         (not last)        "'" + body + "')]"     (last)
+# and is built directly from the bytes of the file (bytes.translate strips the
+# newlines at C speed).  Anything else falls back to contig_table() above.
+_PLAIN = bytes(c for c in range(33, 127) if c not in (0x27, 0x5C))
+
+
+def _plain(b):
+    return not b.translate(None, _PLAIN)
+
+
+def table_from_bytes(data):
+    """[(key str, contig string as bytes)] in dict order, equal to
+    list(contig_table(data.decode()).items()) with the values encoded as ASCII."""
+    formatted = 2 * data.count(b">") != data.count(b"\n") + 1
+    fast = None
+    if formatted:
+        pieces = [p for p in data.split(b">") if p]
+        recs = []
+        ok = bool(pieces)
+        for p in pieces:
+            head, sep, body = p.partition(b"\n")
+            if not sep:
+                ok = False  # a record without a newline prints as a 1-tuple: pairing shifts
+                break
+            body = body.translate(None, b"\n")
+            if not (_plain(head) and _plain(body)):
+                ok = False
+                break
+            recs.append((head, body))
+        if ok:
+            fast = []
+            last = len(recs) - 1
+            for k, (head, body) in enumerate(recs):
+                key = ("[('" if k == 0 else "('") + head.decode("ascii") + "',"
+                fast.append((key, b"'" + body + (b"')]" if k == last else b"'),")))
+    elif _plain(data.translate(None, b"\n")):
+        tokens = data.split()
+        fast = [(tokens[i].decode("ascii"), tokens[i + 1] if i + 1 < len(tokens) else b"")
+                for i in range(0, len(tokens), 2)]
+    if fast is None:
+        table = contig_table(data.decode("utf-8", "surrogateescape"))
+        return [(k, v.encode("ascii", "replace")) for k, v in table.items()]
+    merged = {}
+    for k, v in fast:  # dict semantics: first position, last value
+        merged[k] = v
+    return list(merged.items())
+
+
+def read_text_bytes(path):
+    """The file's bytes as Python's text mode would hand them over (CROPSR.py:58 opens
+    with 'r': universal newlines turn \r\n and \r into \n)."""
+    with open(path, "rb") as f:
+        data = f.read()
+    if b"\r" in data:
+        data = data.replace(b"\r\n", b"\n").replace(b"\r", b"\n")
+    return data
+
+
+def load_bytes(path):
+    return table_from_bytes(read_text_bytes(path))

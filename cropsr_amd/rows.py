@@ -207,10 +207,10 @@ class ContigTable:
     """Array form of ContigRows: same rows, same order, no per-row Python objects."""
 
     def __init__(self, name_token, s, hits, guide_len):
+        """s: the contig string, as str or (one byte per character) bytes."""
         self.guide_len = guide_len
         self.chrom = name_token[1:].encode("utf-8")
-        self.s = s
-        self.text = np.frombuffer(s.encode("ascii", "replace"), dtype=np.uint8)
+        self.text = np.frombuffer(s.encode("ascii", "replace") if isinstance(s, str) else s, dtype=np.uint8)
         self.n_plus = int(hits["pos_plus"].size)
         self.pos = np.ascontiguousarray(np.concatenate([hits["pos_plus"], hits["pos_minus"]]), dtype=np.uint32)
         self.minus = np.zeros(self.pos.size, dtype=np.uint8)
@@ -220,9 +220,9 @@ class ContigTable:
 
     def long_text(self, k):
         l, p = self.guide_len, int(self.pos[k])
-        if self.minus[k]:
-            return minus_text(self.s, p + 3 - 5, p + 3 + l + 5)
-        return plus_text(self.s, p - l - 5, p + 5)
+        a, b = (p + 3 - 5, p + 3 + l + 5) if self.minus[k] else (p - l - 5, p + 5)
+        piece = self.text[max(a, 0):max(b, 0)].tobytes().decode("latin-1")  # Python slice clamping
+        return minus_text(piece, 0, len(piece)) if self.minus[k] else plus_text(piece, 0, len(piece))
 
 
 class NativeDataset:

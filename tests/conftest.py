@@ -73,7 +73,7 @@ class OracleBackend:
         self.orc = orc
 
     def scan(self, strings, l):
-        return [self.orc.scan_score(s.encode("ascii", "replace"), l) for s in strings]
+        return [self.orc.scan_score(s.encode("ascii", "replace") if isinstance(s, str) else s, l) for s in strings]
 
     def rescore(self, rows_u8, order):
         return self.orc.score30_order(rows_u8, order)[1]
