@@ -6,7 +6,13 @@
 namespace crp {
 
 constexpr int BLOCK = 256;     // threads per workgroup (4 wavefronts of 64)
-constexpr int TILE_WPT = 1;    // 64-position words per thread in the count/emit passes
+#ifndef CRP_TILE_WPT
+#define CRP_TILE_WPT 2
+#endif
+#ifndef CRP_LIST_CAP_PER_WPT
+#define CRP_LIST_CAP_PER_WPT 2048  // LDS hit-list entries per round and per word-per-thread
+#endif
+constexpr int TILE_WPT = CRP_TILE_WPT;  // 64-position words per thread in the emit pass (1 or 2)
 constexpr int TILE_WORDS = BLOCK * TILE_WPT;
 constexpr int ARENA_ALIGN_WORDS = 1024;  // arena planes are padded to this many words
 

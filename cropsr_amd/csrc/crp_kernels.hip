@@ -208,8 +208,10 @@ __global__ __launch_bounds__(BLOCK) void count_kernel(Planes pl, uint64_t n_word
                                                        uint2 *__restrict__ tile_cnt, uint32_t pair_first)
 {
     const int l = LFIX > 0 ? LFIX : l_arg;
-    const uint32_t pair = blockIdx.x + pair_first;  // this workgroup counts tiles 2*pair and 2*pair+1
-    static_assert(TILE_WORDS == 256 && BLOCK == 256, "two waves per emit tile");
+    // a workgroup covers 512 words = COUNT_TPB emit tiles
+    constexpr int COUNT_TPB = 512 / TILE_WORDS;
+    static_assert((TILE_WORDS == 256 || TILE_WORDS == 512) && BLOCK == 256, "count pass covers 512 words per workgroup");
+    const uint32_t pair = blockIdx.x + pair_first;
     __shared__ uint64_t wave_tot[BLOCK / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint64_t w0 = ((uint64_t)pair * (BLOCK / 64) + wave) * 128;  // first word of this wave
@@ -243,10 +245,13 @@ __global__ __launch_bounds__(BLOCK) void count_kernel(Planes pl, uint64_t n_word
     for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d, 64);
     if (lane == 0) wave_tot[wave] = c;
     __syncthreads();
-    if (threadIdx.x < 2) {
-        const uint64_t tile = (uint64_t)pair * 2 + threadIdx.x;
+    if (threadIdx.x < COUNT_TPB) {
+        const uint64_t tile = (uint64_t)pair * COUNT_TPB + threadIdx.x;
         if (tile * TILE_WORDS < n_words_padded) {
-            const uint64_t t = wave_tot[2 * threadIdx.x] + wave_tot[2 * threadIdx.x + 1];
+            constexpr int WAVES = (BLOCK / 64) / COUNT_TPB;
+            uint64_t t = 0;
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) t += wave_tot[WAVES * threadIdx.x + w];
             tile_cnt[tile] = make_uint2((uint32_t)t, (uint32_t)(t >> 32));
         }
     }
@@ -462,7 +467,7 @@ __global__ __launch_bounds__(BLOCK) void emit_kernel(Planes pl, uint64_t n_words
 {
     const int l = LFIX > 0 ? LFIX : l_arg;
     constexpr int TW = BLOCK * WPT;
-    constexpr int CAP = 2048 * WPT;  // list entries per round; typical tiles need one round
+    constexpr int CAP = CRP_LIST_CAP_PER_WPT * WPT;  // list entries per round; typical tiles need one round
     __shared__ uint64_t sh[4][TW + 2];
     __shared__ uint64_t exp_tab[256];
     __shared__ uint64_t wave_tot[BLOCK / 64];
@@ -634,9 +639,9 @@ __global__ __launch_bounds__(BLOCK) void emit_stream_kernel(Planes pl, uint64_t 
                                                              HitTables out)
 {
     const int l = LFIX > 0 ? LFIX : l_arg;
-    static_assert(WPT == 1, "register prefetch below is written for 256-word tiles");
+    static_assert(WPT == 1 || WPT == 2, "register prefetch below moves 2*WPT 16-byte loads per thread");
     constexpr int TW = BLOCK * WPT;
-    constexpr int CAP = 2048 * WPT;
+    constexpr int CAP = CRP_LIST_CAP_PER_WPT * WPT;
     __shared__ uint64_t sh[4][TW + 2];
     __shared__ uint64_t exp_tab[256];
     __shared__ uint64_t wave_tot[BLOCK / 64];
@@ -646,12 +651,12 @@ __global__ __launch_bounds__(BLOCK) void emit_stream_kernel(Planes pl, uint64_t 
 
     // prefetch registers: two 16-byte body loads per thread + one halo word for tid < 8
     constexpr int PAIRS = TW / 2;
-    ulonglong2 body[2];
+    ulonglong2 body[2 * WPT];
     uint64_t halo = 0;
     auto fetch = [&](uint32_t tile) {
         const uint64_t t0 = (uint64_t)tile * TW;
 #pragma unroll
-        for (int it = 0; it < 2; ++it) {
+        for (int it = 0; it < 2 * WPT; ++it) {
             const int q = tid + it * BLOCK;
             body[it] = *reinterpret_cast<const ulonglong2 *>(pl.plane[q / PAIRS] + t0 + 2 * (q % PAIRS));
         }
@@ -668,7 +673,7 @@ __global__ __launch_bounds__(BLOCK) void emit_stream_kernel(Planes pl, uint64_t 
     };
     auto commit = [&]() {  // prefetched registers -> LDS tile image
 #pragma unroll
-        for (int it = 0; it < 2; ++it) {
+        for (int it = 0; it < 2 * WPT; ++it) {
             const int q = tid + it * BLOCK;
             sh[q / PAIRS][1 + 2 * (q % PAIRS)] = body[it].x;
             sh[q / PAIRS][2 + 2 * (q % PAIRS)] = body[it].y;
@@ -828,11 +833,12 @@ hipError_t launch_count(hipStream_t s, const Planes &pl, uint64_t n_words_padded
                         uint32_t tile_first, uint32_t tile_count)
 {
     if (tile_count == 0) return hipSuccess;
-    const dim3 grid((tile_count + 1) / 2);
+    constexpr uint32_t TPB = 512 / TILE_WORDS;  // emit tiles per count workgroup
+    const dim3 grid((tile_count + TPB - 1) / TPB);
     if (l == 20)
-        hipLaunchKernelGGL(count_kernel<20>, grid, dim3(BLOCK), 0, s, pl, n_words_padded, l, tile_cnt, tile_first / 2);
+        hipLaunchKernelGGL(count_kernel<20>, grid, dim3(BLOCK), 0, s, pl, n_words_padded, l, tile_cnt, tile_first / TPB);
     else
-        hipLaunchKernelGGL(count_kernel<0>, grid, dim3(BLOCK), 0, s, pl, n_words_padded, l, tile_cnt, tile_first / 2);
+        hipLaunchKernelGGL(count_kernel<0>, grid, dim3(BLOCK), 0, s, pl, n_words_padded, l, tile_cnt, tile_first / TPB);
     return hipGetLastError();
 }
 
