@@ -143,12 +143,19 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan_u32(uint32_t v)
     return v;
 }
 
+// WIDE: a wave's per-strand total can reach 2^16 (tiles of 1024 words or more): scan the halves apart
+template <bool WIDE>
 __device__ __forceinline__ uint64_t block_exclusive_scan(uint64_t v, uint64_t *wave_tot, uint64_t &total)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t v16 = (uint32_t)v | ((uint32_t)(v >> 32) << 16);  // plus | minus << 16
-    const uint32_t inc16 = wave_inclusive_scan_u32(v16);
-    const uint64_t inc = (uint64_t)(inc16 & 0xffffu) | ((uint64_t)(inc16 >> 16) << 32);
+    uint64_t inc;
+    if (WIDE) {
+        inc = (uint64_t)wave_inclusive_scan_u32((uint32_t)v) | ((uint64_t)wave_inclusive_scan_u32((uint32_t)(v >> 32)) << 32);
+    } else {
+        const uint32_t v16 = (uint32_t)v | ((uint32_t)(v >> 32) << 16);  // plus | minus << 16
+        const uint32_t inc16 = wave_inclusive_scan_u32(v16);
+        inc = (uint64_t)(inc16 & 0xffffu) | ((uint64_t)(inc16 >> 16) << 32);
+    }
     if (lane == 63) wave_tot[wave] = inc;
     __syncthreads();
     uint64_t base = 0, tot = 0;
@@ -208,14 +215,18 @@ __global__ __launch_bounds__(BLOCK) void count_kernel(Planes pl, uint64_t n_word
                                                        uint2 *__restrict__ tile_cnt, uint32_t pair_first)
 {
     const int l = LFIX > 0 ? LFIX : l_arg;
-    // a workgroup covers 512 words = COUNT_TPB emit tiles
-    constexpr int COUNT_TPB = 512 / TILE_WORDS;
-    static_assert((TILE_WORDS == 256 || TILE_WORDS == 512) && BLOCK == 256, "count pass covers 512 words per workgroup");
+    // a workgroup covers COUNT_WORDS words = COUNT_TPB emit tiles; a wave takes 128 words at a time
+    constexpr int COUNT_WORDS = TILE_WORDS > 512 ? TILE_WORDS : 512;
+    constexpr int COUNT_TPB = COUNT_WORDS / TILE_WORDS;
+    constexpr int REPS = COUNT_WORDS / 512;
+    static_assert(BLOCK == 256 && (TILE_WORDS == 256 || TILE_WORDS % 512 == 0), "count pass geometry");
     const uint32_t pair = blockIdx.x + pair_first;
     __shared__ uint64_t wave_tot[BLOCK / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint64_t w0 = ((uint64_t)pair * (BLOCK / 64) + wave) * 128;  // first word of this wave
     uint64_t c = 0;
+#pragma unroll
+    for (int rep = 0; rep < REPS; ++rep) {
+    const uint64_t w0 = (uint64_t)pair * COUNT_WORDS + (uint64_t)(wave * REPS + rep) * 128;  // first word of this pass
     if (w0 < n_words_padded) {
         const uint64_t wa = w0 + 2 * lane;  // this lane owns words wa, wa+1
         ulonglong2 q[4];
@@ -239,7 +250,8 @@ __global__ __launch_bounds__(BLOCK) void count_kernel(Planes pl, uint64_t n_word
         uint64_t g_right = __shfl_down(ga, 1, 64), c_right = __shfl_down(ca, 1, 64), v_right = __shfl_down(va, 1, 64);
         if (lane == 0) v_left = ve;
         if (lane == 63) { g_right = ge; c_right = ce; v_right = ve; }
-        c = counts_of(ga, gb, ca, cb, v_left, va, vb, l) + counts_of(gb, g_right, cb, c_right, va, vb, v_right, l);
+        c += counts_of(ga, gb, ca, cb, v_left, va, vb, l) + counts_of(gb, g_right, cb, c_right, va, vb, v_right, l);
+    }
     }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d, 64);
@@ -493,7 +505,7 @@ __global__ __launch_bounds__(BLOCK) void emit_kernel(Planes pl, uint64_t n_words
 #pragma unroll
     for (int k = 0; k < WPT; ++k) c += (uint64_t)__popcll(mp[k]) | ((uint64_t)__popcll(mm[k]) << 32);
     uint64_t total;
-    const uint64_t ex = block_exclusive_scan(c, wave_tot, total);
+    const uint64_t ex = block_exclusive_scan<(WPT > 3)>(c, wave_tot, total);
     const uint32_t n_plus = (uint32_t)total, n_minus = (uint32_t)(total >> 32);
     const uint32_t n_all = n_plus + n_minus;
     uint64_t off_plus, off_minus;
@@ -639,7 +651,7 @@ __global__ __launch_bounds__(BLOCK) void emit_stream_kernel(Planes pl, uint64_t 
                                                              HitTables out)
 {
     const int l = LFIX > 0 ? LFIX : l_arg;
-    static_assert(WPT == 1 || WPT == 2, "register prefetch below moves 2*WPT 16-byte loads per thread");
+    static_assert(WPT >= 1 && WPT <= 4, "register prefetch below moves 2*WPT 16-byte loads per thread");
     constexpr int TW = BLOCK * WPT;
     constexpr int CAP = CRP_LIST_CAP_PER_WPT * WPT;
     __shared__ uint64_t sh[4][TW + 2];
@@ -695,7 +707,7 @@ __global__ __launch_bounds__(BLOCK) void emit_stream_kernel(Planes pl, uint64_t 
 #pragma unroll
         for (int k = 0; k < WPT; ++k) c += (uint64_t)__popcll(mp[k]) | ((uint64_t)__popcll(mm[k]) << 32);
         uint64_t total;
-        const uint64_t ex = block_exclusive_scan(c, wave_tot, total);
+        const uint64_t ex = block_exclusive_scan<(WPT > 3)>(c, wave_tot, total);
         const uint2 off = tile_off[tile];
         emit_rounds<WPT, TW, CAP, LFIX == 20>(sh, list, exp_tab, mp, mm, ex, (uint32_t)total, (uint32_t)(total >> 32), l,
                                   (uint32_t)((uint64_t)tile * TW * 64), off.x, off.y, out);
@@ -833,7 +845,7 @@ hipError_t launch_count(hipStream_t s, const Planes &pl, uint64_t n_words_padded
                         uint32_t tile_first, uint32_t tile_count)
 {
     if (tile_count == 0) return hipSuccess;
-    constexpr uint32_t TPB = 512 / TILE_WORDS;  // emit tiles per count workgroup
+    constexpr uint32_t TPB = (TILE_WORDS > 512 ? TILE_WORDS : 512) / TILE_WORDS;  // emit tiles per count workgroup
     const dim3 grid((tile_count + TPB - 1) / TPB);
     if (l == 20)
         hipLaunchKernelGGL(count_kernel<20>, grid, dim3(BLOCK), 0, s, pl, n_words_padded, l, tile_cnt, tile_first / TPB);
