@@ -12,8 +12,12 @@ constexpr int BLOCK = 256;     // threads per workgroup (4 wavefronts of 64)
 #ifndef CRP_LIST_CAP_PER_WPT
 #define CRP_LIST_CAP_PER_WPT 2048  // LDS hit-list entries per round and per word-per-thread
 #endif
+#ifndef CRP_EMIT_BLOCK
+#define CRP_EMIT_BLOCK 256
+#endif
+constexpr int EMIT_BLOCK = CRP_EMIT_BLOCK;  // threads per workgroup of the emit pass
 constexpr int TILE_WPT = CRP_TILE_WPT;  // 64-position words per thread in the emit pass (1 or 2)
-constexpr int TILE_WORDS = BLOCK * TILE_WPT;
+constexpr int TILE_WORDS = EMIT_BLOCK * TILE_WPT;
 constexpr int ARENA_ALIGN_WORDS = 1024;  // arena planes are padded to this many words
 
 struct Planes {

@@ -82,8 +82,8 @@ __device__ __forceinline__ void stage_tile(const Planes &pl, uint64_t t0, uint64
     const int tid = threadIdx.x;
     constexpr int PAIRS = TW / 2;  // 16-byte units per plane
 #pragma unroll
-    for (int it = 0; it < (4 * PAIRS) / BLOCK; ++it) {
-        const int q = tid + it * BLOCK;
+    for (int it = 0; it < (4 * PAIRS) / EMIT_BLOCK; ++it) {
+        const int q = tid + it * EMIT_BLOCK;
         const int p = q / PAIRS, k = q % PAIRS;
         const uint64_t *src = pl.plane[p] + t0 + 2 * k;
         const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(src);
@@ -160,7 +160,7 @@ __device__ __forceinline__ uint64_t block_exclusive_scan(uint64_t v, uint64_t *w
     __syncthreads();
     uint64_t base = 0, tot = 0;
 #pragma unroll
-    for (int w = 0; w < BLOCK / 64; ++w) {
+    for (int w = 0; w < EMIT_BLOCK / 64; ++w) {
         const uint64_t t = wave_tot[w];
         if (w < wave) base += t;
         tot += t;
@@ -472,17 +472,17 @@ __device__ __forceinline__ void emit_rounds(uint64_t (*sh)[TW + 2], uint16_t *li
 // CHAINED = false: third pass of the count / scan / emit sequence (offsets from
 //                  tile_off); kept as the cross-check for the single-pass mode.
 template <int WPT, bool CHAINED, int LFIX>
-__global__ __launch_bounds__(BLOCK) void emit_kernel(Planes pl, uint64_t n_words_padded, int l_arg,
+__global__ __launch_bounds__(EMIT_BLOCK) void emit_kernel(Planes pl, uint64_t n_words_padded, int l_arg,
                                                       const uint2 *__restrict__ tile_off, uint64_t *chain,
                                                       uint64_t *__restrict__ totals, HitTables out,
                                                       uint32_t tile_first)
 {
     const int l = LFIX > 0 ? LFIX : l_arg;
-    constexpr int TW = BLOCK * WPT;
+    constexpr int TW = EMIT_BLOCK * WPT;
     constexpr int CAP = CRP_LIST_CAP_PER_WPT * WPT;  // list entries per round; typical tiles need one round
     __shared__ uint64_t sh[4][TW + 2];
     __shared__ uint64_t exp_tab[256];
-    __shared__ uint64_t wave_tot[BLOCK / 64];
+    __shared__ uint64_t wave_tot[EMIT_BLOCK / 64];
     __shared__ uint64_t s_excl;
     __shared__ uint32_t s_tile;
     __shared__ uint16_t list[CAP];
@@ -496,7 +496,7 @@ __global__ __launch_bounds__(BLOCK) void emit_kernel(Planes pl, uint64_t n_words
     }
     const uint64_t t0 = (uint64_t)tile * TW;
     stage_tile<TW>(pl, t0, n_words_padded, sh);
-    exp_tab[tid] = CRP_EXP_TAB[tid];
+    for (int k = tid; k < 256; k += EMIT_BLOCK) exp_tab[k] = CRP_EXP_TAB[k];
     __syncthreads();
 
     uint64_t mp[WPT], mm[WPT];
@@ -505,7 +505,7 @@ __global__ __launch_bounds__(BLOCK) void emit_kernel(Planes pl, uint64_t n_words
 #pragma unroll
     for (int k = 0; k < WPT; ++k) c += (uint64_t)__popcll(mp[k]) | ((uint64_t)__popcll(mm[k]) << 32);
     uint64_t total;
-    const uint64_t ex = block_exclusive_scan<(WPT > 3)>(c, wave_tot, total);
+    const uint64_t ex = block_exclusive_scan<(EMIT_BLOCK * WPT >= 1024)>(c, wave_tot, total);
     const uint32_t n_plus = (uint32_t)total, n_minus = (uint32_t)(total >> 32);
     const uint32_t n_all = n_plus + n_minus;
     uint64_t off_plus, off_minus;
@@ -580,7 +580,7 @@ __device__ __forceinline__ void emit_rounds(uint64_t (*sh)[TW + 2], uint16_t *li
         __syncthreads();
         // ---- one hit per lane: extract the 30-window, score, store
         const uint32_t n_round = min((uint32_t)CAP, n_all - lo_rank);
-        for (uint32_t k = tid; k < n_round; k += BLOCK) {
+        for (uint32_t k = tid; k < n_round; k += EMIT_BLOCK) {
             const uint32_t r = lo_rank + k;
             const uint32_t e = list[k];
             const bool minus = r >= n_plus;
@@ -646,20 +646,20 @@ __device__ __forceinline__ void emit_rounds(uint64_t (*sh)[TW + 2], uint16_t *li
 // first hides under ~10 us of VALU work instead of depending on how the phases of
 // co-resident workgroups happen to interleave.
 template <int WPT, int LFIX>
-__global__ __launch_bounds__(BLOCK) void emit_stream_kernel(Planes pl, uint64_t n_words_padded, uint32_t n_tiles,
+__global__ __launch_bounds__(EMIT_BLOCK) void emit_stream_kernel(Planes pl, uint64_t n_words_padded, uint32_t n_tiles,
                                                              int l_arg, const uint2 *__restrict__ tile_off,
                                                              HitTables out)
 {
     const int l = LFIX > 0 ? LFIX : l_arg;
     static_assert(WPT >= 1 && WPT <= 4, "register prefetch below moves 2*WPT 16-byte loads per thread");
-    constexpr int TW = BLOCK * WPT;
+    constexpr int TW = EMIT_BLOCK * WPT;
     constexpr int CAP = CRP_LIST_CAP_PER_WPT * WPT;
     __shared__ uint64_t sh[4][TW + 2];
     __shared__ uint64_t exp_tab[256];
-    __shared__ uint64_t wave_tot[BLOCK / 64];
+    __shared__ uint64_t wave_tot[EMIT_BLOCK / 64];
     __shared__ uint16_t list[CAP];
     const int tid = threadIdx.x;
-    exp_tab[tid] = CRP_EXP_TAB[tid];
+    for (int k = tid; k < 256; k += EMIT_BLOCK) exp_tab[k] = CRP_EXP_TAB[k];
 
     // prefetch registers: two 16-byte body loads per thread + one halo word for tid < 8
     constexpr int PAIRS = TW / 2;
@@ -669,7 +669,7 @@ __global__ __launch_bounds__(BLOCK) void emit_stream_kernel(Planes pl, uint64_t 
         const uint64_t t0 = (uint64_t)tile * TW;
 #pragma unroll
         for (int it = 0; it < 2 * WPT; ++it) {
-            const int q = tid + it * BLOCK;
+            const int q = tid + it * EMIT_BLOCK;
             body[it] = *reinterpret_cast<const ulonglong2 *>(pl.plane[q / PAIRS] + t0 + 2 * (q % PAIRS));
         }
         if (tid < 8) {
@@ -686,7 +686,7 @@ __global__ __launch_bounds__(BLOCK) void emit_stream_kernel(Planes pl, uint64_t 
     auto commit = [&]() {  // prefetched registers -> LDS tile image
 #pragma unroll
         for (int it = 0; it < 2 * WPT; ++it) {
-            const int q = tid + it * BLOCK;
+            const int q = tid + it * EMIT_BLOCK;
             sh[q / PAIRS][1 + 2 * (q % PAIRS)] = body[it].x;
             sh[q / PAIRS][2 + 2 * (q % PAIRS)] = body[it].y;
         }
@@ -707,7 +707,7 @@ __global__ __launch_bounds__(BLOCK) void emit_stream_kernel(Planes pl, uint64_t 
 #pragma unroll
         for (int k = 0; k < WPT; ++k) c += (uint64_t)__popcll(mp[k]) | ((uint64_t)__popcll(mm[k]) << 32);
         uint64_t total;
-        const uint64_t ex = block_exclusive_scan<(WPT > 3)>(c, wave_tot, total);
+        const uint64_t ex = block_exclusive_scan<(EMIT_BLOCK * WPT >= 1024)>(c, wave_tot, total);
         const uint2 off = tile_off[tile];
         emit_rounds<WPT, TW, CAP, LFIX == 20>(sh, list, exp_tab, mp, mm, ex, (uint32_t)total, (uint32_t)(total >> 32), l,
                                   (uint32_t)((uint64_t)tile * TW * 64), off.x, off.y, out);
@@ -868,22 +868,22 @@ hipError_t launch_tile_scan(hipStream_t s, const uint2 *tile_cnt, uint32_t n_til
 hipError_t launch_emit(hipStream_t s, const Planes &pl, uint64_t n_words_padded, int l, const uint2 *tile_off,
                        const HitTables &out, int persistent_blocks, uint32_t tile_first, uint32_t tile_count)
 {
-    constexpr int TW = BLOCK * TILE_WPT;
+    constexpr int TW = EMIT_BLOCK * TILE_WPT;
     const uint32_t n_tiles = (uint32_t)(n_words_padded / TW);
     if (tile_count == 0) return hipSuccess;
     if (persistent_blocks > 0 && tile_first == 0 && tile_count == n_tiles) {
         const uint32_t grid = n_tiles < (uint32_t)persistent_blocks ? n_tiles : (uint32_t)persistent_blocks;
         if (l == 20)
-            hipLaunchKernelGGL((emit_stream_kernel<TILE_WPT, 20>), dim3(grid), dim3(BLOCK), 0, s, pl, n_words_padded,
+            hipLaunchKernelGGL((emit_stream_kernel<TILE_WPT, 20>), dim3(grid), dim3(EMIT_BLOCK), 0, s, pl, n_words_padded,
                                n_tiles, l, tile_off, out);
         else
-            hipLaunchKernelGGL((emit_stream_kernel<TILE_WPT, 0>), dim3(grid), dim3(BLOCK), 0, s, pl, n_words_padded,
+            hipLaunchKernelGGL((emit_stream_kernel<TILE_WPT, 0>), dim3(grid), dim3(EMIT_BLOCK), 0, s, pl, n_words_padded,
                                n_tiles, l, tile_off, out);
     } else if (l == 20) {
-        hipLaunchKernelGGL((emit_kernel<TILE_WPT, false, 20>), dim3(tile_count), dim3(BLOCK), 0, s, pl, n_words_padded,
+        hipLaunchKernelGGL((emit_kernel<TILE_WPT, false, 20>), dim3(tile_count), dim3(EMIT_BLOCK), 0, s, pl, n_words_padded,
                            l, tile_off, (uint64_t *)nullptr, (uint64_t *)nullptr, out, tile_first);
     } else {
-        hipLaunchKernelGGL((emit_kernel<TILE_WPT, false, 0>), dim3(tile_count), dim3(BLOCK), 0, s, pl, n_words_padded,
+        hipLaunchKernelGGL((emit_kernel<TILE_WPT, false, 0>), dim3(tile_count), dim3(EMIT_BLOCK), 0, s, pl, n_words_padded,
                            l, tile_off, (uint64_t *)nullptr, (uint64_t *)nullptr, out, tile_first);
     }
     return hipGetLastError();
@@ -893,7 +893,7 @@ hipError_t launch_emit(hipStream_t s, const Planes &pl, uint64_t n_words_padded,
 int emit_stream_blocks_per_cu()
 {
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, emit_stream_kernel<TILE_WPT, 20>, BLOCK, 0) != hipSuccess || n < 1)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, emit_stream_kernel<TILE_WPT, 20>, EMIT_BLOCK, 0) != hipSuccess || n < 1)
         n = 4;
     return n;
 }
@@ -903,11 +903,11 @@ size_t chain_bytes(uint32_t n_tiles) { return 16 + (size_t)n_tiles * sizeof(uint
 hipError_t launch_emit_chained(hipStream_t s, const Planes &pl, uint64_t n_words_padded, int l, uint64_t *chain,
                                uint64_t *totals, const HitTables &out)
 {
-    constexpr int TW = BLOCK * TILE_WPT;
+    constexpr int TW = EMIT_BLOCK * TILE_WPT;
     const uint32_t n_tiles = (uint32_t)(n_words_padded / TW);
     hipError_t e = hipMemsetAsync(chain, 0, chain_bytes(n_tiles), s);  // ticket, fail flag, descriptors
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((emit_kernel<TILE_WPT, true, 0>), dim3(n_tiles), dim3(BLOCK), 0, s, pl, n_words_padded, l,
+    hipLaunchKernelGGL((emit_kernel<TILE_WPT, true, 0>), dim3(n_tiles), dim3(EMIT_BLOCK), 0, s, pl, n_words_padded, l,
                        (const uint2 *)nullptr, chain, totals, out, 0u);
     return hipGetLastError();
 }
