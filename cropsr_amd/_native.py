@@ -42,6 +42,10 @@ SIGNATURES = {
     "crp_score_30mers": (ctypes.c_int, [ctypes.c_void_p, u8p, ctypes.c_uint64, ctypes.c_int, f64p, f64p]),
     "crp_format_rows": (ctypes.c_int, [u8p, ctypes.c_uint64, u8p, ctypes.c_uint64, ctypes.c_int, u32p, u8p, f64p,
                                        u8p, ctypes.c_uint64, u8p, ctypes.c_uint64, u64p, ctypes.c_int]),
+    "crp_write_rows": (ctypes.c_int, [ctypes.c_int, u8p, ctypes.c_uint64, u8p, ctypes.c_uint64, ctypes.c_int, u32p, u8p,
+                                      f64p, u8p, ctypes.c_uint64, u64p, ctypes.c_int]),
+    "crp_fasta_table": (ctypes.c_int, [u8p, ctypes.c_uint64, u8p, ctypes.c_uint64, u64p, ctypes.c_uint64, u64p, u64p,
+                                       ctypes.POINTER(ctypes.c_int), ctypes.c_int]),
     "crp_configure": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int64]),
     "crp_profile_enable": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "crp_profile_read": (ctypes.c_int, [ctypes.c_void_p, f64p, u64p, ctypes.c_int]),
@@ -54,6 +58,7 @@ OPT_TWO_PASS = 1
 OPT_PERSISTENT_EMIT = 2
 OPT_SLICES = 3
 CRP_ERR_NO_DEVICE = -2
+CRP_ERR_IO = -8
 
 _lib = None
 
@@ -75,7 +80,7 @@ def lib():
             raise ImportError(
                 "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(or `make -C cropsr_amd/csrc`).  cropsr_amd has no CPU fallback." % LIB_PATH)
-        L = ctypes.CDLL(LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH, use_errno=True)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)
             fn.restype = res

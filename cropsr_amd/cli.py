@@ -65,6 +65,9 @@ def build_parser():
                      help="NOT reference behaviour: write every contig's rows once instead of re-writing all "
                           "earlier contigs on every pass (the reference never clears Complete_dataset, "
                           "CROPSR.py:407, which makes multi-contig genomes quadratic)")
+    eng.add_argument("--fast-ids", action="store_true",
+                     help="draw crispr_id from a fresh PCG64 generator instead of numpy's global legacy stream "
+                          "(same alphabet and distribution, ~10x faster; not reproducible with --seed)")
     eng.add_argument("--reference-sleep", action="store_true",
                      help="also reproduce the reference's 5 s pause per contig")
     return p
@@ -177,12 +180,22 @@ def run(args, backend=None, out=sys.stdout):
     all_hits = backend.scan(strings, args.l)  # seam 1 + 2 for every contig, one GPU pass
 
     native = getattr(args, "csv_writer", "native") == "native"
+    once = getattr(args, "each_contig_once", False)
     dataset = rows.NativeDataset() if native else rows.Dataset()  # Complete_dataset, CROPSR.py:407
+    ids = None
+    if native:
+        # every pass draws its ids from one RNG stream, in order; the pass sizes are known now,
+        # so a worker draws pass k+1's ids while pass k is formatted and written
+        per_contig = [int(h["pos_plus"].size + h["pos_minus"].size) for h in all_hits]
+        import numpy as np
+        sizes = per_contig if once else np.cumsum(per_contig).tolist()
+        fast = np.random.default_rng() if getattr(args, "fast_ids", False) else None
+        ids = rows.IdStream(sizes, generator=fast)
     for name, s, hits in zip(names, strings, all_hits):
         print("Searching on Chromosome: ", name[:25], file=out)  # CROPSR.py:410-411
-        print("With start of sequence: ", s[:25].decode("latin-1"), file=out)
-        block = rows.ContigTable(name, s, hits, args.l) if native else rows.ContigRows(name, s.decode("latin-1"), hits, args.l)
-        if getattr(args, "each_contig_once", False):
+        print("With start of sequence: ", bytes(s[:25]).decode("latin-1"), file=out)
+        block = rows.ContigTable(name, s, hits, args.l) if native else rows.ContigRows(name, bytes(s).decode("latin-1"), hits, args.l)
+        if once:
             dataset = rows.NativeDataset() if native else rows.Dataset()  # opt-in fix of CROPSR.py:407
         dataset.append(block)
         if verbose:
@@ -193,12 +206,17 @@ def run(args, backend=None, out=sys.stdout):
             print(f"""
                 {n_sites:n} Cas9 PAM sites were found on {name[1::]}
                 """, file=out)
-        (rows.write_pass_native if native else rows.write_pass)(args.o, dataset, backend.rescore)  # CROPSR.py:442-474
+        if native:  # CROPSR.py:442-474
+            rows.write_pass_native(args.o, dataset, backend.rescore, ids)
+        else:
+            rows.write_pass(args.o, dataset, backend.rescore)
         end = time.time()
         timing.write("Total runtime of the program is " + str(end - begin))  # CROPSR.py:477
         if getattr(args, "reference_sleep", False):
             time.sleep(5)  # CROPSR.py:478
     timing.close()
+    if ids is not None:
+        ids.close()
     if own_backend:
         backend.close()
     if verbose:

@@ -103,6 +103,7 @@ const char *crp_strerror(int status)
         case CRP_ERR_STATE: return "call out of order";
         case CRP_ERR_CAPACITY: return "arena capacity exceeded";
         case CRP_ERR_UNSUPPORTED: return "unsupported parameter";
+        case CRP_ERR_IO: return "write to the output descriptor failed";
         default: return "unknown status";
     }
 }

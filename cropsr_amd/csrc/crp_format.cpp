@@ -10,14 +10,26 @@
 //   * 12 fields for scored rows, 11 (no cutsite, literal -1) for the others (:466-468).
 // The strings are rebuilt from the contig text exactly as the reference slices and maps
 // them (chained str.replace = per-character maps, Python slice clamping at the end).
+//
+// Two entry points share one block formatter: crp_format_rows fills a caller buffer,
+// crp_write_rows appends to a file descriptor (workers format blocks of rows into
+// private buffers and commit them with write(2) in row order, so nothing the size of the
+// whole CSV is ever held in memory).
 #include "cropsr_hip.h"
 
 #include <algorithm>
+#include <atomic>
+#include <cerrno>
 #include <charconv>
+#include <condition_variable>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
+
+#include <unistd.h>
 
 namespace {
 
@@ -39,19 +51,24 @@ struct Maps {
 };
 const Maps kMaps;
 
-inline void put_int(std::string &o, int64_t v)
+inline char *put_lit(char *o, const char *s, size_t n)
 {
-    char buf[24];
-    auto r = std::to_chars(buf, buf + sizeof buf, v);
-    o.append(buf, r.ptr);
+    std::memcpy(o, s, n);
+    return o + n;
+}
+#define PUT_LIT(o, s) put_lit((o), (s), sizeof(s) - 1)
+
+inline char *put_int(char *o, int64_t v)
+{
+    return std::to_chars(o, o + 24, v).ptr;
 }
 
-// repr(float) of CPython (float_repr_style 'short')
-void put_repr(std::string &o, double x)
+// repr(float) of CPython (float_repr_style 'short'); at most 24 characters
+char *put_repr(char *o, double x)
 {
-    if (x != x) { o += "nan"; return; }
-    if (x == 1.0 / 0.0) { o += "inf"; return; }
-    if (x == -1.0 / 0.0) { o += "-inf"; return; }
+    if (x != x) return PUT_LIT(o, "nan");
+    if (x == 1.0 / 0.0) return PUT_LIT(o, "inf");
+    if (x == -1.0 / 0.0) return PUT_LIT(o, "-inf");
     char buf[64];
     auto r = std::to_chars(buf, buf + sizeof buf, x, std::chars_format::scientific);  // shortest round-trip
     // parse  [-]d[.ddd]e[+-]XX
@@ -71,57 +88,56 @@ void put_repr(std::string &o, double x)
         for (; p < r.ptr; ++p) e10 = e10 * 10 + (*p - '0');
         if (eneg) e10 = -e10;
     }
-    if (nd == 1 && digits[0] == '0') {  // +-0.0
-        o += neg ? "-0.0" : "0.0";
-        return;
-    }
+    if (nd == 1 && digits[0] == '0')  // +-0.0
+        return neg ? PUT_LIT(o, "-0.0") : PUT_LIT(o, "0.0");
     const int decpt = e10 + 1;  // value = 0.d1d2... * 10^decpt
-    if (neg) o += '-';
+    if (neg) *o++ = '-';
     if (decpt <= -4 || decpt > 16) {
-        o += digits[0];
+        *o++ = digits[0];
         if (nd > 1) {
-            o += '.';
-            o.append(digits + 1, nd - 1);
+            *o++ = '.';
+            o = put_lit(o, digits + 1, (size_t)(nd - 1));
         }
-        o += 'e';
+        *o++ = 'e';
         int ex = decpt - 1;
-        o += ex < 0 ? '-' : '+';
+        *o++ = ex < 0 ? '-' : '+';
         if (ex < 0) ex = -ex;
-        if (ex < 10) o += '0';
-        put_int(o, ex);
+        if (ex < 10) *o++ = '0';
+        o = put_int(o, ex);
     } else if (decpt <= 0) {
-        o += "0.";
-        o.append((size_t)(-decpt), '0');
-        o.append(digits, nd);
+        o = PUT_LIT(o, "0.");
+        std::memset(o, '0', (size_t)(-decpt));
+        o += -decpt;
+        o = put_lit(o, digits, (size_t)nd);
     } else if (decpt >= nd) {
-        o.append(digits, nd);
-        o.append((size_t)(decpt - nd), '0');
-        o += ".0";
+        o = put_lit(o, digits, (size_t)nd);
+        std::memset(o, '0', (size_t)(decpt - nd));
+        o += decpt - nd;
+        o = PUT_LIT(o, ".0");
     } else {
-        o.append(digits, decpt);
-        o += '.';
-        o.append(digits + decpt, nd - decpt);
+        o = put_lit(o, digits, (size_t)decpt);
+        *o++ = '.';
+        o = put_lit(o, digits + decpt, (size_t)(nd - decpt));
     }
+    return o;
 }
 
-// one csv field, QUOTE_MINIMAL
-void put_field(std::string &o, const uint8_t *s, size_t n)
+// one csv field, QUOTE_MINIMAL; at most 2 n + 2 characters
+char *put_field(char *o, const uint8_t *s, size_t n)
 {
     bool quote = false;
     for (size_t k = 0; k < n; ++k) {
         const uint8_t c = s[k];
         if (c == ',' || c == '"' || c == '\r' || c == '\n') { quote = true; break; }
     }
-    if (!quote) {
-        o.append(reinterpret_cast<const char *>(s), n);
-        return;
-    }
-    o += '"';
+    if (!quote) return put_lit(o, reinterpret_cast<const char *>(s), n);
+    *o++ = '"';
     for (size_t k = 0; k < n; ++k) {
-        if (s[k] == '"') o += '"';
-        o += (char)s[k];
+        if (s[k] == '"') *o++ = '"';
+        *o++ = (char)s[k];
     }
-    o += '"';
+    *o++ = '"';
+    return o;
 }
 
 // text[a:b] with Python clamping, mapped; '+' strand output is reversed
@@ -149,14 +165,27 @@ struct Job {
     const uint8_t *minus;
     const double *score;
     const uint8_t *ids;
+    std::string chrom_field;  // the chromosome column as csv writes it
+    size_t row_bound;         // no row is longer than this
+
+    Job(const uint8_t *text_, uint64_t len_, const uint8_t *chrom_, uint64_t chrom_len_, int l_, const uint32_t *pos_,
+        const uint8_t *minus_, const double *score_, const uint8_t *ids_)
+        : text(text_), len(len_), chrom(chrom_), chrom_len(chrom_len_), l(l_), pos(pos_), minus(minus_),
+          score(score_), ids(ids_)
+    {
+        chrom_field.resize(2 * chrom_len + 2);
+        char *e = put_field(&chrom_field[0], chrom, chrom_len);
+        chrom_field.resize((size_t)(e - chrom_field.data()));
+        // id 7 + ",cas9," 6 + short <= 2l+2 + long <= 2(l+10)+2 + 3 ints <= 11 each + repr <= 24
+        // + strand, commas, ",,completed\r\n" <= 24
+        row_bound = 7 + 6 + (2 * (size_t)l + 2) + (2 * ((size_t)l + 10) + 2) + chrom_field.size() + 33 + 24 + 24;
+    }
 };
 
-void format_range(const Job &j, uint64_t r0, uint64_t r1, std::string &o)
+// rows [r0, r1) -> o (room for (r1 - r0) * row_bound bytes); returns the end
+char *format_range(const Job &j, uint64_t r0, uint64_t r1, char *o)
 {
-    uint8_t shortbuf[128], longbuf[160];
-    std::string chrom_field;
-    put_field(chrom_field, j.chrom, j.chrom_len);
-    o.reserve((size_t)(r1 - r0) * (150 + chrom_field.size()));
+    uint8_t shortbuf[64], longbuf[80];
     const int l = j.l;
     for (uint64_t r = r0; r < r1; ++r) {
         const bool minus = j.minus[r] != 0;
@@ -175,27 +204,55 @@ void format_range(const Job &j, uint64_t r0, uint64_t r1, std::string &o)
         }
         const size_t ns = mapped_slice(j.text, j.len, sa, sb, minus, shortbuf);
         const size_t nl = mapped_slice(j.text, j.len, sa - 5, sb + 5, minus, longbuf);
-        o.append(reinterpret_cast<const char *>(j.ids + 7 * r), 7);
-        o += ",cas9,";
-        put_field(o, shortbuf, ns);
-        o += ',';
-        put_field(o, longbuf, nl);
-        o += ',';
-        o += chrom_field;
-        o += ',';
-        put_int(o, start);
-        o += ',';
-        put_int(o, end);
-        o += ',';
+        o = put_lit(o, reinterpret_cast<const char *>(j.ids + 7 * r), 7);
+        o = PUT_LIT(o, ",cas9,");
+        o = put_field(o, shortbuf, ns);
+        *o++ = ',';
+        o = put_field(o, longbuf, nl);
+        *o++ = ',';
+        o = put_lit(o, j.chrom_field.data(), j.chrom_field.size());
+        *o++ = ',';
+        o = put_int(o, start);
+        *o++ = ',';
+        o = put_int(o, end);
+        *o++ = ',';
         if (nl == 30) {  // CROPSR.py:466: 12 fields with cutsite (end - 3) and the score
-            put_int(o, end - 3);
-            o += minus ? ",-," : ",+,";
-            put_repr(o, j.score[r]);
-            o += ",,completed\r\n";
+            o = put_int(o, end - 3);
+            o = minus ? PUT_LIT(o, ",-,") : PUT_LIT(o, ",+,");
+            o = put_repr(o, j.score[r]);
+            o = PUT_LIT(o, ",,completed\r\n");
         } else {         // 11 fields, literal -1
-            o += minus ? "-,-1,,completed\r\n" : "+,-1,,completed\r\n";
+            o = minus ? PUT_LIT(o, "-,-1,,completed\r\n") : PUT_LIT(o, "+,-1,,completed\r\n");
         }
     }
+    return o;
+}
+
+bool bad_args(const uint8_t *contig_text, const uint8_t *chrom, uint64_t chrom_len, int guide_len, const uint32_t *pos,
+              const uint8_t *minus, const double *score, const uint8_t *ids, uint64_t n_rows)
+{
+    if (guide_len < 1 || guide_len > 50) return true;
+    if (n_rows && (!contig_text || !pos || !minus || !score || !ids)) return true;
+    return chrom_len && !chrom;
+}
+
+int clamp_threads(int n_threads, uint64_t n_rows, uint64_t rows_per_thread_min)
+{
+    int nt = n_threads < 1 ? 1 : n_threads;
+    if ((uint64_t)nt > n_rows / rows_per_thread_min + 1) nt = (int)(n_rows / rows_per_thread_min + 1);
+    return nt;
+}
+
+template <class F>
+void run_threads(int nt, F &&work)
+{
+    if (nt == 1) {
+        work(0);
+        return;
+    }
+    std::vector<std::thread> pool;
+    for (int t = 0; t < nt; ++t) pool.emplace_back(work, t);
+    for (auto &th : pool) th.join();
 }
 
 }  // namespace
@@ -205,40 +262,101 @@ extern "C" int crp_format_rows(const uint8_t *contig_text, uint64_t contig_len, 
                                const double *score, const uint8_t *ids, uint64_t n_rows, uint8_t *out,
                                uint64_t out_cap, uint64_t *out_len, int n_threads)
 {
-    if (!out_len || guide_len < 1 || guide_len > 50) return CRP_ERR_INVALID;
-    if (n_rows && (!contig_text || !pos || !minus || !score || !ids)) return CRP_ERR_INVALID;
-    if (chrom_len && !chrom) return CRP_ERR_INVALID;
-    const Job job{contig_text, contig_len, chrom, chrom_len, guide_len, pos, minus, score, ids};
-    int nt = n_threads < 1 ? 1 : n_threads;
-    if ((uint64_t)nt > n_rows / 4096 + 1) nt = (int)(n_rows / 4096 + 1);
-    std::vector<std::string> parts((size_t)nt);
-    const uint64_t per = (n_rows + nt - 1) / nt;
-    std::vector<char> failed((size_t)nt, 0);
-    auto work = [&](int t) {
-        const uint64_t r0 = std::min<uint64_t>(n_rows, per * t), r1 = std::min<uint64_t>(n_rows, r0 + per);
-        try {
-            format_range(job, r0, r1, parts[(size_t)t]);
-        } catch (...) {
-            failed[(size_t)t] = 1;  // out of memory: nothing may escape a thread or the C ABI
+    if (!out_len || bad_args(contig_text, chrom, chrom_len, guide_len, pos, minus, score, ids, n_rows))
+        return CRP_ERR_INVALID;
+    try {
+        const Job job(contig_text, contig_len, chrom, chrom_len, guide_len, pos, minus, score, ids);
+        const int nt = clamp_threads(n_threads, n_rows, 4096);
+        const uint64_t per = (n_rows + nt - 1) / nt;
+        // pass 1: every thread formats its rows into a private buffer (malloc: untouched pages cost nothing)
+        std::vector<char *> part((size_t)nt, nullptr);
+        std::vector<uint64_t> used((size_t)nt, 0);
+        std::atomic<int> failed{0};
+        run_threads(nt, [&](int t) {
+            const uint64_t r0 = std::min<uint64_t>(n_rows, per * t), r1 = std::min<uint64_t>(n_rows, r0 + per);
+            if (r1 == r0) return;
+            char *buf = static_cast<char *>(std::malloc((size_t)(r1 - r0) * job.row_bound));
+            if (!buf) {
+                failed = 1;
+                return;
+            }
+            part[(size_t)t] = buf;
+            used[(size_t)t] = (uint64_t)(format_range(job, r0, r1, buf) - buf);
+        });
+        uint64_t total = 0;
+        std::vector<uint64_t> at((size_t)nt, 0);
+        for (int t = 0; t < nt; ++t) {
+            at[(size_t)t] = total;
+            total += used[(size_t)t];
         }
-    };
-    if (nt == 1) {
-        work(0);
-    } else {
-        std::vector<std::thread> pool;
-        for (int t = 0; t < nt; ++t) pool.emplace_back(work, t);
-        for (auto &th : pool) th.join();
+        *out_len = total;
+        int st = CRP_OK;
+        if (failed) st = CRP_ERR_NOMEM;
+        else if (total > out_cap || (total && !out)) st = CRP_ERR_CAPACITY;
+        // pass 2: the parts move to their places in parallel
+        if (st == CRP_OK)
+            run_threads(nt, [&](int t) {
+                if (used[(size_t)t]) std::memcpy(out + at[(size_t)t], part[(size_t)t], used[(size_t)t]);
+            });
+        for (char *b : part) std::free(b);
+        return st;
+    } catch (...) {
+        return CRP_ERR_NOMEM;  // nothing may escape the C ABI
     }
-    for (char f : failed)
-        if (f) return CRP_ERR_NOMEM;
-    uint64_t total = 0;
-    for (auto &s : parts) total += s.size();
-    *out_len = total;
-    if (total > out_cap || (total && !out)) return CRP_ERR_CAPACITY;
-    uint64_t off = 0;
-    for (auto &s : parts) {
-        std::memcpy(out + off, s.data(), s.size());
-        off += s.size();
+}
+
+extern "C" int crp_write_rows(int fd, const uint8_t *contig_text, uint64_t contig_len, const uint8_t *chrom,
+                              uint64_t chrom_len, int guide_len, const uint32_t *pos, const uint8_t *minus,
+                              const double *score, const uint8_t *ids, uint64_t n_rows, uint64_t *bytes_written,
+                              int n_threads)
+{
+    if (fd < 0 || bad_args(contig_text, chrom, chrom_len, guide_len, pos, minus, score, ids, n_rows))
+        return CRP_ERR_INVALID;
+    if (bytes_written) *bytes_written = 0;
+    if (n_rows == 0) return CRP_OK;
+    try {
+        const Job job(contig_text, contig_len, chrom, chrom_len, guide_len, pos, minus, score, ids);
+        constexpr uint64_t kBlockRows = 16384;
+        const uint64_t n_blocks = (n_rows + kBlockRows - 1) / kBlockRows;
+        const int nt = (int)std::min<uint64_t>((uint64_t)(n_threads < 1 ? 1 : n_threads), n_blocks);
+        std::atomic<uint64_t> next_block{0};
+        std::mutex mu;
+        std::condition_variable turn;
+        uint64_t committed = 0;  // blocks written so far (guarded by mu)
+        uint64_t total = 0;
+        int status = CRP_OK;
+        run_threads(nt, [&](int) {
+            char *buf = static_cast<char *>(std::malloc((size_t)kBlockRows * job.row_bound));
+            for (;;) {
+                const uint64_t b = next_block.fetch_add(1);
+                if (b >= n_blocks) break;
+                const uint64_t r0 = b * kBlockRows, r1 = std::min(n_rows, r0 + kBlockRows);
+                const size_t n = buf ? (size_t)(format_range(job, r0, r1, buf) - buf) : 0;
+                std::unique_lock<std::mutex> lock(mu);
+                turn.wait(lock, [&] { return committed == b; });
+                if (!buf && status == CRP_OK) status = CRP_ERR_NOMEM;
+                if (status == CRP_OK) {  // blocks go out in row order; a failed write stops the output there
+                    size_t done = 0;
+                    while (done < n) {
+                        const ssize_t w = ::write(fd, buf + done, n - done);
+                        if (w < 0) {
+                            if (errno == EINTR) continue;
+                            status = CRP_ERR_IO;
+                            break;
+                        }
+                        done += (size_t)w;
+                    }
+                    total += done;
+                }
+                ++committed;
+                lock.unlock();
+                turn.notify_all();
+            }
+            std::free(buf);
+        });
+        if (bytes_written) *bytes_written = total;
+        return status;
+    } catch (...) {
+        return CRP_ERR_NOMEM;
     }
-    return CRP_OK;
 }

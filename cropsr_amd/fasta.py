@@ -66,8 +66,9 @@ def load(path):
 # record has a header line and a body -- the printed form is predictable:
 #     key   = "[('" + header + "',"      (first record)   "('" + header + "',"   (others)
 #     value = "'" + body + "'),"         (not last)        "'" + body + "')]"     (last)
-# and is built directly from the bytes of the file (bytes.translate strips the
-# newlines at C speed).  Anything else falls back to contig_table() above.
+# and is built directly from the bytes of the file: by table_from_bytes_python with
+# bytes methods (the executable specification), and by table_from_bytes through the
+# native loader, which is what the CLI uses.  Anything else falls back to contig_table().
 _PLAIN = bytes(c for c in range(33, 127) if c not in (0x27, 0x5C))
 
 
@@ -75,9 +76,18 @@ def _plain(b):
     return not b.translate(None, _PLAIN)
 
 
-def table_from_bytes(data):
+def _merge(pairs):
+    merged = {}
+    for k, v in pairs:  # dict semantics: first position, last value
+        merged[k] = v
+    return list(merged.items())
+
+
+def table_from_bytes_python(data):
     """[(key str, contig string as bytes)] in dict order, equal to
-    list(contig_table(data.decode()).items()) with the values encoded as ASCII."""
+    list(contig_table(data.decode()).items()) with the values encoded as ASCII.
+    Pure-Python form of the fast path (bytes methods); kept as the specification
+    the native loader is tested against."""
     formatted = 2 * data.count(b">") != data.count(b"\n") + 1
     fast = None
     if formatted:
@@ -107,10 +117,46 @@ def table_from_bytes(data):
     if fast is None:
         table = contig_table(data.decode("utf-8", "surrogateescape"))
         return [(k, v.encode("ascii", "replace")) for k, v in table.items()]
-    merged = {}
-    for k, v in fast:  # dict semantics: first position, last value
-        merged[k] = v
-    return list(merged.items())
+    return _merge(fast)
+
+
+def table_from_bytes(data, n_threads=None):
+    """The same table through the native loader (crp_fasta_table, cropsr_amd/csrc/crp_fasta.cpp):
+    one parallel pass over the file's bytes writes every contig string, already decorated,
+    into one buffer; the values returned are memoryview slices of it (no per-contig copies).
+    Inputs outside the native fast path take table_from_bytes_python."""
+    import ctypes
+
+    import numpy as np
+
+    from . import _native as nat
+    from .rows import default_threads
+    L = nat.lib()
+    n = len(data)
+    src = np.frombuffer(data, dtype=np.uint8)
+    n_threads = n_threads or default_threads()
+    out_cap, rec_cap = n + 65536, 16384
+    while True:
+        out = np.empty(out_cap, dtype=np.uint8)
+        recs = np.empty((rec_cap, 4), dtype=np.uint64)
+        n_recs, out_len, plain = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_int()
+        st = L.crp_fasta_table(src.ctypes.data_as(nat.u8p), n, out.ctypes.data_as(nat.u8p), out_cap,
+                               recs.ctypes.data_as(nat.u64p), rec_cap, ctypes.byref(n_recs), ctypes.byref(out_len),
+                               ctypes.byref(plain), n_threads)
+        if st == -6:  # CRP_ERR_CAPACITY: the needed sizes came back
+            out_cap, rec_cap = max(out_cap, int(out_len.value)), max(rec_cap, int(n_recs.value))
+            continue
+        nat.check(st, "crp_fasta_table")
+        break
+    if not plain.value:
+        return table_from_bytes_python(bytes(data))
+    view = memoryview(out)
+    src_view = memoryview(data)
+    pairs = []
+    for k, (h0, hl, v0, vl) in enumerate(recs[:n_recs.value].tolist()):
+        key = ("[('" if k == 0 else "('") + bytes(src_view[h0:h0 + hl]).decode("ascii") + "',"
+        pairs.append((key, view[v0:v0 + vl]))
+    return _merge(pairs)
 
 
 def read_text_bytes(path):

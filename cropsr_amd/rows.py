@@ -17,6 +17,7 @@ Reference behaviours preserved on purpose:
 """
 import csv
 import ctypes
+import os
 
 import numpy as np
 
@@ -225,13 +226,22 @@ class ContigTable:
         return minus_text(piece, 0, len(piece)) if self.minus[k] else plus_text(piece, 0, len(piece))
 
 
+def default_threads():
+    """Formatter threads: the CPUs this process may run on, at most 32."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(32, n))
+
+
 class NativeDataset:
     """Complete_dataset over ContigTables + the chunk formatter."""
 
-    def __init__(self, n_threads=8):
+    def __init__(self, n_threads=None):
         self.blocks = []
         self.starts = [0]
-        self.n_threads = n_threads
+        self.n_threads = n_threads or default_threads()
 
     def append(self, block):
         self.blocks.append(block)
@@ -240,24 +250,27 @@ class NativeDataset:
     def __len__(self):
         return self.starts[-1]
 
-    def chunk_bytes(self, lo, count, ids_u8, index_range, rescore):
-        """CSV bytes of dataset[lo:lo+count], one rs1_score batch of the reference
-        (ids consumed backwards, tail rows re-scored: see Dataset.rows)."""
-        from . import _native as nat
-        L = nat.lib()
+    def _segments(self, lo, count, ids_u8, index_range, rescore):
+        """dataset[lo:lo+count], one rs1_score batch of the reference, cut at contig borders:
+        yields (block, pos, minus, score, ids) per piece (ids consumed backwards, tail rows
+        re-scored: see Dataset.rows)."""
         size = len(self)
         hi = min(lo + count, size)
         n = hi - lo
         if n <= 0:
-            return b""
-        sel = ids_u8[index_range - np.arange(n) - 1]  # negative indices wrap like Python's
+            return
+        if index_range - n >= 0:  # row r takes ids[index_range - r - 1]: a reversed slice, no gather
+            sel = ids_u8[index_range - n:index_range][::-1]
+        elif index_range == 0 and n <= len(ids_u8):  # ids[-1], ids[-2], ...: the tail, reversed
+            sel = ids_u8[len(ids_u8) - n:][::-1]
+        else:
+            sel = ids_u8[index_range - np.arange(n) - 1]  # negative indices wrap like Python's
         if n == 1:
             special, order = [0], ORDER_DOT1
         elif n % 4 >= 2:
             special, order = [4 * (n // 4), 4 * (n // 4) + 1], ORDER_TAIL2
         else:
             special, order = [], ORDER_BODY4
-        out = []
         b = int(np.searchsorted(self.starts, lo, "right") - 1)
         g = lo
         while g < hi:
@@ -276,28 +289,54 @@ class NativeDataset:
                         t = blk.long_text(k0 + j).replace("U", "T").upper()  # CROPSR.py:458
                         seqs[r] = np.frombuffer(t.encode("ascii", "replace"), dtype=np.uint8)
                     score[fix] = rescore(seqs, order)
-                ids_part = np.ascontiguousarray(sel[g - lo:g - lo + m])
-                pos = blk.pos[k0:k1]
-                minus = blk.minus[k0:k1]
-                cap = m * (170 + 2 * len(blk.chrom)) + 64
-                while True:
-                    buf = np.empty(cap, dtype=np.uint8)
-                    used = ctypes.c_uint64()
-                    st = L.crp_format_rows(
-                        blk.text.ctypes.data_as(nat.u8p), blk.text.size,
-                        ctypes.cast(ctypes.c_char_p(blk.chrom), nat.u8p), len(blk.chrom), blk.guide_len,
-                        pos.ctypes.data_as(nat.u32p), minus.ctypes.data_as(nat.u8p),
-                        score.ctypes.data_as(nat.f64p), ids_part.ctypes.data_as(nat.u8p), m,
-                        buf.ctypes.data_as(nat.u8p), cap, ctypes.byref(used), self.n_threads)
-                    if st == -6 and used.value > cap:  # CRP_ERR_CAPACITY: retry with the size it asked for
-                        cap = int(used.value)
-                        continue
-                    nat.check(st, "crp_format_rows")
-                    break
-                out.append(buf[:used.value].tobytes())
+                yield blk, blk.pos[k0:k1], blk.minus[k0:k1], score, np.ascontiguousarray(sel[g - lo:g - lo + m])
             g = base + blk.n
             b += 1
+
+    def chunk_bytes(self, lo, count, ids_u8, index_range, rescore):
+        """CSV bytes of one written chunk (crp_format_rows)."""
+        from . import _native as nat
+        L = nat.lib()
+        out = []
+        for blk, pos, minus, score, ids_part in self._segments(lo, count, ids_u8, index_range, rescore):
+            m = pos.size
+            cap = m * (170 + 2 * len(blk.chrom)) + 64
+            while True:
+                buf = np.empty(cap, dtype=np.uint8)
+                used = ctypes.c_uint64()
+                st = L.crp_format_rows(
+                    blk.text.ctypes.data_as(nat.u8p), blk.text.size,
+                    ctypes.cast(ctypes.c_char_p(blk.chrom), nat.u8p), len(blk.chrom), blk.guide_len,
+                    pos.ctypes.data_as(nat.u32p), minus.ctypes.data_as(nat.u8p),
+                    score.ctypes.data_as(nat.f64p), ids_part.ctypes.data_as(nat.u8p), m,
+                    buf.ctypes.data_as(nat.u8p), cap, ctypes.byref(used), self.n_threads)
+                if st == -6 and used.value > cap:  # CRP_ERR_CAPACITY: retry with the size it asked for
+                    cap = int(used.value)
+                    continue
+                nat.check(st, "crp_format_rows")
+                break
+            out.append(buf[:used.value].tobytes())
         return b"".join(out)
+
+    def chunk_to_fd(self, fd, lo, count, ids_u8, index_range, rescore):
+        """The same chunk appended to file descriptor fd (crp_write_rows); returns the byte count."""
+        from . import _native as nat
+        L = nat.lib()
+        total = 0
+        for blk, pos, minus, score, ids_part in self._segments(lo, count, ids_u8, index_range, rescore):
+            written = ctypes.c_uint64()
+            st = L.crp_write_rows(
+                fd, blk.text.ctypes.data_as(nat.u8p), blk.text.size,
+                ctypes.cast(ctypes.c_char_p(blk.chrom), nat.u8p), len(blk.chrom), blk.guide_len,
+                pos.ctypes.data_as(nat.u32p), minus.ctypes.data_as(nat.u8p),
+                score.ctypes.data_as(nat.f64p), ids_part.ctypes.data_as(nat.u8p), pos.size,
+                ctypes.byref(written), self.n_threads)
+            total += written.value
+            if st == nat.CRP_ERR_IO:
+                err = ctypes.get_errno()
+                raise OSError(err, "crp_write_rows: " + os.strerror(err))
+            nat.check(st, "crp_write_rows")
+        return total
 
 
 def ids_as_bytes(ids_u1):
@@ -306,14 +345,76 @@ def ids_as_bytes(ids_u1):
     return a.view(np.uint32).astype(np.uint8).reshape(a.shape[0], 7) if a.size else np.empty((0, 7), np.uint8)
 
 
-def write_pass_native(path, dataset, rescore):
-    """write_pass with the native formatter: same RNG draws, same chunk walk, same bytes."""
+_ID_LUT = np.frombuffer(b"ABCDEFGHIJKLMNOPQRSTUVWXYZ0123456789", dtype=np.uint8)
+
+
+def draw_ids(size, generator=None, piece=1 << 20):
+    """(size, 7) uint8 crispr ids of one write pass (CROPSR.py:316-318).
+
+    np.random.choice(alphanum, [size, 7]) IS alphanum[np.random.randint(0, 36, [size, 7])]
+    (legacy RandomState.choice, uniform, with replacement): same draws and the same global RNG
+    state afterwards, also when drawn in pieces of rows (tests/test_format.py) -- so no UCS-4
+    string array and no size x 7 int64 array are ever built.  `generator` (a numpy Generator)
+    replaces the global legacy stream when the caller does not need the reference's draws."""
+    out = np.empty((size, 7), dtype=np.uint8)
+    for lo in range(0, size, piece):
+        m = min(piece, size - lo)
+        if generator is None:
+            np.take(_ID_LUT, np.random.randint(0, 36, size=[m, 7]), out=out[lo:lo + m])
+        else:
+            np.take(_ID_LUT, generator.integers(0, 36, size=[m, 7], dtype=np.uint8), out=out[lo:lo + m])
+    return out
+
+
+class IdStream:
+    """The ids of consecutive write passes, drawn ahead of their use on a worker thread.
+
+    The passes of one run draw from one RNG stream in a fixed order and their sizes are known
+    once the scan is done, so pass k+1's ids are drawn while pass k is formatted and written.
+    Nothing else may touch np.random while the stream is open."""
+
+    def __init__(self, sizes, generator=None, depth=2):
+        import queue
+        import threading
+        self._sizes = list(sizes)
+        self._q = queue.Queue(maxsize=depth)
+        self._stop = False
+
+        def work():
+            try:
+                for size in self._sizes:
+                    if self._stop:
+                        return
+                    self._q.put((size, draw_ids(size, generator)))
+            except BaseException as e:  # handed to the consumer
+                self._q.put((None, e))
+
+        self._thread = threading.Thread(target=work, daemon=True)
+        self._thread.start()
+
+    def next(self, size):
+        got, ids = self._q.get()
+        if got is None:
+            raise ids
+        if got != size:
+            raise RuntimeError("IdStream: pass of %d rows, ids drawn for %d" % (size, got))
+        return ids
+
+    def close(self):
+        self._stop = True
+        while self._thread.is_alive():
+            try:
+                self._q.get(timeout=0.05)
+            except Exception:
+                pass
+
+
+def write_pass_native(path, dataset, rescore, ids=None):
+    """write_pass with the native formatter: same RNG draws, same chunk walk, same bytes.
+    `ids` (an IdStream) supplies ids drawn ahead; by default they are drawn here."""
     size = len(dataset)
-    # np.random.choice(alphanum, [size, 7]) IS alphanum[np.random.randint(0, 36, [size, 7])]
-    # (legacy RandomState.choice, uniform, with replacement): same draws, same RNG state
-    # afterwards (tests/test_format.py), without building a UCS-4 string array.
-    lut = np.frombuffer(b"ABCDEFGHIJKLMNOPQRSTUVWXYZ0123456789", dtype=np.uint8)
-    ids_u8 = lut[np.random.randint(0, 36, size=[size, 7])]
+    ids_u8 = draw_ids(size) if ids is None else ids.next(size)
     with open(path, "ab") as f:
+        fd = f.fileno()
         for index_range, count in flush_plan(size):
-            f.write(dataset.chunk_bytes(index_range, count, ids_u8, index_range, rescore))
+            dataset.chunk_to_fd(fd, index_range, count, ids_u8, index_range, rescore)

@@ -48,7 +48,8 @@ typedef enum crp_status {
     CRP_ERR_NOMEM = -4,       /* host or device allocation failed */
     CRP_ERR_STATE = -5,       /* call out of order (e.g. scan before seal) */
     CRP_ERR_CAPACITY = -6,    /* arena capacity exceeded */
-    CRP_ERR_UNSUPPORTED = -7  /* e.g. guide length outside [1, 50] */
+    CRP_ERR_UNSUPPORTED = -7, /* e.g. guide length outside [1, 50] */
+    CRP_ERR_IO = -8           /* write(2) on the caller's descriptor failed; errno is left set */
 } crp_status;
 
 typedef struct crp_ctx crp_ctx;
@@ -160,6 +161,35 @@ int crp_format_rows(const uint8_t *contig_text, uint64_t contig_len, const uint8
                     int guide_len, const uint32_t *pos, const uint8_t *minus, const double *score,
                     const uint8_t *ids, uint64_t n_rows, uint8_t *out, uint64_t out_cap, uint64_t *out_len,
                     int n_threads);
+
+/* The same rows appended to an open file descriptor instead of a buffer: the stand-in for
+ * csv.writer(file).writerows(rows) at CROPSR.py:471-474 when the rows of a chunk are not
+ * wanted in memory.  n_threads workers format blocks of 16384 rows and commit them with
+ * write(2) in row order (a descriptor opened with O_APPEND, like Python's mode "a", appends).
+ * *bytes_written (may be NULL) receives the number of bytes written; on CRP_ERR_IO the output
+ * stops at a block boundary.  Flush any buffered writer on the same file before the call. */
+int crp_write_rows(int fd, const uint8_t *contig_text, uint64_t contig_len, const uint8_t *chrom, uint64_t chrom_len,
+                   int guide_len, const uint32_t *pos, const uint8_t *minus, const double *score,
+                   const uint8_t *ids, uint64_t n_rows, uint64_t *bytes_written, int n_threads);
+
+/* ---- input side: FASTA bytes -> contig strings (host code, no GPU needed) ----- */
+/* The contig table import_fasta_file builds (CROPSR.py:54-74 with cropsr_functions.py:221-229
+ * and :190-196) for a file in the "re-formatted" path whose records all have a header line and
+ * whose headers and bodies are plain (printable ASCII without blank, quote, backslash):
+ *   data/n        the file's bytes as text mode hands them over (newlines already '\n')
+ *   out_text      receives the VALUE strings back to back: for record k
+ *                 ' + body without newlines + ') + (',' or, for the last record, ']')
+ *                 -- the exact character string CROPSR.py:412-434 scans for that contig
+ *   records       4 x uint64 per record: header offset and length in `data`, value offset and
+ *                 length in `out_text` (the host prepends  [('  or  ('  and appends  ',  to the
+ *                 header to get the dict key, and applies dict semantics to repeated keys)
+ * *plain = 1 when the table was produced.  *plain = 0 (with CRP_OK) means the input is outside
+ * this fast path -- already two lines per record, a header with a blank or quote, a record
+ * without a newline, no record at all -- and the caller must build the table the literal way.
+ * CRP_ERR_CAPACITY reports the needed sizes in *n_records / *out_len (out_cap >= n + 4 * records
+ * always suffices).  Work is spread over n_threads threads in 4 MiB pieces of the input. */
+int crp_fasta_table(const uint8_t *data, uint64_t n, uint8_t *out_text, uint64_t out_cap, uint64_t *records,
+                    uint64_t records_cap, uint64_t *n_records, uint64_t *out_len, int *plain, int n_threads);
 
 /* ---- options -------------------------------------------------------------- */
 /* CRP_OPT_TWO_PASS (value 0/1, default 1): crp_scan_score runs the count / tile-scan

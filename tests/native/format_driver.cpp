@@ -1,0 +1,62 @@
+// Sanitizer driver for the host-side formatter (crp_format.cpp): random rows, including
+// windows that hang over both contig ends and fields that need quoting, through
+// crp_format_rows and crp_write_rows; the two must produce the same bytes.
+// Built and run by tests/test_sanitizers.py with -fsanitize=address,undefined and =thread.
+#include "cropsr_hip.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <string>
+#include <vector>
+
+#include <unistd.h>
+
+int main(int argc, char **argv)
+{
+    const char *path = argc > 1 ? argv[1] : "/tmp/format_driver.out";
+    std::mt19937_64 rng(7);
+    const char alphabet[] = "ACGTacgtNUZ,\"'\r\n)]";
+    int failures = 0;
+    for (int round = 0; round < 6; ++round) {
+        const uint64_t len = round == 0 ? 0 : 40 + rng() % 5000;
+        const uint64_t n = round == 0 ? 0 : (round == 5 ? 70000 : 1 + rng() % 3000);
+        const int l = round == 3 ? 50 : (round == 4 ? 1 : 20);
+        std::vector<uint8_t> text(len);
+        for (auto &c : text) c = (uint8_t)alphabet[rng() % (sizeof alphabet - 1)];
+        std::vector<uint32_t> pos(n);
+        std::vector<uint8_t> minus(n), ids(7 * n);
+        std::vector<double> score(n);
+        for (uint64_t r = 0; r < n; ++r) {
+            pos[r] = (uint32_t)(rng() % (len + 8));
+            minus[r] = (uint8_t)(rng() & 1);
+            score[r] = (double)(rng() % 1000003) / 1000003.0 * (r % 7 == 0 ? 1e-9 : 1.0);
+            for (int k = 0; k < 7; ++k) ids[7 * r + k] = (uint8_t)('A' + rng() % 26);
+        }
+        const std::string chrom = round % 2 ? "Chr,\"1\"" : "Chr01";
+        std::vector<uint8_t> out(n * 512 + 64);
+        uint64_t used = 0;
+        int st = crp_format_rows(text.data(), len, (const uint8_t *)chrom.data(), chrom.size(), l, pos.data(),
+                                 minus.data(), score.data(), ids.data(), n, out.data(), out.size(), &used, 4);
+        if (st != CRP_OK) { std::printf("format_rows status %d\n", st); ++failures; continue; }
+        uint64_t need = 0;
+        st = crp_format_rows(text.data(), len, (const uint8_t *)chrom.data(), chrom.size(), l, pos.data(),
+                             minus.data(), score.data(), ids.data(), n, out.data(), used ? used - 1 : 0, &need, 2);
+        if (n && (st != CRP_ERR_CAPACITY || need != used)) { std::printf("capacity probe %d\n", st); ++failures; }
+        std::FILE *f = std::fopen(path, "wb");
+        if (!f) return 2;
+        uint64_t written = 0;
+        st = crp_write_rows(fileno(f), text.data(), len, (const uint8_t *)chrom.data(), chrom.size(), l, pos.data(),
+                            minus.data(), score.data(), ids.data(), n, &written, 6);
+        std::fclose(f);
+        if (st != CRP_OK || written != used) { std::printf("write_rows status %d\n", st); ++failures; continue; }
+        std::vector<uint8_t> back(used);
+        f = std::fopen(path, "rb");
+        const size_t got = used ? std::fread(back.data(), 1, used, f) : 0;
+        std::fclose(f);
+        if (got != used || !std::equal(back.begin(), back.end(), out.begin())) { std::printf("bytes differ\n"); ++failures; }
+    }
+    unlink(path);
+    std::printf(failures ? "FAILED\n" : "OK\n");
+    return failures ? 1 : 0;
+}

@@ -126,3 +126,92 @@ def test_each_contig_once_option(oracle, manifest, tmp_path, monkeypatch):
         assert fa[0] == fb[0] and fa[2:] == fb[2:]
         ulp = abs(int(np.float64(fa[1]).view(np.int64)) - int(np.float64(fb[1]).view(np.int64)))
         assert ulp <= 4
+
+
+def _table_for(oracle, n, seed, alphabet=b"ACGTacgtN,\""):
+    rng = np.random.default_rng(seed)
+    s = "'" + rng.choice(np.frombuffer(alphabet, dtype=np.uint8), n).tobytes().decode() + "'),"
+    table = rows.ContigTable("[('c,\"x',", s, oracle.scan_score(s.encode(), 20), 20)
+    ids_u8, _ = _ids(table.n, rng)
+    return table, ids_u8
+
+
+def _format_direct(table, ids_u8, threads):
+    import ctypes
+    from cropsr_amd import _native as nat
+    cap = table.n * 400 + 64
+    buf = np.empty(cap, dtype=np.uint8)
+    used = ctypes.c_uint64()
+    st = nat.lib().crp_format_rows(
+        table.text.ctypes.data_as(nat.u8p), table.text.size, ctypes.cast(ctypes.c_char_p(table.chrom), nat.u8p),
+        len(table.chrom), 20, table.pos.ctypes.data_as(nat.u32p), table.minus.ctypes.data_as(nat.u8p),
+        table.score.ctypes.data_as(nat.f64p), ids_u8.ctypes.data_as(nat.u8p), table.n,
+        buf.ctypes.data_as(nat.u8p), cap, ctypes.byref(used), threads)
+    assert st == 0
+    return buf[:used.value].tobytes()
+
+
+def _write_direct(fd, table, ids_u8, threads):
+    import ctypes
+    from cropsr_amd import _native as nat
+    written = ctypes.c_uint64(12345)
+    st = nat.lib().crp_write_rows(
+        fd, table.text.ctypes.data_as(nat.u8p), table.text.size, ctypes.cast(ctypes.c_char_p(table.chrom), nat.u8p),
+        len(table.chrom), 20, table.pos.ctypes.data_as(nat.u32p), table.minus.ctypes.data_as(nat.u8p),
+        table.score.ctypes.data_as(nat.f64p), ids_u8.ctypes.data_as(nat.u8p), table.n, ctypes.byref(written), threads)
+    return st, written.value
+
+
+@pytest.mark.parametrize("n,threads", [(0, 4), (300, 4), (200000, 1), (1500000, 5)])
+def test_write_rows_to_fd_equals_format_rows(oracle, tmp_path, n, threads):
+    """crp_write_rows appends exactly the bytes crp_format_rows returns (blocks of 16384 rows
+    committed in order by several workers), after whatever the file already holds."""
+    table, ids_u8 = _table_for(oracle, n, seed=n + threads)
+    want = _format_direct(table, ids_u8, 3)
+    assert want.count(b"\r\n") >= table.n
+    path = tmp_path / "rows.csv"
+    path.write_bytes(b"header\r\n")
+    with open(path, "ab") as f:
+        st, written = _write_direct(f.fileno(), table, ids_u8, threads)
+    assert st == 0 and written == len(want)
+    assert path.read_bytes() == b"header\r\n" + want
+
+
+def test_write_rows_reports_io_errors(oracle, tmp_path):
+    import ctypes
+    from cropsr_amd import _native as nat
+    table, ids_u8 = _table_for(oracle, 5000, seed=1)
+    path = tmp_path / "ro.csv"
+    path.write_bytes(b"")
+    with open(path, "rb") as f:  # not open for writing: write(2) fails with EBADF
+        st, written = _write_direct(f.fileno(), table, ids_u8, 2)
+    assert st == nat.CRP_ERR_IO and written == 0 and ctypes.get_errno() == 9
+    assert _write_direct(-1, table, ids_u8, 2)[0] == -1  # CRP_ERR_INVALID
+    ds = rows.NativeDataset(n_threads=2)
+    ds.append(table)
+    with open(path, "rb") as f, pytest.raises(OSError):
+        ds.chunk_to_fd(f.fileno(), 0, table.n, ids_u8, table.n, lambda seqs, order: np.zeros(len(seqs)))
+
+
+def test_ids_drawn_in_pieces_and_ahead():
+    """draw_ids (pieces of rows) and IdStream (worker thread, several passes) consume the global
+    legacy stream exactly as one np.random.randint(0, 36, [size, 7]) per pass does."""
+    lut = np.frombuffer(b"ABCDEFGHIJKLMNOPQRSTUVWXYZ0123456789", dtype=np.uint8)
+    sizes = [0, 5, 2500, 1, 777]
+    np.random.seed(11)
+    want = [lut[np.random.randint(0, 36, size=[n, 7])] for n in sizes]
+    after = np.random.random()
+    np.random.seed(11)
+    got = [rows.draw_ids(n, piece=1000) for n in sizes]
+    assert after == np.random.random() and all((a == b).all() for a, b in zip(want, got))
+    np.random.seed(11)
+    stream = rows.IdStream(sizes)
+    got = [stream.next(n) for n in sizes]
+    stream.close()
+    assert after == np.random.random() and all((a == b).all() for a, b in zip(want, got))
+    stream = rows.IdStream([3, 4])
+    with pytest.raises(RuntimeError):
+        stream.next(5)
+    stream.close()
+    fast = rows.draw_ids(20000, generator=np.random.default_rng(1))
+    assert fast.shape == (20000, 7) and set(np.unique(fast)) == set(lut.tolist())

@@ -1,0 +1,88 @@
+"""End-to-end timing of `python -m cropsr_amd` on a synthetic genome written as FASTA.
+
+usage: python tools/e2e_cli.py {ecoli|tair10|switchgrass[:scale]} [--reference-behaviour] [--profile]
+Writes the FASTA and the CSV under $TMPDIR (default /tmp), prints one JSON line.
+"""
+import argparse
+import cProfile
+import io
+import json
+import os
+import pstats
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def write_fasta(workload, path, width=60):
+    import numpy as np
+    with open(path, "wb") as f:
+        for spec in workload.specs:
+            a = workload.bases(spec)
+            f.write(b">" + spec.name.encode() + b"\n")
+            full = (a.size // width) * width
+            body = np.empty((a.size // width, width + 1), dtype=np.uint8)
+            body[:, :width] = a[:full].reshape(-1, width)
+            body[:, width] = 10
+            f.write(body.tobytes())
+            if a.size > full:
+                f.write(a[full:].tobytes() + b"\n")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("workload")
+    ap.add_argument("--reference-behaviour", action="store_true", help="re-emit earlier contigs like the reference")
+    ap.add_argument("--legacy-ids", action="store_true", help="ids from numpy's global legacy stream (reference draws)")
+    ap.add_argument("--profile", action="store_true")
+    ap.add_argument("--out", default=None)
+    a = ap.parse_args()
+    import bench_workload as bw
+    name, _, scale = a.workload.partition(":")
+    wl = {"ecoli": bw.ecoli_like, "tair10": bw.tair10_like}.get(name)
+    wl = wl() if wl else bw.switchgrass_like(scale=float(scale or 1.0))
+    tmp = os.environ.get("TMPDIR", "/tmp")
+    fa = os.path.join(tmp, "e2e_%s.fa" % wl.name)
+    gff = os.path.join(tmp, "e2e.gff")
+    out_csv = a.out or os.path.join(tmp, "e2e_out.csv")
+    t0 = time.time()
+    write_fasta(wl, fa)
+    with open(gff, "w") as f:
+        f.write("##gff-version 3\n")
+    t_gen = time.time() - t0
+    import torch  # noqa: F401  (the bundled HIP runtime must come up before the engine's)
+    from cropsr_amd import cli
+    argv = ["-f", fa, "-g", gff, "-o", out_csv, "--cas9", "--seed", "1"]
+    if not a.reference_behaviour:
+        argv.append("--each-contig-once")
+    if not a.legacy_ids:
+        argv.append("--fast-ids")
+    args = cli.build_parser().parse_args(argv)
+    os.chdir(tmp)
+    sink = io.StringIO()
+    prof = cProfile.Profile() if a.profile else None
+    t0 = time.time()
+    if prof:
+        prof.enable()
+    cli.run(args, out=sink)
+    if prof:
+        prof.disable()
+    wall = time.time() - t0
+    size = os.path.getsize(out_csv)
+    with open(out_csv, "rb") as f:
+        rows = sum(chunk.count(b"\n") for chunk in iter(lambda: f.read(1 << 24), b"")) - 1
+    print(json.dumps({"workload": wl.name, "bases": wl.n_bases, "rows": rows, "csv_bytes": size,
+                      "fasta_write_s": round(t_gen, 2), "cli_wall_s": round(wall, 3),
+                      "rows_per_s": round(rows / wall), "phases": getattr(cli, "LAST_PHASES", None)}))
+    if prof:
+        s = io.StringIO()
+        pstats.Stats(prof, stream=s).sort_stats("cumulative").print_stats(30)
+        print(s.getvalue())
+    os.remove(out_csv)
+    os.remove(fa)
+
+
+if __name__ == "__main__":
+    main()
