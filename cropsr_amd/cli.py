@@ -190,7 +190,7 @@ def run(args, backend=None, out=sys.stdout):
         import numpy as np
         sizes = per_contig if once else np.cumsum(per_contig).tolist()
         fast = np.random.default_rng() if getattr(args, "fast_ids", False) else None
-        ids = rows.IdStream(sizes, generator=fast)
+        ids = rows.IdStream(sizes, generator=fast, reverse=True)
     for name, s, hits in zip(names, strings, all_hits):
         print("Searching on Chromosome: ", name[:25], file=out)  # CROPSR.py:410-411
         print("With start of sequence: ", bytes(s[:25]).decode("latin-1"), file=out)

@@ -250,21 +250,26 @@ class NativeDataset:
     def __len__(self):
         return self.starts[-1]
 
-    def _segments(self, lo, count, ids_u8, index_range, rescore):
+    def _segments(self, lo, count, ids_u8, index_range, rescore, ids_rev=None):
         """dataset[lo:lo+count], one rs1_score batch of the reference, cut at contig borders:
         yields (block, pos, minus, score, ids) per piece (ids consumed backwards, tail rows
-        re-scored: see Dataset.rows)."""
+        re-scored: see Dataset.rows).  ids_rev, if given, is ids[::-1] as a contiguous array
+        and is used instead of ids_u8: row r takes ids[index_range - r - 1], i.e. consecutive
+        rows of ids_rev."""
         size = len(self)
         hi = min(lo + count, size)
         n = hi - lo
         if n <= 0:
             return
-        if index_range - n >= 0:  # row r takes ids[index_range - r - 1]: a reversed slice, no gather
-            sel = ids_u8[index_range - n:index_range][::-1]
-        elif index_range == 0 and n <= len(ids_u8):  # ids[-1], ids[-2], ...: the tail, reversed
-            sel = ids_u8[len(ids_u8) - n:][::-1]
-        else:
+        if ids_rev is None:
             sel = ids_u8[index_range - np.arange(n) - 1]  # negative indices wrap like Python's
+        else:
+            m_ids = len(ids_rev)
+            first = (m_ids - index_range) % m_ids
+            if first + n <= m_ids:
+                sel = ids_rev[first:first + n]
+            else:
+                sel = ids_rev[(first + np.arange(n)) % m_ids]
         if n == 1:
             special, order = [0], ORDER_DOT1
         elif n % 4 >= 2:
@@ -293,12 +298,12 @@ class NativeDataset:
             g = base + blk.n
             b += 1
 
-    def chunk_bytes(self, lo, count, ids_u8, index_range, rescore):
+    def chunk_bytes(self, lo, count, ids_u8, index_range, rescore, ids_rev=None):
         """CSV bytes of one written chunk (crp_format_rows)."""
         from . import _native as nat
         L = nat.lib()
         out = []
-        for blk, pos, minus, score, ids_part in self._segments(lo, count, ids_u8, index_range, rescore):
+        for blk, pos, minus, score, ids_part in self._segments(lo, count, ids_u8, index_range, rescore, ids_rev):
             m = pos.size
             cap = m * (170 + 2 * len(blk.chrom)) + 64
             while True:
@@ -318,12 +323,12 @@ class NativeDataset:
             out.append(buf[:used.value].tobytes())
         return b"".join(out)
 
-    def chunk_to_fd(self, fd, lo, count, ids_u8, index_range, rescore):
+    def chunk_to_fd(self, fd, lo, count, ids_u8, index_range, rescore, ids_rev=None):
         """The same chunk appended to file descriptor fd (crp_write_rows); returns the byte count."""
         from . import _native as nat
         L = nat.lib()
         total = 0
-        for blk, pos, minus, score, ids_part in self._segments(lo, count, ids_u8, index_range, rescore):
+        for blk, pos, minus, score, ids_part in self._segments(lo, count, ids_u8, index_range, rescore, ids_rev):
             written = ctypes.c_uint64()
             st = L.crp_write_rows(
                 fd, blk.text.ctypes.data_as(nat.u8p), blk.text.size,
@@ -348,8 +353,9 @@ def ids_as_bytes(ids_u1):
 _ID_LUT = np.frombuffer(b"ABCDEFGHIJKLMNOPQRSTUVWXYZ0123456789", dtype=np.uint8)
 
 
-def draw_ids(size, generator=None, piece=1 << 20):
-    """(size, 7) uint8 crispr ids of one write pass (CROPSR.py:316-318).
+def draw_ids(size, generator=None, piece=1 << 20, reverse=False):
+    """(size, 7) uint8 crispr ids of one write pass (CROPSR.py:316-318); with reverse=True the
+    same ids last-first (the order the reference consumes them in, CROPSR.py:448-449).
 
     np.random.choice(alphanum, [size, 7]) IS alphanum[np.random.randint(0, 36, [size, 7])]
     (legacy RandomState.choice, uniform, with replacement): same draws and the same global RNG
@@ -360,9 +366,13 @@ def draw_ids(size, generator=None, piece=1 << 20):
     for lo in range(0, size, piece):
         m = min(piece, size - lo)
         if generator is None:
-            np.take(_ID_LUT, np.random.randint(0, 36, size=[m, 7]), out=out[lo:lo + m])
+            draws = np.random.randint(0, 36, size=[m, 7])
         else:
-            np.take(_ID_LUT, generator.integers(0, 36, size=[m, 7], dtype=np.uint8), out=out[lo:lo + m])
+            draws = generator.integers(0, 36, size=[m, 7], dtype=np.uint8)
+        if reverse:
+            np.take(_ID_LUT, draws[::-1], out=out[size - lo - m:size - lo])
+        else:
+            np.take(_ID_LUT, draws, out=out[lo:lo + m])
     return out
 
 
@@ -373,7 +383,7 @@ class IdStream:
     once the scan is done, so pass k+1's ids are drawn while pass k is formatted and written.
     Nothing else may touch np.random while the stream is open."""
 
-    def __init__(self, sizes, generator=None, depth=2):
+    def __init__(self, sizes, generator=None, depth=2, reverse=False):
         import queue
         import threading
         self._sizes = list(sizes)
@@ -385,7 +395,7 @@ class IdStream:
                 for size in self._sizes:
                     if self._stop:
                         return
-                    self._q.put((size, draw_ids(size, generator)))
+                    self._q.put((size, draw_ids(size, generator, reverse=reverse)))
             except BaseException as e:  # handed to the consumer
                 self._q.put((None, e))
 
@@ -411,10 +421,11 @@ class IdStream:
 
 def write_pass_native(path, dataset, rescore, ids=None):
     """write_pass with the native formatter: same RNG draws, same chunk walk, same bytes.
-    `ids` (an IdStream) supplies ids drawn ahead; by default they are drawn here."""
+    `ids` (an IdStream built with reverse=True) supplies ids drawn ahead; by default they are
+    drawn here."""
     size = len(dataset)
-    ids_u8 = draw_ids(size) if ids is None else ids.next(size)
+    ids_rev = draw_ids(size, reverse=True) if ids is None else ids.next(size)
     with open(path, "ab") as f:
         fd = f.fileno()
         for index_range, count in flush_plan(size):
-            dataset.chunk_to_fd(fd, index_range, count, ids_u8, index_range, rescore)
+            dataset.chunk_to_fd(fd, index_range, count, None, index_range, rescore, ids_rev=ids_rev)

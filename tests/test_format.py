@@ -209,6 +209,9 @@ def test_ids_drawn_in_pieces_and_ahead():
     got = [stream.next(n) for n in sizes]
     stream.close()
     assert after == np.random.random() and all((a == b).all() for a, b in zip(want, got))
+    np.random.seed(11)
+    rev = [rows.draw_ids(n, piece=1000, reverse=True) for n in sizes]
+    assert after == np.random.random() and all((a[::-1] == b).all() for a, b in zip(want, rev))
     stream = rows.IdStream([3, 4])
     with pytest.raises(RuntimeError):
         stream.next(5)
