@@ -39,6 +39,8 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="switchgrass", choices=["switchgrass", "tair10", "ecoli"])
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the switchgrass-like genome (debug)")
+    ap.add_argument("--two-pass", action="store_true",
+                    help="count / tile-scan / emit launch sequence (CRP_OPT_TWO_PASS=1) instead of the default single launch")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the final RCCL gatherv altogether")
     ap.add_argument("--gather-every-step", action="store_true",
                     help="N > 1: run the gatherv inside every timed step instead of once at the end")
@@ -108,6 +110,8 @@ def main():
     from cropsr_amd import parallel
 
     eng = Engine(local_rank)  # raises without libcropsr_hip.so / GPU: no fallback
+    if args.two_pass:
+        eng.configure(two_pass=True)
 
     # ---- workload: `world` genomes, contigs dealt to ranks by LPT (weak scaling)
     genomes = [make_workload(args.workload, g, args.scale) for g in range(world)]
@@ -229,12 +233,15 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": genomes[0].name, "genomes": world, "contigs_per_genome": len(genomes[0].specs),
                        "bases_total": int(bases_all), "kept_hits_total": int(hits_all),
-                       "guide_len": 20, "parallelism": ("contigs by LPT over %d ranks" % world) +
+                       "guide_len": 20, "launches_per_step": 3 if args.two_pass else 1, "parallelism": ("contigs by LPT over %d ranks" % world) +
                        ("" if gather is None else (" + RCCL gatherv to rank 0 " +
                                                    ("every step" if args.gather_every_step else "once, after the steps"))),
                        "device": info["name"].strip()},
             "bases_per_s": bases_all * args.steps / dt,
-            "roofline": {"bound": "hbm", "kernel": "emit_kernel (scan+compact+score)", "achieved": achieved,
+            "roofline": {"bound": "hbm",
+                         "kernel": "emit_kernel (scan+compact+score)" if args.two_pass else
+                                   "emit_kernel, single launch (masks + chained tile offsets + compact + score)",
+                         "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "algorithmic_bytes_per_launch": int(algo_bytes),
                          "kernel_ms": emit_ms, "all_kernels_ms": path_ms,

@@ -43,7 +43,8 @@ struct crp_ctx {
     uint8_t *d_rows = nullptr;
     double *d_rpre = nullptr, *d_rscore = nullptr;
     uint64_t d_rows_cap = 0;
-    bool two_pass = true;  // CRP_OPT_TWO_PASS
+    bool two_pass = false;  // CRP_OPT_TWO_PASS
+    uint64_t chain_timeouts = 0;  // single-pass scans that fell back to the three-launch sequence
     int emit_blocks = 0;   // CRP_OPT_PERSISTENT_EMIT: workgroups of the persistent emit kernel (0 = one per tile)
     // measurement
     int profiling = 0;  // 0 off, 1 emit kernel only, 2 all kernels
@@ -65,7 +66,8 @@ struct crp_arena {
     bool sealed = false;
     // per-tile scratch
     uint2 *d_tile_cnt = nullptr, *d_tile_off = nullptr;
-    uint64_t *d_chain = nullptr;  // single-pass mode: ticket, fail flag, tile descriptors
+    uint64_t *d_chain[2] = {nullptr, nullptr};  // single-pass mode: header + tile descriptors, used alternately
+    int chain_cur = 0;                          // the buffer the next single-pass launch uses (all zero)
     uint64_t *d_totals = nullptr;
     uint64_t *h_totals = nullptr;  // pinned
     uint32_t n_tiles = 0;
@@ -267,7 +269,8 @@ int crp_arena_destroy(crp_arena *a)
     for (int p = 0; p < 4; ++p) (void)hipFree(a->d_plane[p]);
     (void)hipFree(a->d_tile_cnt);
     (void)hipFree(a->d_tile_off);
-    (void)hipFree(a->d_chain);
+    (void)hipFree(a->d_chain[0]);
+    (void)hipFree(a->d_chain[1]);
     (void)hipFree(a->d_totals);
     if (a->h_totals) (void)hipHostFree(a->h_totals);
     for (int s = 0; s < 2; ++s) {
@@ -362,7 +365,10 @@ int crp_arena_seal(crp_arena *a)
     a->n_tiles = (uint32_t)(eff / crp::TILE_WORDS);
     CRP_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&a->d_tile_cnt), a->n_tiles * sizeof(uint2)));
     CRP_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&a->d_tile_off), a->n_tiles * sizeof(uint2)));
-    CRP_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&a->d_chain), crp::chain_bytes(a->n_tiles)));
+    for (int b = 0; b < 2; ++b) {
+        CRP_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&a->d_chain[b]), crp::chain_bytes(a->n_tiles)));
+        CRP_HIP(ctx, hipMemsetAsync(a->d_chain[b], 0, crp::chain_bytes(a->n_tiles), ctx->stream));
+    }
     CRP_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&a->d_totals), 2 * sizeof(uint64_t)));
     CRP_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&a->h_totals), 4 * sizeof(uint64_t), hipHostMallocDefault));
     CRP_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -508,29 +514,36 @@ static int scan_two_pass(crp_arena *a, const crp::Planes &pl, uint64_t eff_words
 // property of the sealed arena) or, the first time, from a density guess; a scan
 // that finds more hits than fit writes nothing out of bounds and is repeated once
 // with the exact sizes.
+// One launch: offsets from the chained scan inside the emit kernel.  Returns CRP_ERR_STATE with
+// *chain_failed = true when a look-back timed out (the caller then runs the three-launch sequence).
 static int scan_single_pass(crp_arena *a, const crp::Planes &pl, uint64_t eff_words, int guide_len, int want_pre,
-                            uint64_t n[2])
+                            uint64_t n[2], bool *chain_failed)
 {
     crp_ctx *ctx = a->ctx;
+    *chain_failed = false;
     uint64_t want[2] = {std::max<uint64_t>(a->tab_cap[0], a->n_chars / 8 + 1024),
                         std::max<uint64_t>(a->tab_cap[1], a->n_chars / 8 + 1024)};
     for (int attempt = 0; attempt < 2; ++attempt) {
         int rc = reserve_tables(a, want, want_pre);
         if (rc != CRP_OK) return rc;
         const crp::HitTables out = table_args(a, want_pre);
+        uint64_t *cur = a->d_chain[a->chain_cur], *next = a->d_chain[a->chain_cur ^ 1];
         prof_begin(ctx, 2, 0, ctx->stream);
-        CRP_HIP(ctx, crp::launch_emit_chained(ctx->stream, pl, eff_words, guide_len, a->d_chain, a->d_totals, out));
+        CRP_HIP(ctx, crp::launch_emit_chained(ctx->stream, pl, eff_words, guide_len, cur, next, out));
         prof_end(ctx, 2, 0, ctx->stream);
-        CRP_HIP(ctx, hipMemcpyAsync(a->h_totals, a->d_totals, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-        CRP_HIP(ctx, hipMemcpyAsync(a->h_totals + 2, a->d_chain, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+        // header: ticket | fail << 32, total '+', total '-'
+        CRP_HIP(ctx, hipMemcpyAsync(a->h_totals, cur, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
         CRP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (a->h_totals[2] >> 32) {  // fail flag: a look-back spin ran out
-            ctx->last_error = "emit kernel: chained-scan look-back timed out";
-            return CRP_ERR_HIP;
+        a->chain_cur ^= 1;  // the kernel left the other buffer zeroed
+        if (a->h_totals[0] >> 32) {  // fail flag: a look-back spin ran out; neither buffer can be trusted now
+            for (int b = 0; b < 2; ++b)
+                CRP_HIP(ctx, hipMemsetAsync(a->d_chain[b], 0, crp::chain_bytes(a->n_tiles), ctx->stream));
+            *chain_failed = true;
+            return CRP_ERR_STATE;
         }
         prof_collect(ctx, 2, 0);
-        n[0] = a->h_totals[0];
-        n[1] = a->h_totals[1];
+        n[0] = a->h_totals[1];
+        n[1] = a->h_totals[2];
         if (n[0] <= out.cap_plus && n[1] <= out.cap_minus) return CRP_OK;
         want[0] = n[0];
         want[1] = n[1];
@@ -550,8 +563,18 @@ int crp_scan_score(crp_arena *a, int guide_len, int want_pre, uint64_t *n_plus, 
     const uint64_t eff_words = (uint64_t)a->n_tiles * crp::TILE_WORDS;
     crp::Planes pl{{a->d_plane[0], a->d_plane[1], a->d_plane[2], a->d_plane[3]}};
     uint64_t n[2] = {0, 0};
-    const int rc = ctx->two_pass ? scan_two_pass(a, pl, eff_words, guide_len, want_pre, n)
-                                 : scan_single_pass(a, pl, eff_words, guide_len, want_pre, n);
+    int rc;
+    if (ctx->two_pass) {
+        rc = scan_two_pass(a, pl, eff_words, guide_len, want_pre, n);
+    } else {
+        bool chain_failed = false;
+        rc = scan_single_pass(a, pl, eff_words, guide_len, want_pre, n, &chain_failed);
+        if (chain_failed) {  // never seen; results stay right either way
+            ctx->two_pass = true;
+            ctx->chain_timeouts++;
+            rc = scan_two_pass(a, pl, eff_words, guide_len, want_pre, n);
+        }
+    }
     if (rc != CRP_OK) return rc;
     a->n_hits[0] = n[0];
     a->n_hits[1] = n[1];

@@ -6,6 +6,9 @@
 namespace crp {
 
 constexpr int BLOCK = 256;     // threads per workgroup (4 wavefronts of 64)
+#ifndef CRP_CHAIN_TICKET
+#define CRP_CHAIN_TICKET 1  // single-pass mode: tile ids from an atomic ticket (start order) instead of blockIdx
+#endif
 #ifndef CRP_TILE_WPT
 #define CRP_TILE_WPT 2
 #endif
@@ -48,10 +51,12 @@ hipError_t launch_tile_scan(hipStream_t s, const uint2 *tile_cnt, uint32_t n_til
 hipError_t launch_emit(hipStream_t s, const Planes &pl, uint64_t n_words_padded, int l, const uint2 *tile_off,
                        const HitTables &out, int persistent_blocks, uint32_t tile_first, uint32_t tile_count);
 int emit_stream_blocks_per_cu();
-// single-pass mode: `chain` = chain_bytes(n_tiles) bytes of device scratch, zeroed by the launcher
+// single-pass mode: `chain` and `chain_next` = chain_bytes(n_tiles) bytes of device scratch each; `chain`
+// must be all zero, the kernel leaves `chain_next` all zero; on return chain[0] = ticket | fail << 32,
+// chain[1], chain[2] = the '+' and '-' table totals
 size_t chain_bytes(uint32_t n_tiles);
 hipError_t launch_emit_chained(hipStream_t s, const Planes &pl, uint64_t n_words_padded, int l, uint64_t *chain,
-                               uint64_t *totals, const HitTables &out);
+                               uint64_t *chain_next, const HitTables &out);
 hipError_t launch_score30(hipStream_t s, const uint8_t *rows, uint64_t n, int order, double *pre, double *score);
 hipError_t launch_pack(hipStream_t s, const uint8_t *text, uint64_t len, uint64_t n_words, uint64_t *hi,
                        uint64_t *lo, uint64_t *up, uint64_t *ac);

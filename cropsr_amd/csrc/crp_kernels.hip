@@ -388,37 +388,47 @@ __device__ __forceinline__ uint64_t desc_unpack(uint64_t v)
     return (v & 0x7fffffffull) | (((v >> 31) & 0x7fffffffull) << 32);
 }
 
-// Exclusive prefix of this tile's (plus | minus << 32) counts over all earlier
-// tiles, by decoupled look-back; called by wave 0 only, returns in every lane.
-// Tiles are numbered in dispatch order (atomic ticket), so every tile this one
-// waits for is already running.  Spins are bounded: on timeout *fail is set and
-// the (wrong) prefix 0 is returned so the grid still drains.
-__device__ __forceinline__ uint64_t lookback_exclusive(uint64_t *desc, uint32_t tile, uint64_t total,
-                                                       uint32_t *fail)
+// Decoupled look-back over the tile descriptors (single-pass mode).  A tile publishes its
+// (plus | minus << 32) counts as an AGGREGATE as soon as its block scan is done, and later
+// -- once it knows the sum over all earlier tiles -- as an inclusive PREFIX.  Tiles are
+// numbered in start order (an atomic ticket, CRP_CHAIN_TICKET) so that every tile this one
+// waits for is already running or finished.  Spins are bounded all the same: on timeout
+// *fail is set, every later look-back gives up at once, and the host repeats the scan with
+// the count / scan / emit sequence instead of using the result.
+constexpr int CHAIN_HEADER_WORDS = 4;
+constexpr int LB_DEPTH = 2;  // descriptors per lane and round trip: 128 tiles (measured: 1 and 2 equal, 4 and 8 slower)
+
+__device__ __forceinline__ void lookback_publish(uint64_t *desc, uint32_t tile, uint64_t total)
+{
+    const uint64_t tag = tile == 0 ? DESC_PREFIX : DESC_AGG;
+    __hip_atomic_store(&desc[tile], tag | desc_pack(total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// lane k, slot j looks at tile base - k - 64*j; all loads in flight together
+__device__ __forceinline__ void lookback_load(const uint64_t *desc, int64_t base, uint64_t (&v)[LB_DEPTH])
 {
     const int lane = threadIdx.x & 63;
-    if (tile == 0) {
-        if (lane == 0) __hip_atomic_store(&desc[0], DESC_PREFIX | desc_pack(total), __ATOMIC_RELAXED,
-                                          __HIP_MEMORY_SCOPE_AGENT);
-        return 0;
+#pragma unroll
+    for (int j = 0; j < LB_DEPTH; ++j) {
+        const int64_t idx = base - lane - 64 * j;
+        v[j] = DESC_PREFIX;  // before tile 0: an empty prefix
+        if (idx >= 0) v[j] = __hip_atomic_load(&desc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (lane == 0) __hip_atomic_store(&desc[tile], DESC_AGG | desc_pack(total), __ATOMIC_RELAXED,
-                                      __HIP_MEMORY_SCOPE_AGENT);
-    // Each round inspects the LB_DEPTH*64 tiles before `base` (lane k, slot j looks at
-    // tile base - k - 64*j) with all loads in flight together: about as many tiles as
-    // are resident without a published prefix, so one round usually suffices.
-    constexpr int LB_DEPTH = 8;
+}
+
+// Called by ONE wave; `v` holds the descriptors lookback_load fetched earlier for
+// base = tile - 1 (the loads were issued before the wave scored its first hits, so they
+// cost no wait here).  Returns the exclusive prefix in every lane and publishes the
+// inclusive one.
+__device__ __forceinline__ uint64_t lookback_resolve(uint64_t *desc, uint32_t tile, uint64_t total,
+                                                     uint64_t (&v)[LB_DEPTH], uint32_t *fail)
+{
+    const int lane = threadIdx.x & 63;
+    if (tile == 0) return 0;
     uint64_t excl = 0;
     int64_t base = (int64_t)tile - 1;
     uint32_t spins = 0;
     while (true) {
-        uint64_t v[LB_DEPTH];
-#pragma unroll
-        for (int j = 0; j < LB_DEPTH; ++j) {
-            const int64_t idx = base - lane - 64 * j;
-            v[j] = DESC_PREFIX;  // before tile 0: an empty prefix
-            if (idx >= 0) v[j] = __hip_atomic_load(&desc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
         uint64_t contrib = 0;
         bool found = false, stall = false;
 #pragma unroll
@@ -439,42 +449,76 @@ __device__ __forceinline__ uint64_t lookback_exclusive(uint64_t *desc, uint32_t 
             }
         }
         if (stall) {  // some nearer tile has not published yet: look again
-            if (++spins > (1u << 20)) {
+            ++spins;
+            bool give_up = spins > (1u << 20);
+            if ((spins & 63u) == 0)  // someone else already timed out: drain
+                give_up |= __hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+            if (give_up) {
                 if (lane == 0) atomicExch(fail, 1u);
                 return 0;
             }
             __builtin_amdgcn_s_sleep(4);
-            continue;
-        }
+        } else {
 #pragma unroll
-        for (int d = 32; d > 0; d >>= 1) contrib += __shfl_xor(contrib, d, 64);
-        excl += contrib;
-        if (found) break;
-        base -= 64 * LB_DEPTH;
+            for (int d = 32; d > 0; d >>= 1) contrib += __shfl_xor(contrib, d, 64);
+            excl += contrib;
+            if (found) break;
+            base -= 64 * LB_DEPTH;
+        }
+        lookback_load(desc, base, v);
     }
     if (lane == 0) __hip_atomic_store(&desc[tile], DESC_PREFIX | desc_pack(excl + total), __ATOMIC_RELAXED,
                                       __HIP_MEMORY_SCOPE_AGENT);
     return excl;
 }
 
-template <int WPT, int TW, int CAP, bool PAM>
+// what the single-pass mode needs inside emit_rounds
+struct ChainArgs {
+    uint64_t *desc;     // one descriptor per tile
+    uint32_t *fail;
+    uint64_t *totals;   // written by the last tile
+    uint64_t *s_excl;   // LDS hand-over from the resolving wave to the workgroup
+    uint32_t *s_flag;   // LDS: s_excl is valid
+    uint32_t tile, n_tiles;
+    uint64_t total;     // this tile's (plus | minus << 32)
+};
+
+__device__ __forceinline__ void chain_resolve(const ChainArgs &ch, uint64_t (&lb)[LB_DEPTH])
+{
+    const uint64_t e = lookback_resolve(ch.desc, ch.tile, ch.total, lb, ch.fail);
+    if ((threadIdx.x & 63) == 0) {
+        *ch.s_excl = e;
+        if (ch.tile == ch.n_tiles - 1) {
+            const uint64_t all = e + ch.total;
+            ch.totals[0] = all & 0xffffffffull;
+            ch.totals[1] = all >> 32;
+        }
+    }
+}
+
+template <int WPT, int TW, int CAP, bool PAM, bool CHAINED>
 __device__ __forceinline__ void emit_rounds(uint64_t (*sh)[TW + 2], uint16_t *list, const uint64_t *exp_tab,
                                             const uint64_t (&mp)[WPT], const uint64_t (&mm)[WPT], uint64_t ex,
                                             uint32_t n_plus, uint32_t n_minus, int l, uint32_t tile_pos,
-                                            uint64_t off_plus, uint64_t off_minus, const HitTables &out);
+                                            uint64_t off_plus, uint64_t off_minus, const HitTables &out,
+                                            const ChainArgs &ch);
 
-// CHAINED = true : single pass.  Tile ids come from an atomic ticket, table
-//                  offsets from the decoupled look-back above; `chain` holds
-//                  [0] ticket (u32) [1] fail flag (u32), then one descriptor per
-//                  tile from byte 16; all zeroed before every launch.  Stores
-//                  are bounds-checked against the table capacities, totals are
-//                  published by the last tile.
-// CHAINED = false: third pass of the count / scan / emit sequence (offsets from
-//                  tile_off); kept as the cross-check for the single-pass mode.
+// CHAINED = true : single pass.  Table offsets come from the decoupled look-back above;
+//                  `chain` holds a 32-byte header -- tile ticket (u32), fail flag (u32), the two
+//                  table totals (u64 each, written by the last tile), padding -- then one
+//                  descriptor per tile; it must be all zero at launch.  Launches alternate
+//                  between two such buffers and every tile zeroes its slot of the other one
+//                  (`chain_next`), so no memset runs between scans.  The tile
+//                  publishes its counts right after the block scan, builds its hit list
+//                  and scores the first hit of every lane BEFORE it needs its offsets, so
+//                  the look-back's round trip hides under that work.  Stores are
+//                  bounds-checked against the table capacities, totals are published by
+//                  the last tile.
+// CHAINED = false: third pass of the count / scan / emit sequence (offsets from tile_off).
 template <int WPT, bool CHAINED, int LFIX>
-__global__ __launch_bounds__(EMIT_BLOCK) void emit_kernel(Planes pl, uint64_t n_words_padded, int l_arg,
+__global__ __launch_bounds__(EMIT_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8))) void emit_kernel(Planes pl, uint64_t n_words_padded, int l_arg,
                                                       const uint2 *__restrict__ tile_off, uint64_t *chain,
-                                                      uint64_t *__restrict__ totals, HitTables out,
+                                                      uint64_t *__restrict__ chain_next, HitTables out,
                                                       uint32_t tile_first)
 {
     const int l = LFIX > 0 ? LFIX : l_arg;
@@ -484,15 +528,24 @@ __global__ __launch_bounds__(EMIT_BLOCK) void emit_kernel(Planes pl, uint64_t n_
     __shared__ uint64_t exp_tab[256];
     __shared__ uint64_t wave_tot[EMIT_BLOCK / 64];
     __shared__ uint64_t s_excl;
-    __shared__ uint32_t s_tile;
+    __shared__ uint32_t s_flag, s_tile;
     __shared__ uint16_t list[CAP];
 
     const int tid = threadIdx.x;
     uint32_t tile = blockIdx.x + tile_first;
     if (CHAINED) {
-        if (tid == 0) s_tile = atomicAdd(reinterpret_cast<uint32_t *>(chain), 1u);
+#if CRP_CHAIN_TICKET
+        // tile ids in START order: whatever order the hardware dispatches workgroups in, every
+        // tile a workgroup waits for has started before it
+        if (tid == 0) {
+            s_flag = 0;
+            s_tile = atomicAdd(reinterpret_cast<uint32_t *>(chain), 1u);
+        }
         __syncthreads();
         tile = s_tile;
+#else
+        if (tid == 0) s_flag = 0;
+#endif
     }
     const uint64_t t0 = (uint64_t)tile * TW;
     stage_tile<TW>(pl, t0, n_words_padded, sh);
@@ -508,42 +561,48 @@ __global__ __launch_bounds__(EMIT_BLOCK) void emit_kernel(Planes pl, uint64_t n_
     const uint64_t ex = block_exclusive_scan<(EMIT_BLOCK * WPT >= 1024)>(c, wave_tot, total);
     const uint32_t n_plus = (uint32_t)total, n_minus = (uint32_t)(total >> 32);
     const uint32_t n_all = n_plus + n_minus;
-    uint64_t off_plus, off_minus;
+    uint64_t off_plus = 0, off_minus = 0;
+    ChainArgs ch{};
     if (CHAINED) {
-        if (tid < 64) {
-            uint32_t *fail = reinterpret_cast<uint32_t *>(chain) + 1;
-            const uint64_t e = lookback_exclusive(chain + 2, tile, total, fail);
-            if (tid == 0) {
-                s_excl = e;
-                if (tile == gridDim.x - 1) {
-                    const uint64_t all = e + total;
-                    totals[0] = all & 0xffffffffull;
-                    totals[1] = all >> 32;
-                }
-            }
+        ch = ChainArgs{chain + CHAIN_HEADER_WORDS, reinterpret_cast<uint32_t *>(chain) + 1, chain + 1, &s_excl, &s_flag,
+                       tile, gridDim.x + tile_first, total};
+        if (tid == 0) {
+            lookback_publish(ch.desc, tile, total);
+            // leave the OTHER descriptor buffer zeroed for the next launch (no memset between scans)
+            chain_next[CHAIN_HEADER_WORDS + tile] = 0;
+            if (tile == 0) chain_next[0] = chain_next[1] = chain_next[2] = chain_next[3] = 0;
         }
-        __syncthreads();
-        off_plus = s_excl & 0xffffffffull;
-        off_minus = s_excl >> 32;
+        if (n_all == 0) {
+            // nothing to store: the aggregate (0) is all later tiles need; only the last tile
+            // must still learn its prefix, to publish the totals
+            if (tile == ch.n_tiles - 1 && tid < 64) {
+                uint64_t lb[LB_DEPTH];
+                lookback_load(ch.desc, (int64_t)tile - 1, lb);
+                chain_resolve(ch, lb);
+            }
+            return;
+        }
     } else {
         const uint2 off = tile_off[tile];
         off_plus = off.x;
         off_minus = off.y;
+        if (n_all == 0) return;
     }
-    if (n_all == 0) return;
-    emit_rounds<WPT, TW, CAP, LFIX == 20>(sh, list, exp_tab, mp, mm, ex, n_plus, n_minus, l, (uint32_t)(t0 * 64), off_plus,
-                              off_minus, out);
+    emit_rounds<WPT, TW, CAP, LFIX == 20, CHAINED>(sh, list, exp_tab, mp, mm, ex, n_plus, n_minus, l, (uint32_t)(t0 * 64),
+                                                   off_plus, off_minus, out, ch);
 }
 
 // Compact the kept hits of one staged tile and score them, CAP list entries per round.
-template <int WPT, int TW, int CAP, bool PAM>
+template <int WPT, int TW, int CAP, bool PAM, bool CHAINED>
 __device__ __forceinline__ void emit_rounds(uint64_t (*sh)[TW + 2], uint16_t *list, const uint64_t *exp_tab,
                                             const uint64_t (&mp)[WPT], const uint64_t (&mm)[WPT], uint64_t ex,
                                             uint32_t n_plus, uint32_t n_minus, int l, uint32_t tile_pos,
-                                            uint64_t off_plus, uint64_t off_minus, const HitTables &out)
+                                            uint64_t off_plus, uint64_t off_minus, const HitTables &out,
+                                            const ChainArgs &ch)
 {
     const int tid = threadIdx.x;
     const uint32_t n_all = n_plus + n_minus;
+    bool resolved = !CHAINED;  // single pass: this lane has not picked up off_plus / off_minus yet
     for (uint32_t lo_rank = 0; lo_rank < n_all; lo_rank += CAP) {
         if (lo_rank) __syncthreads();  // previous round's readers are done
         // ---- compact: rank -> tile-local position, '+' hits first, then '-'
@@ -580,18 +639,20 @@ __device__ __forceinline__ void emit_rounds(uint64_t (*sh)[TW + 2], uint16_t *li
         __syncthreads();
         // ---- one hit per lane: extract the 30-window, score, store
         const uint32_t n_round = min((uint32_t)CAP, n_all - lo_rank);
-        for (uint32_t k = tid; k < n_round; k += EMIT_BLOCK) {
-            const uint32_t r = lo_rank + k;
-            const uint32_t e = list[k];
-            const bool minus = r >= n_plus;
+        struct Hit {
+            uint32_t e, r;
+            double pre, score;
+        };
+        auto compute = [&](uint32_t k) -> Hit {  // list entry k of this round
+            Hit hit{list[k], lo_rank + k, -1.0, -1.0};
+            const bool minus = hit.r >= n_plus;
             // '+': long_sequence = T(s[i-l-5 : i+5])       (CROPSR.py:421)
             // '-': long_sequence = T(R(s[j-2 : j+l+8]))     (CROPSR.py:432)
             // Python clamps the slice at len(s); the row is scored iff the result
             // has exactly 30 characters (CROPSR.py:458,466): for l = 20 a complete
             // window, for l > 20 a window cut to 30 by the end of the string, for
             // l < 20 never.
-            const uint32_t q = 64u + e - (minus ? 2u : (uint32_t)(l + 5));
-            double pre = -1.0, score = -1.0;
+            const uint32_t q = 64u + hit.e - (minus ? 2u : (uint32_t)(l + 5));
             if (l >= 20) {
                 uint32_t h = window31(sh[0], q), w = window31(sh[1], q);
                 uint32_t u = window31(sh[2], q), a = window31(sh[3], q);
@@ -613,27 +674,68 @@ __device__ __forceinline__ void emit_rounds(uint64_t (*sh)[TW + 2], uint16_t *li
                     const uint32_t mG = h & w & valid, mC = h & ~w & valid;
                     const uint32_t mT = ~h & w & valid, mA = ~h & ~w & valid;
 #if defined(CRP_EXPERIMENT_NO_SCORE)
-                    score = __hiloint2double((int)(mA ^ mT), (int)(mC ^ mG));
+                    hit.score = __hiloint2double((int)(mA ^ mT), (int)(mC ^ mG));
 #else
-                    crp_score_masks<PAM>(mA, mT, mC, mG, exp_tab, pre, score);
+                    crp_score_masks<PAM>(mA, mT, mC, mG, exp_tab, hit.pre, hit.score);
 #endif
                 }
             }
-            const uint32_t pos = tile_pos + e;
-            if (minus) {
-                const uint64_t o = off_minus + (r - n_plus);
+            return hit;
+        };
+        auto store = [&](const Hit &hit) {
+            const uint32_t pos = tile_pos + hit.e;
+            if (hit.r >= n_plus) {
+                const uint64_t o = off_minus + (hit.r - n_plus);
                 if (o < out.cap_minus) {
                     out.pos_minus[o] = pos;
-                    out.score_minus[o] = score;
-                    if (out.pre_minus) out.pre_minus[o] = pre;
+                    out.score_minus[o] = hit.score;
+                    if (out.pre_minus) out.pre_minus[o] = hit.pre;
                 }
             } else {
-                const uint64_t o = off_plus + r;
+                const uint64_t o = off_plus + hit.r;
                 if (o < out.cap_plus) {
                     out.pos_plus[o] = pos;
-                    out.score_plus[o] = score;
-                    if (out.pre_plus) out.pre_plus[o] = pre;
+                    out.score_plus[o] = hit.score;
+                    if (out.pre_plus) out.pre_plus[o] = hit.pre;
                 }
+            }
+        };
+        if (!CHAINED) {
+            for (uint32_t k = tid; k < n_round; k += EMIT_BLOCK) store(compute(k));
+        } else {
+            // Single pass: the table offsets are not known yet.  Every wave scores its first
+            // hits; wave 0 then walks the descriptors (its round trip is exposed to that wave
+            // only) and raises the LDS flag; the other waves go on scoring and store one
+            // iteration behind, so they look at the flag one full iteration (~4 us) later and
+            // normally find it set.  No workgroup barrier is involved.
+            auto settle = [&]() {
+                if (resolved) return;
+                while (__hip_atomic_load(ch.s_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0)
+                    __builtin_amdgcn_s_sleep(1);
+                const uint64_t e = *ch.s_excl;
+                off_plus = e & 0xffffffffull;
+                off_minus = e >> 32;
+                resolved = true;
+            };
+            uint32_t k = tid;
+            const bool any = k < n_round;
+            Hit cur{};
+            if (any) cur = compute(k);
+            if (lo_rank == 0 && tid < 64) {  // wave-uniform: once per tile
+                uint64_t lb[LB_DEPTH];
+                lookback_load(ch.desc, (int64_t)ch.tile - 1, lb);
+                chain_resolve(ch, lb);
+                __hip_atomic_store(ch.s_flag, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            if (any) {
+                for (k += EMIT_BLOCK; k < n_round; k += EMIT_BLOCK) {
+                    const Hit nxt = compute(k);
+                    settle();
+                    store(cur);
+                    cur = nxt;
+                }
+                settle();
+                store(cur);
             }
         }
     }
@@ -709,8 +811,8 @@ __global__ __launch_bounds__(EMIT_BLOCK) void emit_stream_kernel(Planes pl, uint
         uint64_t total;
         const uint64_t ex = block_exclusive_scan<(EMIT_BLOCK * WPT >= 1024)>(c, wave_tot, total);
         const uint2 off = tile_off[tile];
-        emit_rounds<WPT, TW, CAP, LFIX == 20>(sh, list, exp_tab, mp, mm, ex, (uint32_t)total, (uint32_t)(total >> 32), l,
-                                  (uint32_t)((uint64_t)tile * TW * 64), off.x, off.y, out);
+        emit_rounds<WPT, TW, CAP, LFIX == 20, false>(sh, list, exp_tab, mp, mm, ex, (uint32_t)total, (uint32_t)(total >> 32), l,
+                                  (uint32_t)((uint64_t)tile * TW * 64), off.x, off.y, out, ChainArgs{});
         __syncthreads();  // everyone is done with sh / list / wave_tot before the next tile lands
     }
 }
@@ -898,17 +1000,19 @@ int emit_stream_blocks_per_cu()
     return n;
 }
 
-size_t chain_bytes(uint32_t n_tiles) { return 16 + (size_t)n_tiles * sizeof(uint64_t); }
+size_t chain_bytes(uint32_t n_tiles) { return (CHAIN_HEADER_WORDS + (size_t)n_tiles) * sizeof(uint64_t); }
 
 hipError_t launch_emit_chained(hipStream_t s, const Planes &pl, uint64_t n_words_padded, int l, uint64_t *chain,
-                               uint64_t *totals, const HitTables &out)
+                               uint64_t *chain_next, const HitTables &out)
 {
     constexpr int TW = EMIT_BLOCK * TILE_WPT;
     const uint32_t n_tiles = (uint32_t)(n_words_padded / TW);
-    hipError_t e = hipMemsetAsync(chain, 0, chain_bytes(n_tiles), s);  // ticket, fail flag, descriptors
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((emit_kernel<TILE_WPT, true, 0>), dim3(n_tiles), dim3(EMIT_BLOCK), 0, s, pl, n_words_padded, l,
-                       (const uint2 *)nullptr, chain, totals, out, 0u);
+    if (l == 20)
+        hipLaunchKernelGGL((emit_kernel<TILE_WPT, true, 20>), dim3(n_tiles), dim3(EMIT_BLOCK), 0, s, pl, n_words_padded,
+                           l, (const uint2 *)nullptr, chain, chain_next, out, 0u);
+    else
+        hipLaunchKernelGGL((emit_kernel<TILE_WPT, true, 0>), dim3(n_tiles), dim3(EMIT_BLOCK), 0, s, pl, n_words_padded,
+                           l, (const uint2 *)nullptr, chain, chain_next, out, 0u);
     return hipGetLastError();
 }
 

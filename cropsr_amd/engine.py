@@ -238,7 +238,8 @@ class Engine:
         return score
 
     def configure(self, two_pass=None, persistent_emit=None, slices=None):
-        """two_pass=False: one chained-scan kernel instead of count / scan / emit;
+        """two_pass=False (the default): one launch per scan, table offsets from the chained
+        scan inside the emit kernel; True: the count / tile-scan / emit launch sequence;
         persistent_emit=0: one workgroup per tile instead of the pipelined persistent
         emit kernel (1 = default sizing, n > 1 = that many workgroups).  Same results
         either way; the options exist for cross-checks and A/B timing."""

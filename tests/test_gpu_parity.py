@@ -21,11 +21,20 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(scope="module")
-def engine():
+def _engine():
     from cropsr_amd import Engine
     eng = Engine(0)  # raises if libcropsr_hip.so or the GPU is missing: no fallback
     yield eng
     eng.close()
+
+
+@pytest.fixture(params=["single_pass", "two_pass"])
+def engine(_engine, request):
+    """Every parity test runs in both scan modes: the default single launch (offsets from the
+    chained scan inside the emit kernel) and the count / tile-scan / emit sequence."""
+    _engine.configure(two_pass=request.param == "two_pass")
+    yield _engine
+    _engine.configure(two_pass=False)
 
 
 def bits(a):
@@ -249,7 +258,7 @@ def test_single_pass_equals_two_pass(engine):
         for name in ("pos_plus", "pre_plus", "score_plus", "pos_minus", "pre_minus", "score_minus"):
             assert (bits(getattr(results[-1], name)) == bits(getattr(again, name))).all()
         arena.close()
-    engine.configure(two_pass=True)  # the default
+    engine.configure(two_pass=False)  # the default
     for name in ("pos_plus", "pre_plus", "score_plus", "pos_minus", "pre_minus", "score_minus"):
         assert (bits(getattr(results[0], name)) == bits(getattr(results[1], name))).all(), name
         assert (bits(getattr(results[0], name)) == bits(getattr(results[2], name))).all(), name
