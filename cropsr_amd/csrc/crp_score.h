@@ -51,7 +51,9 @@ __device__ __forceinline__ double crp_exp(double x, const uint64_t *tab)
     const double shift = 0x1.8p52;
     const double c2 = 0x1.ffffffffffdbdp-2, c3 = 0x1.555555555543cp-3;
     const double c4 = 0x1.55555cf172b91p-5, c5 = 0x1.1111167a4d017p-7;
-    if (__builtin_fabs(x) < 0x1p-54) return 1.0 + x;
+    // (glibc returns 1.0 + x early for |x| < 2^-54 to keep the inexact/underflow flags clean; the
+    // value is the same on the main path -- tail + r == x, fma(1, x, 1) rounds like 1 + x -- so the
+    // test is not needed here)
     const double z = inv_ln2_n * x;
     double kd = z + shift;
     const uint64_t ki = (uint64_t)__double_as_longlong(kd);
@@ -68,6 +70,21 @@ __device__ __forceinline__ double crp_exp(double x, const uint64_t *tab)
     tmp = __builtin_fma(r2 * r2, p_hi, tmp);
     const double scale = __longlong_as_double((long long)sbits);
     return __builtin_fma(scale, tmp, scale);
+}
+
+// 1 / d for 1 <= d < 2^64, correctly rounded: the f64 division sequence of the compiler
+// (v_rcp_f64, two Newton steps, quotient, remainder, final fma) without v_div_scale_f64 /
+// v_div_fmas_f64 / v_div_fixup_f64, which are the identity when numerator and denominator are
+// this far from the exponent range's ends.
+__device__ __forceinline__ double crp_recip(double d)
+{
+    double r = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    const double rem = __builtin_fma(-d, r, 1.0);
+    return __builtin_fma(rem, r, r);
 }
 
 // pre = -(s1 + s2 + intersect + low_gc)  (CROPSR.py:312), score = 1/(1+exp(pre)) (:313)
@@ -93,6 +110,6 @@ __device__ __forceinline__ void crp_score_masks(uint32_t mA, uint32_t mT, uint32
 #if defined(CRP_EXPERIMENT_NO_EXP)
     score = pre;
 #else
-    score = 1.0 / (1.0 + crp_exp(pre, exp_tab));
+    score = crp_recip(1.0 + crp_exp(pre, exp_tab));
 #endif
 }
