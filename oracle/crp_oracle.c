@@ -146,6 +146,39 @@ void orc_exp_many(const double *x, int64_t n, double *out)
     for (int64_t i = 0; i < n; ++i) out[i] = orc_exp(x[i]);
 }
 
+/* The table path alone, for |x| < 512, WITHOUT glibc's early return for |x| < 2^-54: the HIP
+ * scorer (cropsr_amd/csrc/crp_score.h crp_exp) runs exactly this, on the argument that the
+ * early return only protects the exception flags and never changes the value.
+ * tests/test_oracle.py checks that claim against libm on tiny, denormal and zero arguments. */
+void orc_exp_table_path_many(const double *x, int64_t n, double *out)
+{
+    const double inv_ln2_n = 0x1.71547652b82fep0 * 128;
+    const double neg_ln2_hi_n = -0x1.62e42fefa0000p-8;
+    const double neg_ln2_lo_n = -0x1.cf79abc9e3b3ap-47;
+    const double shift = 0x1.8p52;
+    const double c2 = 0x1.ffffffffffdbdp-2, c3 = 0x1.555555555543cp-3;
+    const double c4 = 0x1.55555cf172b91p-5, c5 = 0x1.1111167a4d017p-7;
+    for (int64_t i = 0; i < n; ++i) {
+        const double v = x[i];
+        double z = inv_ln2_n * v;
+        double kd = z + shift;
+        uint64_t ki = as_u64(kd);
+        kd -= shift;
+        double r = fma(kd, neg_ln2_lo_n, fma(kd, neg_ln2_hi_n, v));
+        uint64_t idx = 2 * (ki % 128);
+        uint64_t top = ki << (52 - 7);
+        double tail = as_f64(EXP_TAB[idx]);
+        uint64_t sbits = EXP_TAB[idx + 1] + top;
+        double r2 = r * r;
+        double p_lo = fma(r, c3, c2);
+        double p_hi = fma(r, c5, c4);
+        double tmp = fma(r2, p_lo, tail + r);
+        tmp = fma(r2 * r2, p_hi, tmp);
+        double scale = as_f64(sbits);
+        out[i] = fma(scale, tmp, scale);
+    }
+}
+
 /* ------------------------------------------------------------------- score */
 /* rs1_score on ONE row of 30 bytes (CROPSR.py:285-313).  One-hot compare with
  * 'A','T','C','G' (65,84,67,71) only: any other byte selects no column. */

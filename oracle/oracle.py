@@ -33,6 +33,7 @@ def lib():
         L.orc_exp.restype = ctypes.c_double
         L.orc_exp.argtypes = [ctypes.c_double]
         L.orc_exp_many.argtypes = [_f64p, ctypes.c_int64, _f64p]
+        L.orc_exp_table_path_many.argtypes = [_f64p, ctypes.c_int64, _f64p]
         L.orc_score30.argtypes = [_u8p, ctypes.c_int64, _f64p, _f64p]
         L.orc_score30_order.argtypes = [_u8p, ctypes.c_int64, ctypes.c_int, _f64p, _f64p]
         L.orc_rs1_batch.argtypes = [_u8p, ctypes.c_int64, _f64p, _f64p]
@@ -63,6 +64,14 @@ def exp(x):
     x = np.ascontiguousarray(x, dtype=np.float64)
     out = np.empty_like(x)
     lib().orc_exp_many(_p(x, _f64p), x.size, _p(out, _f64p))
+    return out
+
+
+def exp_table_path(x):
+    """exp through the table path only (what the HIP scorer runs), valid for |x| < 512."""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    out = np.empty_like(x)
+    lib().orc_exp_table_path_many(_p(x, _f64p), x.size, _p(out, _f64p))
     return out
 
 

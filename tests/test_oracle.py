@@ -2,6 +2,7 @@
 vectors produced by the real reference (tests/golden/make_golden.py).  CPU only."""
 import ctypes
 import hashlib
+import math
 import os
 
 import numpy as np
@@ -96,3 +97,24 @@ def test_big_chunk_csv_md5_cpu(oracle, manifest, tmp_path, monkeypatch):
     got, _ = run_cli(tmp_path, monkeypatch, str(fa), oracle_scan_provider(oracle), manifest["seed"])
     assert got.count(b"\r\n") - 1 == manifest["cases"]["big9m"]["rows"]
     assert hashlib.md5(got).hexdigest() == manifest["cases"]["big9m"]["md5_libm"]
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+def test_exp_table_path_needs_no_small_argument_case(oracle):
+    """The HIP scorer drops glibc's early `return 1 + x` for |x| < 2^-54 (it exists to keep the
+    floating-point flags clean).  The table path must then give the same VALUE there: checked
+    against libm (math.exp) on zeros, denormals, powers of two down to the smallest denormal, values just
+    either side of 2^-54 -- and against orc_exp on the scorer's working range."""
+    tiny = [0.0, -0.0, 5e-324, -5e-324, 2.2250738585072014e-308, -2.2250738585072014e-308]
+    tiny += [s * 2.0 ** -k for k in range(40, 1075, 7) for s in (1.0, -1.0)]
+    tiny += [s * np.nextafter(2.0 ** -54, d) for d in (0.0, 1.0) for s in (1.0, -1.0)]
+    rng = np.random.default_rng(5)
+    tiny += list(rng.uniform(-1, 1, 2000) * 2.0 ** rng.integers(-1074, -50, 2000).astype(np.float64))
+    tiny = np.array(tiny)
+    libm = np.array([math.exp(v) for v in tiny.tolist()])  # math.exp IS libm's exp (numpy may use its own SIMD exp)
+    assert (bits(oracle.exp_table_path(tiny)) == bits(libm)).all()
+    x = rng.uniform(-40, 40, 200000)
+    assert (bits(oracle.exp_table_path(x)) == bits(oracle.exp(x))).all()
