@@ -234,7 +234,7 @@ def main():
             "config": {"workload": genomes[0].name, "genomes": world, "contigs_per_genome": len(genomes[0].specs),
                        "bases_total": int(bases_all), "kept_hits_total": int(hits_all),
                        "guide_len": 20, "launches_per_step": 3 if args.two_pass else 1, "parallelism": ("contigs by LPT over %d ranks" % world) +
-                       ("" if gather is None else (" + RCCL gatherv to rank 0 " +
+                       ("" if gather is None else (" + %s gatherv to rank 0 " % ("RCCL" if args.backend == "nccl" else "gloo (host-staged)") +
                                                    ("every step" if args.gather_every_step else "once, after the steps"))),
                        "device": info["name"].strip()},
             "bases_per_s": bases_all * args.steps / dt,
