@@ -47,9 +47,14 @@ def sample_fasta_text():
 
 
 PROBES = ["multi", "twoline", "spaces", "edges", "mixed", "rightend", "tiny", "dupname"]
+# probes the real reference was also run on with a non-default guide length: (probe, -l value)
+LENGTH_CASES = [("mixed", 23), ("rightend", 17), ("multi", 25), ("tiny", 21), ("edges", 24)]
 
 
-def read_golden_csv(name):
+def read_golden_csv(name, guide_len=None):
+    if guide_len is not None:
+        with open(os.path.join(GOLDEN, "probe_%s.l%d.libm.csv" % (name, guide_len)), "rb") as f:
+            return f.read()
     if name == "sample":
         with gzip.open(os.path.join(GOLDEN, "sample_libm.csv.gz"), "rb") as f:
             return f.read()

@@ -43,7 +43,7 @@ AVX512_OFF = "AVX512F AVX512CD AVX512_SKX AVX512_CLX AVX512_CNL AVX512_ICL AVX51
 CHILD = r"""
 import sys, time
 fa, gff, out, seed = sys.argv[1:5]
-sys.argv = ['CROPSR.py', '-f', fa, '-g', gff, '-o', out, '--cas9']
+sys.argv = ['CROPSR.py', '-f', fa, '-g', gff, '-o', out, '--cas9'] + sys.argv[5:]
 sys.path.insert(0, %r)
 time.sleep = lambda s: None
 import numpy as np
@@ -74,8 +74,8 @@ def env_for(kind):
     return env
 
 
-def run_reference(fa_text, gff_text, kind, scratch):
-    """Return (csv_bytes, stdout_text, time_txt_text-with-numbers-stripped)."""
+def run_reference(fa_text, gff_text, kind, scratch, extra=()):
+    """Return (csv_bytes, stdout_text); `extra` = more reference command-line arguments."""
     d = tempfile.mkdtemp(dir=scratch)
     fa = os.path.join(d, "in.fa")
     gff = os.path.join(d, "in.gff")
@@ -84,7 +84,7 @@ def run_reference(fa_text, gff_text, kind, scratch):
         f.write(fa_text)
     with open(gff, "w") as f:
         f.write(gff_text)
-    p = subprocess.run([sys.executable, "-c", CHILD, fa, gff, out, str(SEED)],
+    p = subprocess.run([sys.executable, "-c", CHILD, fa, gff, out, str(SEED)] + list(extra),
                        cwd=d, env=env_for(kind), capture_output=True, text=True)
     if p.returncode != 0:
         raise RuntimeError(p.stderr)
@@ -153,14 +153,40 @@ def build_probes():
     return probes
 
 
+# probes re-run with a non-default guide length (-l): l > 20 scores only windows the end of the
+# contig string cuts to 30 characters, l < 20 scores nothing (CROPSR.py:458,466)
+LENGTH_CASES = [("mixed", 23), ("rightend", 17), ("multi", 25), ("tiny", 21), ("edges", 24)]
+
+
+def length_cases(scratch, manifest):
+    probes = build_probes()
+    for name, l in LENGTH_CASES:
+        csv_b, out = run_reference(probes[name], MINI_GFF, "libm", scratch, extra=("-l", str(l)))
+        with open(os.path.join(HERE, "probe_%s.l%d.libm.csv" % (name, l)), "wb") as f:
+            f.write(csv_b)
+        manifest["cases"]["%s.l%d" % (name, l)] = {"rows": csv_b.count(b"\r\n") - 1, "guide_len": l, "probe": name,
+                                                   "md5_libm": hashlib.md5(csv_b).hexdigest(), "stdout": out}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--big", action="store_true",
                     help="also run the >1e6-hit probe (about 100 s, 14 GB RSS); stores checksums only")
+    ap.add_argument("--lengths-only", action="store_true",
+                    help="only (re)generate the non-default guide-length cases and merge them into manifest.json")
     args = ap.parse_args()
     import numpy as np
 
     scratch = tempfile.mkdtemp(prefix="golden_")
+    if args.lengths_only:
+        with open(os.path.join(HERE, "manifest.json")) as f:
+            manifest = json.load(f)
+        length_cases(scratch, manifest)
+        with open(os.path.join(HERE, "manifest.json"), "w") as f:
+            json.dump(manifest, f, indent=1, sort_keys=True)
+        shutil.rmtree(scratch)
+        print("wrote guide-length fixtures to", HERE)
+        return
     manifest = {"seed": SEED, "numpy": np.__version__, "cases": {}}
 
     # ---- sample genome: the reference's own data files are copied as fixtures
@@ -207,6 +233,8 @@ def main():
             f.write(csv_b)
         manifest["cases"][name] = {"rows": csv_b.count(b"\r\n") - 1,
                                    "md5_libm": hashlib.md5(csv_b).hexdigest(), "stdout": out}
+
+    length_cases(scratch, manifest)
 
     # ---- seam-2 vectors: rs1_score on raw (n,30) uint8, incl. non-ATCG bytes
     rng = np.random.default_rng(11)

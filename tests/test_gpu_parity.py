@@ -15,7 +15,7 @@ import pytest
 import torch  # noqa: F401  -- before libcropsr_hip.so: PyTorch-ROCm bundles its own HIP
 #                runtime, and the one that initialises first must be torch's (parallel.py)
 
-from conftest import GOLDEN, PROBES, golden_fasta_path, read_golden_csv, run_cli
+from conftest import GOLDEN, LENGTH_CASES, PROBES, golden_fasta_path, read_golden_csv, run_cli
 
 pytestmark = pytest.mark.gpu
 
@@ -115,6 +115,19 @@ def test_cli_csv_bytes_equal_reference(name, manifest, tmp_path, monkeypatch):
     assert hashlib.md5(got).hexdigest() == manifest["cases"][name]["md5_libm"]
     assert got == want
     assert stdout == manifest["cases"][name]["stdout"]
+
+
+@pytest.mark.parametrize("name,guide_len", LENGTH_CASES)
+def test_cli_csv_bytes_equal_reference_other_guide_lengths(name, guide_len, manifest, tmp_path, monkeypatch):
+    """The same with -l 17 ... 25 (generic-length kernels): bytes of the real reference's CSV."""
+    from cropsr_amd.cli import EngineBackend
+    be = EngineBackend(0)
+    got, stdout = run_cli(tmp_path, monkeypatch, golden_fasta_path(name, tmp_path), be, manifest["seed"],
+                          extra=("-l", str(guide_len)))
+    be.close()
+    case = manifest["cases"]["%s.l%d" % (name, guide_len)]
+    assert got == read_golden_csv(name, guide_len)
+    assert hashlib.md5(got).hexdigest() == case["md5_libm"] and stdout == case["stdout"]
 
 
 def test_sample_vs_committed_reference_output(engine, sample_fasta_text):

@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, PROBES, golden_fasta_path, oracle_scan_provider, read_golden_csv, run_cli
+from conftest import GOLDEN, LENGTH_CASES, PROBES, golden_fasta_path, oracle_scan_provider, read_golden_csv, run_cli
 
 
 def test_weights_match_reference_constants(oracle):
@@ -118,3 +118,19 @@ def test_exp_table_path_needs_no_small_argument_case(oracle):
     assert (bits(oracle.exp_table_path(tiny)) == bits(libm)).all()
     x = rng.uniform(-40, 40, 200000)
     assert (bits(oracle.exp_table_path(x)) == bits(oracle.exp(x))).all()
+
+
+@pytest.mark.parametrize("name,guide_len", LENGTH_CASES)
+def test_cli_reproduces_reference_csv_other_guide_lengths(name, guide_len, oracle, manifest, tmp_path, monkeypatch):
+    """-l 17 ... 25: the oracle's keep-filter / window rules for l != 20 and the host's row
+    assembly against the real reference's CSV bytes and stdout."""
+    got, stdout = run_cli(tmp_path, monkeypatch, golden_fasta_path(name, tmp_path), oracle_scan_provider(oracle),
+                          manifest["seed"], extra=("-l", str(guide_len)))
+    case = manifest["cases"]["%s.l%d" % (name, guide_len)]
+    assert got == read_golden_csv(name, guide_len)
+    assert hashlib.md5(got).hexdigest() == case["md5_libm"] and stdout == case["stdout"]
+    import csv
+    import io
+    body = list(csv.reader(io.StringIO(got.decode(), newline="")))[1:]
+    scored = sum(1 for r in body if len(r) == 12)
+    assert len(body) == case["rows"] and (scored == 0 if guide_len < 20 else scored < len(body))
