@@ -1,9 +1,10 @@
 // crp_api.cpp -- C ABI of libcropsr_hip.so (see include/cropsr_hip.h).
 //
 // Host side of the MI355X PAM-scan/score engine: owns the HIP stream, the
-// device-resident arena (four bit-planes in HBM), the hit tables and the
-// count -> scan -> emit launch sequence.  No CPU compute path exists here except
-// crp_pack_ascii (host packing, the alternative to the on-GPU pack kernel).
+// device-resident arena (four bit-planes in HBM), the hit tables and the scan
+// launches (one chained-scan kernel by default, count -> tile scan -> emit with
+// CRP_OPT_TWO_PASS).  No CPU compute path exists here except crp_pack_ascii
+// (host packing, the alternative to the on-GPU pack kernel).
 #include "cropsr_hip.h"
 
 #include <hip/hip_runtime.h>
