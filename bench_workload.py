@@ -129,6 +129,18 @@ def switchgrass_like(genome=0, scale=1.0):
                     specs, gc=0.46, soft_mask=0.55, n_frac=0.03)
 
 
+def sorghum_like():
+    """cfg 4 stand-in: 10 chromosomes (52-81 Mb) + 857 scaffolds (1-200 kb), ~730 Mb, GC 0.44,
+    60 % soft-masked, 1 % N."""
+    rng = np.random.default_rng(np.random.SeedSequence([4, 0]))
+    chrom, scaf = _lengths(rng, 10, 52_000_000, 81_000_000, 857, 1_000, 200_000)
+    f = (730e6 - sum(scaf)) / sum(chrom)
+    chrom = [int(c * f) for c in chrom]
+    specs = [ContigSpec("Chr%02d" % (i + 1), n, (4, 0, i)) for i, n in enumerate(chrom)]
+    specs += [ContigSpec("super_%d" % (i + 11), n, (4, 0, 1000 + i)) for i, n in enumerate(scaf)]
+    return Workload("sorghum-like-730Mb", specs, gc=0.44, soft_mask=0.60, n_frac=0.01)
+
+
 def ecoli_like():
     """cfg 2 stand-in: one 4 641 652-base contig, GC 0.508, upper case, no N."""
     return Workload("ecoli-like-4.6Mb", [ContigSpec("NC_000913", 4_641_652, (2, 0, 0))],

@@ -370,6 +370,69 @@ def test_full_size_properties(engine):
     ar.close()
 
 
+@pytest.mark.parametrize("config", ["ecoli", "tair10", "sorghum", "switchgrass"])
+def test_baseline_config_workloads_sampled_against_oracle(_engine, oracle, config):
+    """The four genome configurations of BASELINE.json as seeded stand-ins (bench_workload.py: same
+    size, contig structure, GC, soft-mask and N content), decorated as the reference decorates
+    them, scanned whole on the GPU (as many arenas as needed) and then checked against the oracle:
+    the whole genome for E. coli, and for the larger ones the first and last 200 kb of the big
+    contigs, every small contig and 40 random 100 kb windows (interior hits only: a window is
+    re-scanned by the oracle as if it were a contig, so hits within 64 positions of its cut ends
+    are left out).  Positions and scores bit-exact; per-strand counts of the whole genome equal a
+    numpy count of the PAM predicate."""
+    import bench_workload as bw
+    scale = float(os.environ.get("CROPSR_TEST_CONFIG_SCALE", "1.0"))
+    wl = {"ecoli": bw.ecoli_like, "tair10": bw.tair10_like, "sorghum": bw.sorghum_like,
+          "switchgrass": lambda: bw.switchgrass_like(scale=scale)}[config]()
+    _engine.configure(two_pass=False)
+    strings = [wl.contig_string(k) for k in range(len(wl.specs))]
+    genome = _engine.genome(strings)
+    hits = genome.scan_score(20, want_pre=False)
+    G, C = ord("G"), ord("C")
+    n_plus = n_minus = 0
+    rng = np.random.default_rng(17)
+    big = [k for k, s in enumerate(strings) if s.size > 2_000_000]
+    windows = [(k, 0, s.size) for k, s in enumerate(strings) if s.size <= 300_000][:60]
+    if config == "ecoli":
+        windows = [(0, 0, strings[0].size)]
+    else:
+        for k in big:
+            windows += [(k, 0, 200_000), (k, strings[k].size - 200_000, strings[k].size)]
+        for _ in range(40):
+            k = big[int(rng.integers(0, len(big)))]
+            a = int(rng.integers(0, strings[k].size - 100_000))
+            windows.append((k, a, a + 100_000))
+    per_contig = {}
+    for k, s in enumerate(strings):
+        # the reference's predicate on the decorated string (upper-case G / C only, CROPSR.py:98-104,419,430)
+        gg = (s[1:-1] == G) & (s[2:] == G)
+        cc = (s[:-2] == C) & (s[1:-1] == C)
+        i = np.nonzero(gg)[0]
+        j = np.nonzero(cc)[0]
+        n_plus += int((i - 20 >= 5).sum())
+        n_minus += int(((j >= 2) & (j + 23 <= s.size + 10) & (j + 2 < s.size)).sum())
+    assert (hits.n_plus, hits.n_minus) == (n_plus, n_minus)
+    checked = 0
+    for k, a, b in windows:
+        if k not in per_contig:
+            per_contig[k] = hits.contig(k)
+        got = per_contig[k]
+        s = strings[k]
+        want = oracle.scan_score(s[a:b].tobytes(), 20)
+        lo = a if a == 0 else a + 64
+        hi = b if b == s.size else b - 64
+        for strand in ("plus", "minus"):
+            gp = got["pos_" + strand].astype(np.int64)
+            gsel = (gp >= lo) & (gp < hi)
+            wp = want["pos_" + strand].astype(np.int64) + a
+            wsel = (wp >= lo) & (wp < hi)
+            assert (gp[gsel] == wp[wsel]).all(), (config, k, a, strand)
+            assert (bits(got["score_" + strand][gsel]) == bits(want["score_" + strand][wsel])).all(), (config, k, a, strand)
+            checked += int(gsel.sum())
+    assert checked > {"ecoli": 400_000, "tair10": 300_000, "sorghum": 400_000, "switchgrass": 400_000 * scale}[config]
+    genome.close()
+
+
 def test_genome_spread_over_several_arenas(engine, oracle):
     """Inputs beyond one arena (2^31 characters) are split contig by contig; forced here
     with a tiny per-arena limit.  Results must not depend on the split."""
