@@ -73,14 +73,14 @@ def build_parser():
     return p
 
 
-def import_gff_file(gff, verbose):
+def import_gff_file(gff, verbose, out=sys.stdout):
     """Side effects of CROPSR.py:77-95.  The table is parsed exactly as the
     reference parses it and, exactly as there, never used."""
     import pandas as pd
     start_index = 0
     with open(gff, "r") as raw:
         if verbose:
-            print(f"Annotation file {gff} successfully imported")
+            print(f"Annotation file {gff} successfully imported", file=out)
         lines = raw.readlines()
         for index, line in enumerate(lines):
             if "##" not in line:
@@ -89,7 +89,7 @@ def import_gff_file(gff, verbose):
     cols = ["chromosome", "source", "feature", "start", "end", "score", "strand", "phase", "attributes"]
     table = pd.read_csv(gff, sep="\t", skiprows=start_index, header=None, names=cols)
     if verbose:
-        print("Annotation database successfully generated")
+        print("Annotation database successfully generated", file=out)
     return table
 
 
@@ -157,14 +157,12 @@ def run(args, backend=None, out=sys.stdout):
     del data
     if verbose:
         print("The genome was successfully converted to a dictionary", file=out)
-    import_gff_file(args.g, verbose)  # CROPSR.py:375 (raises like the reference if -g is missing)
+    import_gff_file(args.g, verbose, out)  # CROPSR.py:375 (raises like the reference if -g is missing)
 
     if verbose:
-        print("""
-            Initiating PAM site detection.
-
-            Please wait, this may take a while...
-            """, file=out)
+        # (the blank line in the middle carries the reference's 12 blanks of indentation)
+        print("\n            Initiating PAM site detection.\n            \n"
+              "            Please wait, this may take a while...\n            ", file=out)
 
     if getattr(args, "seed", None) is not None:
         import numpy as np

@@ -51,6 +51,16 @@ PROBES = ["multi", "twoline", "spaces", "edges", "mixed", "rightend", "tiny", "d
 LENGTH_CASES = [("mixed", 23), ("rightend", 17), ("multi", 25), ("tiny", 21), ("edges", 24)]
 
 
+VERBOSE_CASES = ["multi", "mixed"]
+
+
+def normalize_verbose(text):
+    """-v output with the run-specific parts masked: file paths and the host's CPU count."""
+    import re
+    text = re.sub(r"\S*/\S+", "<PATH>", text)
+    return re.sub(r"(Number of available CPUs:\s+)\d+", r"\1<N>", text)
+
+
 def read_golden_csv(name, guide_len=None):
     if guide_len is not None:
         with open(os.path.join(GOLDEN, "probe_%s.l%d.libm.csv" % (name, guide_len)), "rb") as f:

@@ -158,8 +158,17 @@ def build_probes():
 LENGTH_CASES = [("mixed", 23), ("rightend", 17), ("multi", 25), ("tiny", 21), ("edges", 24)]
 
 
+# probes re-run with -v: the banner, the per-contig site counts and the progress lines on stdout
+VERBOSE_CASES = ["multi", "mixed"]
+
+
 def length_cases(scratch, manifest):
     probes = build_probes()
+    for name in VERBOSE_CASES:
+        csv_b, out = run_reference(probes[name], MINI_GFF, "libm", scratch, extra=("-v",))
+        assert hashlib.md5(csv_b).hexdigest() == manifest["cases"][name]["md5_libm"]  # -v does not change the CSV
+        manifest["cases"]["%s.verbose" % name] = {"probe": name, "md5_libm": hashlib.md5(csv_b).hexdigest(),
+                                                  "stdout": out}
     for name, l in LENGTH_CASES:
         csv_b, out = run_reference(probes[name], MINI_GFF, "libm", scratch, extra=("-l", str(l)))
         with open(os.path.join(HERE, "probe_%s.l%d.libm.csv" % (name, l)), "wb") as f:

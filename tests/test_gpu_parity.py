@@ -15,7 +15,8 @@ import pytest
 import torch  # noqa: F401  -- before libcropsr_hip.so: PyTorch-ROCm bundles its own HIP
 #                runtime, and the one that initialises first must be torch's (parallel.py)
 
-from conftest import GOLDEN, LENGTH_CASES, PROBES, golden_fasta_path, read_golden_csv, run_cli
+from conftest import (GOLDEN, LENGTH_CASES, PROBES, VERBOSE_CASES, golden_fasta_path, normalize_verbose,
+                      read_golden_csv, run_cli)
 
 pytestmark = pytest.mark.gpu
 
@@ -128,6 +129,17 @@ def test_cli_csv_bytes_equal_reference_other_guide_lengths(name, guide_len, mani
     case = manifest["cases"]["%s.l%d" % (name, guide_len)]
     assert got == read_golden_csv(name, guide_len)
     assert hashlib.md5(got).hexdigest() == case["md5_libm"] and stdout == case["stdout"]
+
+
+@pytest.mark.parametrize("name", VERBOSE_CASES)
+def test_cli_verbose_output_equals_reference(name, manifest, tmp_path, monkeypatch):
+    """-v on the GPU path: the reference's banner, progress lines and pre-filter site counts."""
+    from cropsr_amd.cli import EngineBackend
+    be = EngineBackend(0)
+    got, stdout = run_cli(tmp_path, monkeypatch, golden_fasta_path(name, tmp_path), be, manifest["seed"], extra=("-v",))
+    be.close()
+    assert got == read_golden_csv(name)
+    assert normalize_verbose(stdout) == normalize_verbose(manifest["cases"][name + ".verbose"]["stdout"])
 
 
 def test_sample_vs_committed_reference_output(engine, sample_fasta_text):

@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, LENGTH_CASES, PROBES, golden_fasta_path, oracle_scan_provider, read_golden_csv, run_cli
+from conftest import GOLDEN, LENGTH_CASES, PROBES, VERBOSE_CASES, golden_fasta_path, normalize_verbose, oracle_scan_provider, read_golden_csv, run_cli
 
 
 def test_weights_match_reference_constants(oracle):
@@ -134,3 +134,14 @@ def test_cli_reproduces_reference_csv_other_guide_lengths(name, guide_len, oracl
     body = list(csv.reader(io.StringIO(got.decode(), newline="")))[1:]
     scored = sum(1 for r in body if len(r) == 12)
     assert len(body) == case["rows"] and (scored == 0 if guide_len < 20 else scored < len(body))
+
+
+@pytest.mark.parametrize("name", VERBOSE_CASES)
+def test_cli_verbose_output_equals_reference(name, oracle, manifest, tmp_path, monkeypatch):
+    """-v: banner, settings block, progress lines and the per-contig PAM-site counts (which the
+    reference takes BEFORE its keep-filter, CROPSR.py:436-439) as the real reference prints them;
+    paths and the CPU count masked on both sides.  The CSV is the non-verbose one."""
+    got, stdout = run_cli(tmp_path, monkeypatch, golden_fasta_path(name, tmp_path), oracle_scan_provider(oracle),
+                          manifest["seed"], extra=("-v",))
+    assert got == read_golden_csv(name)
+    assert normalize_verbose(stdout) == normalize_verbose(manifest["cases"][name + ".verbose"]["stdout"])
