@@ -46,7 +46,7 @@ def sample_fasta_text():
         return f.read()
 
 
-PROBES = ["multi", "twoline", "spaces", "edges", "mixed", "rightend", "tiny", "dupname"]
+PROBES = ["multi", "twoline", "spaces", "edges", "mixed", "rightend", "tiny", "dupname", "crlf"]
 # probes the real reference was also run on with a non-default guide length: (probe, -l value)
 LENGTH_CASES = [("mixed", 23), ("rightend", 17), ("multi", 25), ("tiny", 21), ("edges", 24)]
 

@@ -80,7 +80,7 @@ def run_reference(fa_text, gff_text, kind, scratch, extra=()):
     fa = os.path.join(d, "in.fa")
     gff = os.path.join(d, "in.gff")
     out = os.path.join(d, "out.csv")
-    with open(fa, "w") as f:
+    with open(fa, "w", newline="") as f:
         f.write(fa_text)
     with open(gff, "w") as f:
         f.write(gff_text)
@@ -164,6 +164,16 @@ VERBOSE_CASES = ["multi", "mixed"]
 
 def length_cases(scratch, manifest):
     probes = build_probes()
+    # CRLF line ends: the reference opens the FASTA in text mode (CROPSR.py:58), which turns \r\n into \n
+    crlf = probes["multi"].replace("\n", "\r\n")
+    csv_b, out = run_reference(crlf, MINI_GFF, "libm", scratch)
+    with open(os.path.join(HERE, "probe_crlf.fa"), "w", newline="") as f:
+        f.write(crlf)
+    with open(os.path.join(HERE, "probe_crlf.libm.csv"), "wb") as f:
+        f.write(csv_b)
+    manifest["cases"]["crlf"] = {"rows": csv_b.count(b"\r\n") - 1, "md5_libm": hashlib.md5(csv_b).hexdigest(),
+                                 "stdout": out, "same_csv_as": "multi"}
+    assert csv_b == open(os.path.join(HERE, "probe_multi.libm.csv"), "rb").read()
     for name in VERBOSE_CASES:
         csv_b, out = run_reference(probes[name], MINI_GFF, "libm", scratch, extra=("-v",))
         assert hashlib.md5(csv_b).hexdigest() == manifest["cases"][name]["md5_libm"]  # -v does not change the CSV
