@@ -231,3 +231,36 @@ def test_small_chunk_walk_end_to_end(oracle, tmp_path, monkeypatch):
         for index, (g, w) in enumerate(zip(got, lesser)):
             assert g[0] == id_list[index_range - index - 1]
             assert g[1:9] == w[1:9]
+
+
+def test_cli_error_behaviour_of_the_reference(oracle, tmp_path, monkeypatch):
+    """CROPSR.py:335-336 exits with a message when --cas9 is missing, before anything is written;
+    a missing -g fails in open(None) after time.txt was created (:371, :375, :77-79); a missing
+    FASTA raises FileNotFoundError from :58."""
+    import io
+    from conftest import GOLDEN, oracle_scan_provider
+    from cropsr_amd import cli
+    monkeypatch.chdir(tmp_path)
+    fa = os.path.join(GOLDEN, "probe_tiny.fa")
+    gff = os.path.join(GOLDEN, "sample_head.gff")
+    out_csv = str(tmp_path / "o.csv")
+    be = oracle_scan_provider(oracle)
+
+    args = cli.build_parser().parse_args(["-f", fa, "-g", gff, "-o", out_csv])
+    with pytest.raises(SystemExit) as e:
+        cli.run(args, backend=be, out=io.StringIO())
+    assert e.value.code == "Please select at least one CRISPR system: Cas9"
+    assert not os.path.exists(out_csv) and not os.path.exists(tmp_path / "time.txt")
+
+    args = cli.build_parser().parse_args(["-f", fa, "-o", out_csv, "--cas9"])
+    with pytest.raises(TypeError):
+        cli.run(args, backend=be, out=io.StringIO())
+    assert os.path.exists(tmp_path / "time.txt") and not os.path.exists(out_csv)
+
+    args = cli.build_parser().parse_args(["-f", str(tmp_path / "nope.fa"), "-g", gff, "-o", out_csv, "--cas9"])
+    with pytest.raises(FileNotFoundError):
+        cli.run(args, backend=be, out=io.StringIO())
+    # -f is required (CROPSR.py:24-26).  With metavar='' on every option, like the reference, Python 3.10's
+    # argparse trips over its own usage formatter while reporting that (AssertionError instead of exit 2)
+    with pytest.raises((SystemExit, AssertionError)):
+        cli.build_parser().parse_args(["-g", gff, "--cas9"])
