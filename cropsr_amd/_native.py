@@ -55,8 +55,6 @@ SIGNATURES = {
 CRP_OK = 0
 ORDER_BODY4, ORDER_TAIL2, ORDER_DOT1 = 0, 1, 2
 OPT_TWO_PASS = 1
-OPT_PERSISTENT_EMIT = 2
-OPT_SLICES = 3
 CRP_ERR_NO_DEVICE = -2
 CRP_ERR_IO = -8
 

@@ -25,7 +25,6 @@ namespace {
 // descriptors carry two 31-bit counts in one 64-bit word
 constexpr uint64_t kMaxArenaWords = (1ull << 31) / 64 - 2 * crp::ARENA_ALIGN_WORDS;
 constexpr uint64_t kUploadChunk = 64ull << 20;  // characters per H2D + pack round (multiple of 4096)
-constexpr int kMaxSlices = 8;
 
 inline uint64_t round_up(uint64_t x, uint64_t m) { return (x + m - 1) / m * m; }
 
@@ -46,13 +45,9 @@ struct crp_ctx {
     uint64_t d_rows_cap = 0;
     bool two_pass = false;  // CRP_OPT_TWO_PASS
     uint64_t chain_timeouts = 0;  // single-pass scans that fell back to the three-launch sequence
-    int emit_blocks = 0;   // CRP_OPT_PERSISTENT_EMIT: workgroups of the persistent emit kernel (0 = one per tile)
     // measurement
     int profiling = 0;  // 0 off, 1 emit kernel only, 2 all kernels
-    hipStream_t stream2 = nullptr;             // count + scan of the next slice (CRP_OPT_SLICES)
-    int slices = 1;
-    hipEvent_t ev[6 * 8] = {};                 // profiling: (slice, kind) start/stop pairs
-    hipEvent_t ev_slice[8] = {};               // "counts and offsets of slice k are ready"
+    hipEvent_t ev[6] = {};  // profiling: start/stop pair per kernel kind
     double ms[3] = {0, 0, 0};
     uint64_t launches[3] = {0, 0, 0};
 };
@@ -131,21 +126,11 @@ int crp_init(int device_id, crp_ctx **out)
         delete ctx;
         return CRP_ERR_HIP;
     }
-    if (hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess) {
-        crp_destroy(ctx);
-        return CRP_ERR_HIP;
-    }
     for (auto &e : ctx->ev)
         if (hipEventCreate(&e) != hipSuccess) {
             crp_destroy(ctx);
             return CRP_ERR_HIP;
         }
-    for (auto &e : ctx->ev_slice)
-        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
-            crp_destroy(ctx);
-            return CRP_ERR_HIP;
-        }
-    ctx->emit_blocks = 0;  // one workgroup per tile: measured faster than the persistent form
     *out = ctx;
     return CRP_OK;
 }
@@ -155,12 +140,8 @@ int crp_destroy(crp_ctx *ctx)
     if (!ctx) return CRP_OK;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
     for (auto &e : ctx->ev)
         if (e) (void)hipEventDestroy(e);
-    for (auto &e : ctx->ev_slice)
-        if (e) (void)hipEventDestroy(e);
-    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     (void)hipFree(ctx->d_text);
     (void)hipFree(ctx->d_rows);
     (void)hipFree(ctx->d_rpre);
@@ -399,23 +380,22 @@ static int grow(crp_ctx *ctx, void **p, uint64_t *cap, uint64_t need, size_t ele
     return CRP_OK;
 }
 
-// event pair (kind, slice): kind 0 = count, 1 = tile scan, 2 = emit
+// event pair per kind: 0 = count, 1 = tile scan, 2 = emit (the whole scan in single-launch mode)
 // profiling level 1 brackets only the emit kernel (the one the roofline is quoted on; two event
-// records per step), level 2 all three kernels
+// records per step), level 2 all kernels
 static bool prof_on(const crp_ctx *ctx, int kind) { return ctx->profiling >= 2 || (ctx->profiling == 1 && kind == 2); }
-static void prof_begin(crp_ctx *ctx, int kind, int slice, hipStream_t s)
+static void prof_begin(crp_ctx *ctx, int kind)
 {
-    if (prof_on(ctx, kind)) (void)hipEventRecord(ctx->ev[(slice * 3 + kind) * 2], s);
+    if (prof_on(ctx, kind)) (void)hipEventRecord(ctx->ev[kind * 2], ctx->stream);
 }
-static void prof_end(crp_ctx *ctx, int kind, int slice, hipStream_t s)
+static void prof_end(crp_ctx *ctx, int kind)
 {
-    if (prof_on(ctx, kind)) (void)hipEventRecord(ctx->ev[(slice * 3 + kind) * 2 + 1], s);
+    if (prof_on(ctx, kind)) (void)hipEventRecord(ctx->ev[kind * 2 + 1], ctx->stream);
 }
-static void prof_collect(crp_ctx *ctx, int kind, int slice)
+static void prof_collect(crp_ctx *ctx, int kind)
 {
     float ms = 0.f;
-    if (prof_on(ctx, kind) &&
-        hipEventElapsedTime(&ms, ctx->ev[(slice * 3 + kind) * 2], ctx->ev[(slice * 3 + kind) * 2 + 1]) == hipSuccess) {
+    if (prof_on(ctx, kind) && hipEventElapsedTime(&ms, ctx->ev[kind * 2], ctx->ev[kind * 2 + 1]) == hipSuccess) {
         ctx->ms[kind] += ms;
         ctx->launches[kind] += 1;
     }
@@ -446,56 +426,36 @@ static crp::HitTables table_args(const crp_arena *a, int want_pre)
                           want_pre ? std::min(a->tab_cap[1], a->pre_cap[1]) : a->tab_cap[1]};
 }
 
-// count -> tile scan -> emit.  The tile range is cut into `slices` contiguous slices (whole scan
-// chunks); count + scan of slice k+1 run on a second stream while slice k is emitted on the main
-// one, because the count pass is HBM-bound and the emit pass is VALU-bound.  The table sizes must
-// be known before the first emit: once an arena has been scanned the tables exist and the emits
-// are queued speculatively (stores are bounds-checked, totals compared afterwards); the very
-// first scan of an arena waits for the totals instead.
+// count -> tile scan -> emit.  The table sizes must be known before the emit: once an arena has been
+// scanned the tables exist and the emit is queued speculatively (stores are bounds-checked, totals
+// compared afterwards); the very first scan of an arena waits for the totals instead.
 static int scan_two_pass(crp_arena *a, const crp::Planes &pl, uint64_t eff_words, int guide_len, int want_pre,
                          uint64_t n[2])
 {
     crp_ctx *ctx = a->ctx;
     const uint32_t n_tiles = a->n_tiles;
-    const uint32_t n_chunks = (n_tiles + crp::SCAN_CHUNK_TILES - 1) / crp::SCAN_CHUNK_TILES;
     const bool speculative = a->tab_cap[0] && a->tab_cap[1] && (!want_pre || (a->pre_cap[0] && a->pre_cap[1]));
-    int slices = speculative ? ctx->slices : 1;
-    if ((uint32_t)slices > n_chunks) slices = (int)n_chunks;
-    if (slices > kMaxSlices) slices = kMaxSlices;
-    if (slices < 1) slices = 1;
-    hipStream_t s_count = slices > 1 ? ctx->stream2 : ctx->stream;
-
-    crp::HitTables out = table_args(a, want_pre);
-    for (int k = 0; k < slices; ++k) {
-        const uint32_t c0 = (uint32_t)((uint64_t)n_chunks * k / slices), c1 = (uint32_t)((uint64_t)n_chunks * (k + 1) / slices);
-        const uint32_t t0 = c0 * crp::SCAN_CHUNK_TILES, t1 = std::min(n_tiles, c1 * crp::SCAN_CHUNK_TILES);
-        prof_begin(ctx, 0, k, s_count);
-        CRP_HIP(ctx, crp::launch_count(s_count, pl, eff_words, guide_len, a->d_tile_cnt, t0, t1 - t0));
-        prof_end(ctx, 0, k, s_count);
-        prof_begin(ctx, 1, k, s_count);
-        CRP_HIP(ctx, crp::launch_tile_scan(s_count, a->d_tile_cnt, n_tiles, a->d_tile_off, a->d_totals, c0, c1 - c0));
-        prof_end(ctx, 1, k, s_count);
-        if (slices > 1) {
-            CRP_HIP(ctx, hipEventRecord(ctx->ev_slice[k], s_count));
-            CRP_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_slice[k], 0));
-        }
-        if (!speculative) {
-            CRP_HIP(ctx, hipMemcpyAsync(a->h_totals, a->d_totals, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-            CRP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            n[0] = a->h_totals[0];
-            n[1] = a->h_totals[1];
-            int rc = reserve_tables(a, n, want_pre);
-            if (rc != CRP_OK) return rc;
-            out = table_args(a, want_pre);
-        }
-        prof_begin(ctx, 2, k, ctx->stream);
-        CRP_HIP(ctx, crp::launch_emit(ctx->stream, pl, eff_words, guide_len, a->d_tile_off, out, ctx->emit_blocks, t0, t1 - t0));
-        prof_end(ctx, 2, k, ctx->stream);
+    prof_begin(ctx, 0);
+    CRP_HIP(ctx, crp::launch_count(ctx->stream, pl, eff_words, guide_len, a->d_tile_cnt, n_tiles));
+    prof_end(ctx, 0);
+    prof_begin(ctx, 1);
+    CRP_HIP(ctx, crp::launch_tile_scan(ctx->stream, a->d_tile_cnt, n_tiles, a->d_tile_off, a->d_totals));
+    prof_end(ctx, 1);
+    if (!speculative) {
+        CRP_HIP(ctx, hipMemcpyAsync(a->h_totals, a->d_totals, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+        CRP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        n[0] = a->h_totals[0];
+        n[1] = a->h_totals[1];
+        int rc = reserve_tables(a, n, want_pre);
+        if (rc != CRP_OK) return rc;
     }
+    crp::HitTables out = table_args(a, want_pre);
+    prof_begin(ctx, 2);
+    CRP_HIP(ctx, crp::launch_emit(ctx->stream, pl, eff_words, guide_len, a->d_tile_off, out));
+    prof_end(ctx, 2);
     CRP_HIP(ctx, hipMemcpyAsync(a->h_totals, a->d_totals, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
     CRP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    for (int k = 0; k < slices; ++k)
-        for (int kind = 0; kind < 3; ++kind) prof_collect(ctx, kind, k);
+    for (int kind = 0; kind < 3; ++kind) prof_collect(ctx, kind);
     n[0] = a->h_totals[0];
     n[1] = a->h_totals[1];
     if (n[0] > out.cap_plus || n[1] > out.cap_minus) {
@@ -504,7 +464,7 @@ static int scan_two_pass(crp_arena *a, const crp::Planes &pl, uint64_t eff_words
         int rc = reserve_tables(a, n, want_pre);
         if (rc != CRP_OK) return rc;
         out = table_args(a, want_pre);
-        CRP_HIP(ctx, crp::launch_emit(ctx->stream, pl, eff_words, guide_len, a->d_tile_off, out, ctx->emit_blocks, 0, n_tiles));
+        CRP_HIP(ctx, crp::launch_emit(ctx->stream, pl, eff_words, guide_len, a->d_tile_off, out));
         CRP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     return CRP_OK;
@@ -529,9 +489,9 @@ static int scan_single_pass(crp_arena *a, const crp::Planes &pl, uint64_t eff_wo
         if (rc != CRP_OK) return rc;
         const crp::HitTables out = table_args(a, want_pre);
         uint64_t *cur = a->d_chain[a->chain_cur], *next = a->d_chain[a->chain_cur ^ 1];
-        prof_begin(ctx, 2, 0, ctx->stream);
+        prof_begin(ctx, 2);
         CRP_HIP(ctx, crp::launch_emit_chained(ctx->stream, pl, eff_words, guide_len, cur, next, out));
-        prof_end(ctx, 2, 0, ctx->stream);
+        prof_end(ctx, 2);
         // header: ticket | fail << 32, total '+', total '-'
         CRP_HIP(ctx, hipMemcpyAsync(a->h_totals, cur, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
         CRP_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -542,7 +502,7 @@ static int scan_single_pass(crp_arena *a, const crp::Planes &pl, uint64_t eff_wo
             *chain_failed = true;
             return CRP_ERR_STATE;
         }
-        prof_collect(ctx, 2, 0);
+        prof_collect(ctx, 2);
         n[0] = a->h_totals[1];
         n[1] = a->h_totals[2];
         if (n[0] <= out.cap_plus && n[1] <= out.cap_minus) return CRP_OK;
@@ -675,14 +635,6 @@ int crp_configure(crp_ctx *ctx, int option, int64_t value)
     if (!ctx) return CRP_ERR_INVALID;
     switch (option) {
         case CRP_OPT_TWO_PASS: ctx->two_pass = value != 0; return CRP_OK;
-        case CRP_OPT_SLICES:
-            if (value < 1 || value > kMaxSlices) return CRP_ERR_INVALID;
-            ctx->slices = (int)value;
-            return CRP_OK;
-        case CRP_OPT_PERSISTENT_EMIT:
-            if (value < 0) return CRP_ERR_INVALID;
-            ctx->emit_blocks = value == 1 ? ctx->n_cu * crp::emit_stream_blocks_per_cu() : (int)value;
-            return CRP_OK;
         default: return CRP_ERR_INVALID;
     }
 }

@@ -38,19 +38,13 @@ struct HitTables {
     uint64_t cap_minus;
 };
 
-// The three passes can be launched on slices of the tile range (tile_first even, scan in chunks of
-// SCAN_CHUNK_TILES), so that the memory-bound count pass of slice k+1 overlaps the VALU-bound emit
-// pass of slice k on another stream.
+// three-launch mode: per-tile counts, their exclusive scan (one workgroup per SCAN_CHUNK_TILES tiles), emit
 constexpr uint32_t SCAN_CHUNK_TILES = 8192;
 hipError_t launch_count(hipStream_t s, const Planes &pl, uint64_t n_words_padded, int l, uint2 *tile_cnt,
-                        uint32_t tile_first, uint32_t tile_count);
-hipError_t launch_tile_scan(hipStream_t s, const uint2 *tile_cnt, uint32_t n_tiles, uint2 *tile_off,
-                            uint64_t *totals, uint32_t chunk_first, uint32_t chunk_count);
-// persistent_blocks > 0: the software-pipelined persistent kernel with that many workgroups;
-// 0: one workgroup per tile
+                        uint32_t n_tiles);
+hipError_t launch_tile_scan(hipStream_t s, const uint2 *tile_cnt, uint32_t n_tiles, uint2 *tile_off, uint64_t *totals);
 hipError_t launch_emit(hipStream_t s, const Planes &pl, uint64_t n_words_padded, int l, const uint2 *tile_off,
-                       const HitTables &out, int persistent_blocks, uint32_t tile_first, uint32_t tile_count);
-int emit_stream_blocks_per_cu();
+                       const HitTables &out);
 // single-pass mode: `chain` and `chain_next` = chain_bytes(n_tiles) bytes of device scratch each; `chain`
 // must be all zero, the kernel leaves `chain_next` all zero; on return chain[0] = ticket | fail << 32,
 // chain[1], chain[2] = the '+' and '-' table totals

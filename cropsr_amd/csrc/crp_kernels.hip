@@ -212,7 +212,7 @@ __device__ __forceinline__ uint64_t counts_of(uint64_t g_c, uint64_t g_n, uint64
 // every funnel shift has a constant amount and becomes one v_alignbit_b32 per half.
 template <int LFIX>
 __global__ __launch_bounds__(BLOCK) void count_kernel(Planes pl, uint64_t n_words_padded, int l_arg,
-                                                       uint2 *__restrict__ tile_cnt, uint32_t pair_first)
+                                                       uint2 *__restrict__ tile_cnt)
 {
     const int l = LFIX > 0 ? LFIX : l_arg;
     // a workgroup covers COUNT_WORDS words = COUNT_TPB emit tiles; a wave takes 128 words at a time
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(BLOCK) void count_kernel(Planes pl, uint64_t n_word
     constexpr int COUNT_TPB = COUNT_WORDS / TILE_WORDS;
     constexpr int REPS = COUNT_WORDS / 512;
     static_assert(BLOCK == 256 && (TILE_WORDS == 256 || TILE_WORDS % 512 == 0), "count pass geometry");
-    const uint32_t pair = blockIdx.x + pair_first;
+    const uint32_t pair = blockIdx.x;
     __shared__ uint64_t wave_tot[BLOCK / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint64_t c = 0;
@@ -276,9 +276,9 @@ __global__ __launch_bounds__(BLOCK) void count_kernel(Planes pl, uint64_t n_word
 // in parallel with no hand-off; the last workgroup also publishes the totals.
 __global__ __launch_bounds__(1024) void tile_scan_kernel(const uint2 *__restrict__ tile_cnt, uint32_t n_tiles,
                                                           uint2 *__restrict__ tile_off,
-                                                          uint64_t *__restrict__ totals, uint32_t chunk_first)
+                                                          uint64_t *__restrict__ totals)
 {
-    const uint32_t chunk = blockIdx.x + chunk_first;
+    const uint32_t chunk = blockIdx.x;
     // Chunks of 8192 tiles go through LDS: coalesced load, every thread scans its 8
     // consecutive entries, one scan of the 1024 thread sums, coalesced store.
     // Per-strand totals stay below 2^31, so the packed halves never carry into
@@ -518,8 +518,7 @@ __device__ __forceinline__ void emit_rounds(uint64_t (*sh)[TW + 2], uint16_t *li
 template <int WPT, bool CHAINED, int LFIX>
 __global__ __launch_bounds__(EMIT_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8))) void emit_kernel(Planes pl, uint64_t n_words_padded, int l_arg,
                                                       const uint2 *__restrict__ tile_off, uint64_t *chain,
-                                                      uint64_t *__restrict__ chain_next, HitTables out,
-                                                      uint32_t tile_first)
+                                                      uint64_t *__restrict__ chain_next, HitTables out)
 {
     const int l = LFIX > 0 ? LFIX : l_arg;
     constexpr int TW = EMIT_BLOCK * WPT;
@@ -532,7 +531,7 @@ __global__ __launch_bounds__(EMIT_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8
     __shared__ uint16_t list[CAP];
 
     const int tid = threadIdx.x;
-    uint32_t tile = blockIdx.x + tile_first;
+    uint32_t tile = blockIdx.x;
     if (CHAINED) {
 #if CRP_CHAIN_TICKET
         // tile ids in START order: whatever order the hardware dispatches workgroups in, every
@@ -565,7 +564,7 @@ __global__ __launch_bounds__(EMIT_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8
     ChainArgs ch{};
     if (CHAINED) {
         ch = ChainArgs{chain + CHAIN_HEADER_WORDS, reinterpret_cast<uint32_t *>(chain) + 1, chain + 1, &s_excl, &s_flag,
-                       tile, gridDim.x + tile_first, total};
+                       tile, gridDim.x, total};
         if (tid == 0) {
             lookback_publish(ch.desc, tile, total);
             // leave the OTHER descriptor buffer zeroed for the next launch (no memset between scans)
@@ -741,82 +740,6 @@ __device__ __forceinline__ void emit_rounds(uint64_t (*sh)[TW + 2], uint16_t *li
     }
 }
 
-// Persistent, software-pipelined form of the emit pass (offsets from tile_off).
-// A workgroup walks tiles blockIdx.x, +gridDim.x, ...; the global loads of the NEXT
-// tile are issued into registers before the current tile is compacted and scored,
-// and land in LDS when that is done -- so the HBM latency of every tile but the
-// first hides under ~10 us of VALU work instead of depending on how the phases of
-// co-resident workgroups happen to interleave.
-template <int WPT, int LFIX>
-__global__ __launch_bounds__(EMIT_BLOCK) void emit_stream_kernel(Planes pl, uint64_t n_words_padded, uint32_t n_tiles,
-                                                             int l_arg, const uint2 *__restrict__ tile_off,
-                                                             HitTables out)
-{
-    const int l = LFIX > 0 ? LFIX : l_arg;
-    static_assert(WPT >= 1 && WPT <= 4, "register prefetch below moves 2*WPT 16-byte loads per thread");
-    constexpr int TW = EMIT_BLOCK * WPT;
-    constexpr int CAP = CRP_LIST_CAP_PER_WPT * WPT;
-    __shared__ uint64_t sh[4][TW + 2];
-    __shared__ uint64_t exp_tab[256];
-    __shared__ uint64_t wave_tot[EMIT_BLOCK / 64];
-    __shared__ uint16_t list[CAP];
-    const int tid = threadIdx.x;
-    for (int k = tid; k < 256; k += EMIT_BLOCK) exp_tab[k] = CRP_EXP_TAB[k];
-
-    // prefetch registers: two 16-byte body loads per thread + one halo word for tid < 8
-    constexpr int PAIRS = TW / 2;
-    ulonglong2 body[2 * WPT];
-    uint64_t halo = 0;
-    auto fetch = [&](uint32_t tile) {
-        const uint64_t t0 = (uint64_t)tile * TW;
-#pragma unroll
-        for (int it = 0; it < 2 * WPT; ++it) {
-            const int q = tid + it * EMIT_BLOCK;
-            body[it] = *reinterpret_cast<const ulonglong2 *>(pl.plane[q / PAIRS] + t0 + 2 * (q % PAIRS));
-        }
-        if (tid < 8) {
-            const int p = tid >> 1;
-            const uint64_t voidw = (p < 2) ? ALL : 0ull;
-            if (tid & 1) {
-                const uint64_t idx = t0 + TW;
-                halo = idx < n_words_padded ? pl.plane[p][idx] : voidw;
-            } else {
-                halo = t0 > 0 ? pl.plane[p][t0 - 1] : voidw;
-            }
-        }
-    };
-    auto commit = [&]() {  // prefetched registers -> LDS tile image
-#pragma unroll
-        for (int it = 0; it < 2 * WPT; ++it) {
-            const int q = tid + it * EMIT_BLOCK;
-            sh[q / PAIRS][1 + 2 * (q % PAIRS)] = body[it].x;
-            sh[q / PAIRS][2 + 2 * (q % PAIRS)] = body[it].y;
-        }
-        if (tid < 8) sh[tid >> 1][(tid & 1) ? TW + 1 : 0] = halo;
-    };
-
-    uint32_t tile = blockIdx.x;
-    if (tile < n_tiles) fetch(tile);
-    for (; tile < n_tiles; tile += gridDim.x) {
-        commit();
-        __syncthreads();
-        const uint32_t next = tile + gridDim.x;
-        if (next < n_tiles) fetch(next);  // in flight while this tile is processed
-
-        uint64_t mp[WPT], mm[WPT];
-        thread_masks<WPT, TW>(sh, l, mp, mm);
-        uint64_t c = 0;
-#pragma unroll
-        for (int k = 0; k < WPT; ++k) c += (uint64_t)__popcll(mp[k]) | ((uint64_t)__popcll(mm[k]) << 32);
-        uint64_t total;
-        const uint64_t ex = block_exclusive_scan<(EMIT_BLOCK * WPT >= 1024)>(c, wave_tot, total);
-        const uint2 off = tile_off[tile];
-        emit_rounds<WPT, TW, CAP, LFIX == 20, false>(sh, list, exp_tab, mp, mm, ex, (uint32_t)total, (uint32_t)(total >> 32), l,
-                                  (uint32_t)((uint64_t)tile * TW * 64), off.x, off.y, out, ChainArgs{});
-        __syncthreads();  // everyone is done with sh / list / wave_tot before the next tile lands
-    }
-}
-
 // ------------------------------------------------------------ seam 2 kernel
 // rs1_score on rows of 30 raw bytes: compare with 'A','T','C','G' exactly as
 // CROPSR.py:300-309 does; no case folding here (the caller did it, :458).
@@ -942,62 +865,41 @@ __global__ __launch_bounds__(BLOCK) void pack_kernel(const uint8_t *__restrict__
 }
 
 // ------------------------------------------------------------ launch wrappers
-// tile_first (even) .. tile_first + tile_count: the slice of tiles this launch covers
 hipError_t launch_count(hipStream_t s, const Planes &pl, uint64_t n_words_padded, int l, uint2 *tile_cnt,
-                        uint32_t tile_first, uint32_t tile_count)
+                        uint32_t n_tiles)
 {
-    if (tile_count == 0) return hipSuccess;
+    if (n_tiles == 0) return hipSuccess;
     constexpr uint32_t TPB = (TILE_WORDS > 512 ? TILE_WORDS : 512) / TILE_WORDS;  // emit tiles per count workgroup
-    const dim3 grid((tile_count + TPB - 1) / TPB);
+    const dim3 grid((n_tiles + TPB - 1) / TPB);
     if (l == 20)
-        hipLaunchKernelGGL(count_kernel<20>, grid, dim3(BLOCK), 0, s, pl, n_words_padded, l, tile_cnt, tile_first / TPB);
+        hipLaunchKernelGGL(count_kernel<20>, grid, dim3(BLOCK), 0, s, pl, n_words_padded, l, tile_cnt);
     else
-        hipLaunchKernelGGL(count_kernel<0>, grid, dim3(BLOCK), 0, s, pl, n_words_padded, l, tile_cnt, tile_first / TPB);
+        hipLaunchKernelGGL(count_kernel<0>, grid, dim3(BLOCK), 0, s, pl, n_words_padded, l, tile_cnt);
     return hipGetLastError();
 }
 
-// scan chunks (8192 tiles each) chunk_first .. chunk_first + chunk_count; the counts of all earlier
-// tiles must already be in tile_cnt
-hipError_t launch_tile_scan(hipStream_t s, const uint2 *tile_cnt, uint32_t n_tiles, uint2 *tile_off,
-                            uint64_t *totals, uint32_t chunk_first, uint32_t chunk_count)
+// one workgroup per chunk of SCAN_CHUNK_TILES tiles
+hipError_t launch_tile_scan(hipStream_t s, const uint2 *tile_cnt, uint32_t n_tiles, uint2 *tile_off, uint64_t *totals)
 {
-    if (chunk_count == 0) return hipSuccess;
-    hipLaunchKernelGGL(tile_scan_kernel, dim3(chunk_count), dim3(1024), 0, s, tile_cnt, n_tiles, tile_off, totals,
-                       chunk_first);
+    if (n_tiles == 0) return hipSuccess;
+    const uint32_t n_chunks = (n_tiles + SCAN_CHUNK_TILES - 1) / SCAN_CHUNK_TILES;
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(n_chunks), dim3(1024), 0, s, tile_cnt, n_tiles, tile_off, totals);
     return hipGetLastError();
 }
 
 hipError_t launch_emit(hipStream_t s, const Planes &pl, uint64_t n_words_padded, int l, const uint2 *tile_off,
-                       const HitTables &out, int persistent_blocks, uint32_t tile_first, uint32_t tile_count)
+                       const HitTables &out)
 {
     constexpr int TW = EMIT_BLOCK * TILE_WPT;
     const uint32_t n_tiles = (uint32_t)(n_words_padded / TW);
-    if (tile_count == 0) return hipSuccess;
-    if (persistent_blocks > 0 && tile_first == 0 && tile_count == n_tiles) {
-        const uint32_t grid = n_tiles < (uint32_t)persistent_blocks ? n_tiles : (uint32_t)persistent_blocks;
-        if (l == 20)
-            hipLaunchKernelGGL((emit_stream_kernel<TILE_WPT, 20>), dim3(grid), dim3(EMIT_BLOCK), 0, s, pl, n_words_padded,
-                               n_tiles, l, tile_off, out);
-        else
-            hipLaunchKernelGGL((emit_stream_kernel<TILE_WPT, 0>), dim3(grid), dim3(EMIT_BLOCK), 0, s, pl, n_words_padded,
-                               n_tiles, l, tile_off, out);
-    } else if (l == 20) {
-        hipLaunchKernelGGL((emit_kernel<TILE_WPT, false, 20>), dim3(tile_count), dim3(EMIT_BLOCK), 0, s, pl, n_words_padded,
-                           l, tile_off, (uint64_t *)nullptr, (uint64_t *)nullptr, out, tile_first);
-    } else {
-        hipLaunchKernelGGL((emit_kernel<TILE_WPT, false, 0>), dim3(tile_count), dim3(EMIT_BLOCK), 0, s, pl, n_words_padded,
-                           l, tile_off, (uint64_t *)nullptr, (uint64_t *)nullptr, out, tile_first);
-    }
+    if (n_tiles == 0) return hipSuccess;
+    if (l == 20)
+        hipLaunchKernelGGL((emit_kernel<TILE_WPT, false, 20>), dim3(n_tiles), dim3(EMIT_BLOCK), 0, s, pl, n_words_padded,
+                           l, tile_off, (uint64_t *)nullptr, (uint64_t *)nullptr, out);
+    else
+        hipLaunchKernelGGL((emit_kernel<TILE_WPT, false, 0>), dim3(n_tiles), dim3(EMIT_BLOCK), 0, s, pl, n_words_padded,
+                           l, tile_off, (uint64_t *)nullptr, (uint64_t *)nullptr, out);
     return hipGetLastError();
-}
-
-// Workgroups of the persistent emit kernel that are resident on one CU.
-int emit_stream_blocks_per_cu()
-{
-    int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, emit_stream_kernel<TILE_WPT, 20>, EMIT_BLOCK, 0) != hipSuccess || n < 1)
-        n = 4;
-    return n;
 }
 
 size_t chain_bytes(uint32_t n_tiles) { return (CHAIN_HEADER_WORDS + (size_t)n_tiles) * sizeof(uint64_t); }
@@ -1009,10 +911,10 @@ hipError_t launch_emit_chained(hipStream_t s, const Planes &pl, uint64_t n_words
     const uint32_t n_tiles = (uint32_t)(n_words_padded / TW);
     if (l == 20)
         hipLaunchKernelGGL((emit_kernel<TILE_WPT, true, 20>), dim3(n_tiles), dim3(EMIT_BLOCK), 0, s, pl, n_words_padded,
-                           l, (const uint2 *)nullptr, chain, chain_next, out, 0u);
+                           l, (const uint2 *)nullptr, chain, chain_next, out);
     else
         hipLaunchKernelGGL((emit_kernel<TILE_WPT, true, 0>), dim3(n_tiles), dim3(EMIT_BLOCK), 0, s, pl, n_words_padded,
-                           l, (const uint2 *)nullptr, chain, chain_next, out, 0u);
+                           l, (const uint2 *)nullptr, chain, chain_next, out);
     return hipGetLastError();
 }
 

@@ -237,19 +237,12 @@ class Engine:
             score[base:base + 2] = self.score_30mers(sequences[base:base + 2], nat.ORDER_TAIL2)[1]
         return score
 
-    def configure(self, two_pass=None, persistent_emit=None, slices=None):
+    def configure(self, two_pass=None):
         """two_pass=False (the default): one launch per scan, table offsets from the chained
-        scan inside the emit kernel; True: the count / tile-scan / emit launch sequence;
-        persistent_emit=0: one workgroup per tile instead of the pipelined persistent
-        emit kernel (1 = default sizing, n > 1 = that many workgroups).  Same results
-        either way; the options exist for cross-checks and A/B timing."""
+        scan inside the emit kernel; True: the count / tile-scan / emit launch sequence.
+        Same results either way (every GPU parity test runs in both modes)."""
         if two_pass is not None:
             nat.check(nat.lib().crp_configure(self._ctx, nat.OPT_TWO_PASS, int(bool(two_pass))), "crp_configure")
-        if persistent_emit is not None:
-            nat.check(nat.lib().crp_configure(self._ctx, nat.OPT_PERSISTENT_EMIT, int(persistent_emit)),
-                      "crp_configure")
-        if slices is not None:  # count/scan of slice k+1 overlap the emit of slice k on a second stream
-            nat.check(nat.lib().crp_configure(self._ctx, nat.OPT_SLICES, int(slices)), "crp_configure")
 
     # ---- measurement
     def profile(self, on=2):

@@ -200,17 +200,6 @@ int crp_fasta_table(const uint8_t *data, uint64_t n, uint8_t *out_text, uint64_t
  * look-back ever time out, the scan is repeated with the three-launch sequence and the
  * context stays in that mode. */
 #define CRP_OPT_TWO_PASS 1
-/* CRP_OPT_PERSISTENT_EMIT (default 0 = one workgroup per tile): with 1 the emit+score
- * pass runs as a persistent, software-pipelined kernel (one grid that fills the
- * chip, next tile prefetched while the current one is scored); a value > 1 sets the
- * number of workgroups explicitly.  Results are identical; the per-tile form
- * balances the uneven hit counts of tiles better and measured faster. */
-#define CRP_OPT_PERSISTENT_EMIT 2
-/* CRP_OPT_SLICES (1..8, default 1): cut the tile range into that many slices and run
- * count + scan of slice k+1 on a second HIP stream while slice k is emitted (the
- * count pass is HBM-bound, the emit pass VALU-bound).  Results are identical; measured
- * slower than 1 on MI355X (the emit pass already fills the issue slots), kept for A/B. */
-#define CRP_OPT_SLICES 3
 int crp_configure(crp_ctx *ctx, int option, int64_t value);
 
 /* ---- measurement --------------------------------------------------------- */
