@@ -23,18 +23,11 @@ __device__ const uint64_t CRP_EXP_TAB[256] = {
 #include "exp_table.inc"
 };
 
-// Pre-scaled weights in evaluation order.  As literals they cost two s_mov_b32 per
-// term on the CU's shared scalar ALU.  Measured alternatives, both SLOWER for the emit
-// kernel (0.64 ms with literals): wide scalar loads from constant memory 0.79 ms
-// (CRP_WEIGHTS_IN_CONSTANT_MEMORY; s_waitcnt lgkmcnt(0) also drains the LDS reads),
-// uniform ds_read_b64 from LDS 1.11 ms.  Literals are the default.
-#if defined(CRP_WEIGHTS_IN_CONSTANT_MEMORY)
-__constant__ double CRP_WS_MEM[CRP_WS_COUNT] = CRP_WS_TABLE;
-#define CRP_WS(i) (CRP_WS_MEM[i])
-#else
+// Pre-scaled weights in evaluation order, as literals: two s_mov_b32 per term on the scalar ALU,
+// hidden under the VALU work.  (Wide scalar loads from constant memory and uniform ds_read_b64
+// from LDS were both measured slower)
 static constexpr double CRP_WS_LIT[CRP_WS_COUNT] = CRP_WS_TABLE;
 #define CRP_WS(i) (CRP_WS_LIT[i])
-#endif
 
 #define CRP_TERM(acc, copy, bit, wc) \
     acc = __builtin_fma(__hiloint2double((int)((copy) & (1u << (bit))), 0), (wc), acc);
