@@ -13,7 +13,7 @@ constexpr int BLOCK = 256;     // threads per workgroup (4 wavefronts of 64)
 #define CRP_TILE_WPT 2
 #endif
 #ifndef CRP_LIST_CAP_PER_WPT
-#define CRP_LIST_CAP_PER_WPT 2048  // LDS hit-list entries per round and per word-per-thread
+#define CRP_LIST_CAP_PER_WPT 1024  // LDS hit-list entries per round and per word-per-thread
 #endif
 #ifndef CRP_EMIT_BLOCK
 #define CRP_EMIT_BLOCK 256

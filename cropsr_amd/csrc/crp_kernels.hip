@@ -497,7 +497,7 @@ __device__ __forceinline__ void chain_resolve(const ChainArgs &ch, uint64_t (&lb
 }
 
 template <int WPT, int TW, int CAP, bool PAM, bool CHAINED>
-__device__ __forceinline__ void emit_rounds(uint64_t (*sh)[TW + 2], uint16_t *list, const uint64_t *exp_tab,
+__device__ __forceinline__ void emit_rounds(uint64_t (*sh)[TW + 2], uint16_t *list, const uint64_t *exp_tab, const double *score_tab,
                                             const uint64_t (&mp)[WPT], const uint64_t (&mm)[WPT], uint64_t ex,
                                             uint32_t n_plus, uint32_t n_minus, int l, uint32_t tile_pos,
                                             uint64_t off_plus, uint64_t off_minus, const HitTables &out,
@@ -525,6 +525,7 @@ __global__ __launch_bounds__(EMIT_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8
     constexpr int CAP = CRP_LIST_CAP_PER_WPT * WPT;  // list entries per round; typical tiles need one round
     __shared__ uint64_t sh[4][TW + 2];
     __shared__ uint64_t exp_tab[256];
+    __shared__ double score_tab[CRP_SCORE_TAB_N];
     __shared__ uint64_t wave_tot[EMIT_BLOCK / 64];
     __shared__ uint64_t s_excl;
     __shared__ uint32_t s_flag, s_tile;
@@ -549,6 +550,8 @@ __global__ __launch_bounds__(EMIT_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8
     const uint64_t t0 = (uint64_t)tile * TW;
     stage_tile<TW>(pl, t0, n_words_padded, sh);
     for (int k = tid; k < 256; k += EMIT_BLOCK) exp_tab[k] = CRP_EXP_TAB[k];
+    if (LFIX == 20)
+        for (int k = tid; k < CRP_SCORE_TAB_N; k += EMIT_BLOCK) score_tab[k] = CRP_SCORE_TAB[k];
     __syncthreads();
 
     uint64_t mp[WPT], mm[WPT];
@@ -587,13 +590,13 @@ __global__ __launch_bounds__(EMIT_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8
         off_minus = off.y;
         if (n_all == 0) return;
     }
-    emit_rounds<WPT, TW, CAP, LFIX == 20, CHAINED>(sh, list, exp_tab, mp, mm, ex, n_plus, n_minus, l, (uint32_t)(t0 * 64),
+    emit_rounds<WPT, TW, CAP, LFIX == 20, CHAINED>(sh, list, exp_tab, score_tab, mp, mm, ex, n_plus, n_minus, l, (uint32_t)(t0 * 64),
                                                    off_plus, off_minus, out, ch);
 }
 
 // Compact the kept hits of one staged tile and score them, CAP list entries per round.
 template <int WPT, int TW, int CAP, bool PAM, bool CHAINED>
-__device__ __forceinline__ void emit_rounds(uint64_t (*sh)[TW + 2], uint16_t *list, const uint64_t *exp_tab,
+__device__ __forceinline__ void emit_rounds(uint64_t (*sh)[TW + 2], uint16_t *list, const uint64_t *exp_tab, const double *score_tab,
                                             const uint64_t (&mp)[WPT], const uint64_t (&mm)[WPT], uint64_t ex,
                                             uint32_t n_plus, uint32_t n_minus, int l, uint32_t tile_pos,
                                             uint64_t off_plus, uint64_t off_minus, const HitTables &out,
@@ -675,7 +678,7 @@ __device__ __forceinline__ void emit_rounds(uint64_t (*sh)[TW + 2], uint16_t *li
 #if defined(CRP_EXPERIMENT_NO_SCORE)
                     hit.score = __hiloint2double((int)(mA ^ mT), (int)(mC ^ mG));
 #else
-                    crp_score_masks<PAM>(mA, mT, mC, mG, exp_tab, hit.pre, hit.score);
+                    crp_score_masks<PAM>(mA, mT, mC, mG, exp_tab, score_tab, hit.pre, hit.score);
 #endif
                 }
             }
@@ -762,7 +765,7 @@ __global__ __launch_bounds__(BLOCK) void score30_kernel(const uint8_t *__restric
             mG |= (uint32_t)(ch == 'G') << p;
         }
         double pre, score;
-        crp_score_masks<false>(mA, mT, mC, mG, exp_tab, pre, score);
+        crp_score_masks<false>(mA, mT, mC, mG, exp_tab, nullptr, pre, score);
         if (pre_out) pre_out[i] = pre;
         score_out[i] = score;
     }

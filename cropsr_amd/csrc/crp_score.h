@@ -29,6 +29,15 @@ __device__ const uint64_t CRP_EXP_TAB[256] = {
 static constexpr double CRP_WS_LIT[CRP_WS_COUNT] = CRP_WS_TABLE;
 #define CRP_WS(i) (CRP_WS_LIT[i])
 
+// Chain-prefix tables of the PAM-variant scorer (gen_score_terms.py, "table form"): the value of a
+// chain after its first k terms, for every pattern of the k gate bits.  Staged into LDS by the
+// emit kernel; `off` is a byte offset inside the chain's table.
+__device__ const double CRP_SCORE_TAB[CRP_SCORE_TAB_N] = CRP_SCORE_TAB_DATA;
+__device__ __forceinline__ double crp_tab_at(const double *tab, uint32_t base_bytes, uint32_t off_bytes)
+{
+    return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(tab) + base_bytes + off_bytes);
+}
+
 #define CRP_TERM(acc, copy, bit, wc) \
     acc = __builtin_fma(__hiloint2double((int)((copy) & (1u << (bit))), 0), (wc), acc);
 // second order: both bases tested in the gate (three-input AND = one v_bitop3_b32)
@@ -84,16 +93,22 @@ __device__ __forceinline__ double crp_recip(double d)
 // PAM = true: the row is a window found by the PAM scan with guide length 20, whose
 // characters 3 and 4 are always 'C' (SURVEY.md A.3); the four terms that test those
 // positions are folded into the chain start values / dropped by the generator.
+// score_tab: LDS copy of CRP_SCORE_TAB (PAM variant only; may be null otherwise).
 template <bool PAM>
 __device__ __forceinline__ void crp_score_masks(uint32_t mA, uint32_t mT, uint32_t mC, uint32_t mG,
-                                                const uint64_t *exp_tab, double &pre, double &score)
+                                                const uint64_t *exp_tab, const double *score_tab, double &pre,
+                                                double &score)
 {
     double fA = PAM ? CRP_PAM_INIT_fA : 0.0, fT = PAM ? CRP_PAM_INIT_fT : 0.0;
     double fC = PAM ? CRP_PAM_INIT_fC : 0.0, fG = PAM ? CRP_PAM_INIT_fG : 0.0;
     double sA = PAM ? CRP_PAM_INIT_sA : 0.0, sT = PAM ? CRP_PAM_INIT_sT : 0.0;
     double sC = PAM ? CRP_PAM_INIT_sC : 0.0, sG = PAM ? CRP_PAM_INIT_sG : 0.0;
     if (PAM) {
+#if defined(CRP_SCORER_NO_TABLES)  // every term a gated FMA (the form the tables were derived from)
         CRP_SCORE_BODY_PAM(mA, mT, mC, mG)
+#else
+        CRP_SCORE_BODY_PAM_TABLES(mA, mT, mC, mG)
+#endif
     } else {
         CRP_SCORE_BODY(mA, mT, mC, mG)
     }

@@ -75,6 +75,122 @@ def scaled(w, bit):
     return v.hex()
 
 
+# ---------------------------------------------------------------------------------------------
+# Table form of the PAM-variant scorer.  The value of an accumulation chain after its first k
+# terms is a function of k gate bits only, so it is looked up instead of summed: the table entry
+# for a bit pattern is init + (the weights of the set bits, added one by one in chain order, each
+# addition rounded to double) -- exactly what the k gated FMAs would have produced.  The k gate
+# bits are gathered into a table index with one multiplication: for the right constant the top k
+# bits of (bits * MAGIC) are different for every one of the 2^k patterns (any one-to-one mapping
+# will do, the table is laid out to match).  Terms past the first k of a chain stay gated FMAs.
+TABLE_BITS = {"fA": 8, "fT": 8, "fG": 7, "fC": 7, "sG": 7, "sC": 7, "sA": 6, "sT": 0}  # sT: 4 terms, 25 positions apart
+
+
+def find_gather(qs, rng_seed):
+    """bits at positions qs (chain order) of a 32-bit word -> (lo, magic, W): the table index of a
+    bit pattern is the top k bits of ((word >> lo) * magic) mod 2^W, one-to-one on all 2^k patterns.
+    W = 24 when the bits span fewer than 24 positions (v_mul_u32_u24, full rate), else 32."""
+    import random
+
+    import numpy as np
+    k = len(qs)
+    lo = min(qs)
+    rel = np.array([q - lo for q in qs], dtype=np.uint64)
+    W = 24 if int(rel.max()) < 24 else 32
+    modmask = np.uint64((1 << W) - 1)
+    rng = random.Random(rng_seed)
+    patterns = np.array([[(s >> i) & 1 for i in range(k)] for s in range(1 << k)], dtype=np.uint64).T
+    batch = 4096
+    for _ in range(2000):
+        magic = np.array([rng.getrandbits(W) for _ in range(batch)], dtype=np.uint64)
+        contrib = (magic[:, None] << rel[None, :]) & modmask
+        idx = ((contrib @ patterns) & modmask) >> np.uint64(W - k)
+        idx.sort(axis=1)
+        ok = (np.diff(idx.astype(np.int64), axis=1) != 0).all(axis=1) & (magic != 0)
+        if ok.any():
+            return lo, int(magic[np.nonzero(ok)[0][0]]), W
+    raise RuntimeError("no gather constant found for bit positions %r" % (qs,))
+
+
+def emit_table_scorer(out, live, init, wtable, emit_copies):
+    import collections
+    chains = collections.OrderedDict()
+    for t in live:
+        chains.setdefault(t[5], []).append(t)
+    lines = []
+    data = []  # table entries (doubles), all chains back to back
+    leftover = []
+    lines.append("const uint32_t nA = (mA) >> 1, nT = (mT) >> 1, nC = (mC) >> 1, nG = (mG) >> 1; (void)nA; (void)nT; (void)nC; (void)nG;")
+    for cname in ("fA", "fT", "fC", "fG", "sA", "sT", "sC", "sG"):
+        terms = chains.get(cname, [])
+        k = min(len(terms), TABLE_BITS[cname])
+        head, tail = terms[:k], terms[k:]
+        leftover.extend(tail)
+        if k == 0:
+            continue  # the chain keeps its start value and is summed by gated FMAs only
+        # where each head term's gate bit sits in the source word
+        if cname[0] == "f":
+            b = cname[1]
+            qs = [t[1] // 4 for t in head]
+            sel = sum(1 << q for q in qs)
+            src = "((m%s) & 0x%xu)" % (b, sel)
+        else:
+            x = cname[1]
+            by_b1 = collections.OrderedDict()
+            for t in head:
+                p, b1 = t[1] // 16, "ATCG"[(t[1] % 16) // 4]
+                by_b1.setdefault(b1, []).append(p)
+            taken, shift_of, qs_of = set(), {}, {}
+            for b1, ps in by_b1.items():  # move a whole part up when one of its positions is taken
+                for sh in range(0, 32):
+                    moved = [p + sh for p in ps]
+                    if max(moved) < 32 and not (set(moved) & taken):
+                        break
+                else:
+                    raise RuntimeError("no room for the %s terms of chain %s" % (b1, cname))
+                shift_of[b1] = sh
+                taken |= set(moved)
+                for p in ps:
+                    qs_of[(p, b1)] = p + sh
+            qs = [qs_of[(t[1] // 16, "ATCG"[(t[1] % 16) // 4])] for t in head]
+            parts = []
+            for b1, ps in by_b1.items():
+                part = "((m%s) & n%s & 0x%xu)" % (b1, x, sum(1 << p for p in ps))
+                parts.append("(%s << %d)" % (part, shift_of[b1]) if shift_of[b1] else part)
+            src = "(" + " | ".join(parts) + ")"
+        lo, magic, W = find_gather(qs, "%s-%d" % (cname, k))
+        # table: entry for every bit pattern, at the index the kernel will compute for it
+        base = len(data)
+        entries = [None] * (1 << k)
+        for pattern in range(1 << k):
+            word = sum(1 << (qs[i] - lo) for i in range(k) if (pattern >> i) & 1)
+            idx = ((word * magic) & ((1 << W) - 1)) >> (W - k)
+            v = init[cname]
+            for i in range(k):
+                if (pattern >> i) & 1:
+                    v = v + head[i][6]  # one rounding per addition, chain order
+            assert entries[idx] is None
+            entries[idx] = v
+        data.extend(entries)
+        word = src if lo == 0 else "(%s >> %d)" % (src, lo)
+        mul = "__umul24(%s, 0x%xu)" % (word, magic) if W == 24 else "(%s * 0x%xu)" % (word, magic)
+        lines.append("%s = crp_tab_at(score_tab, %d, (%s >> %d) & 0x%xu); /* %d terms: %s */"
+                     % (cname, 8 * base, mul, W - k - 3, ((1 << k) - 1) << 3, k,
+                        " ".join(t[2].split("/*")[1].split()[0] for t in head)))
+    body = emit_copies(leftover) + lines
+    for t in leftover:
+        body.append(t[2].replace("@W@", "CRP_WS(%d)" % wtable.index(t[3])))
+    out.append("/* PAM variant with chain-prefix tables: %d of %d terms looked up, %d gated FMAs left */"
+               % (len(live) - len(leftover), len(live), len(leftover)))
+    out.append("#define CRP_SCORE_TAB_N %d" % len(data))
+    out.append("#define CRP_SCORE_TAB_DATA { \\")
+    out.extend("    %s, \\" % float(v).hex() for v in data)
+    out.append("    }")
+    out.append("#define CRP_SCORE_BODY_PAM_TABLES(mA, mT, mC, mG) \\")
+    out.extend("    %s \\" % b for b in body)
+    out.append("    /* end */")
+
+
 def generate(def_path):
     consts, first, second = parse(def_path)
     out = []
@@ -109,9 +225,9 @@ def generate(def_path):
     n_shift = {"a": "<< 19", "b": "<< 8", "c": ">> 3"}  # (m >> 1) moved like the m copy; stray low bit lands below bit 20
     ordered = sorted(terms, key=lambda t: (t[1] // (16 if t[0] else 4), t[0], t[1]))
 
-    def emit_body(macro, keep, table):
+    def emit_copies(live):
+        """shifted mask copies and pair masks the gated terms in `live` read"""
         body = []
-        live = [t for t in ordered if keep(t)]
         need = set()
         for t in live:
             need.update(t[4])
@@ -119,6 +235,11 @@ def generate(def_path):
             body.append("const uint32_t %s_%s = (m%s) %s;" % (name, cp, name[1], (m_shift if name[0] == "m" else n_shift)[cp]))
         for b1, b2, cp in sorted(n for n in need if len(n) == 3):
             body.append("const uint32_t p%s%s_%s = m%s_%s & n%s_%s;" % (b1, b2, cp, b1, cp, b2, cp))
+        return body
+
+    def emit_body(macro, keep, table):
+        live = [t for t in ordered if keep(t)]
+        body = emit_copies(live)
         # interleave first- and second-order terms by position: eight independent chains
         for t in live:
             body.append(t[2].replace("@W@", "CRP_WS(%d)" % table.index(t[3])))
@@ -167,6 +288,7 @@ def generate(def_path):
         elif st == "live":
             seen_live.add(chain)
     emit_body("CRP_SCORE_BODY_PAM", lambda t: settled[id(t)] == "live", table)
+    emit_table_scorer(out, [t for t in ordered if settled[id(t)] == "live"], init, table, emit_copies)
     for c in sorted(init):
         out.append("#define CRP_PAM_INIT_%s %s" % (c, float(init[c]).hex()))
     # the pre-scaled weights in evaluation order
