@@ -7,7 +7,11 @@ namespace crp {
 
 constexpr int BLOCK = 256;     // threads per workgroup (4 wavefronts of 64)
 #ifndef CRP_CHAIN_TICKET
-#define CRP_CHAIN_TICKET 1  // single-pass mode: tile ids from an atomic ticket (start order) instead of blockIdx
+// single-launch mode: 0 = tile id is blockIdx (the hardware dispatches workgroups in index order, so every
+// tile a workgroup waits for has started; costs nothing), 1 = tile ids from an atomic ticket (start order
+// by construction; one more memory round trip per tile, measured +5 % on the kernel).  Either way every
+// wait is bounded and a timed-out scan is repeated with the three-launch sequence (crp_api.cpp).
+#define CRP_CHAIN_TICKET 0
 #endif
 #ifndef CRP_TILE_WPT
 #define CRP_TILE_WPT 2

@@ -390,11 +390,13 @@ __device__ __forceinline__ uint64_t desc_unpack(uint64_t v)
 
 // Decoupled look-back over the tile descriptors (single-pass mode).  A tile publishes its
 // (plus | minus << 32) counts as an AGGREGATE as soon as its block scan is done, and later
-// -- once it knows the sum over all earlier tiles -- as an inclusive PREFIX.  Tiles are
-// numbered in start order (an atomic ticket, CRP_CHAIN_TICKET) so that every tile this one
-// waits for is already running or finished.  Spins are bounded all the same: on timeout
-// *fail is set, every later look-back gives up at once, and the host repeats the scan with
-// the count / scan / emit sequence instead of using the result.
+// -- once it knows the sum over all earlier tiles -- as an inclusive PREFIX.  A tile only
+// ever waits for tiles with a lower number, and those have started before it: workgroups are
+// dispatched in index order (or, with CRP_CHAIN_TICKET, numbered by an atomic ticket in start
+// order).  Spins are bounded all the same: on timeout *fail is set, every later look-back
+// gives up at once, and the host repeats the scan with the count / scan / emit sequence
+// instead of using the result -- a wrong assumption about dispatch order would cost time
+// once, never a wrong table.
 constexpr int CHAIN_HEADER_WORDS = 4;
 constexpr int LB_DEPTH = 2;  // descriptors per lane and round trip: 128 tiles (measured: 1 and 2 equal, 4 and 8 slower)
 
@@ -450,7 +452,7 @@ __device__ __forceinline__ uint64_t lookback_resolve(uint64_t *desc, uint32_t ti
         }
         if (stall) {  // some nearer tile has not published yet: look again
             ++spins;
-            bool give_up = spins > (1u << 20);
+            bool give_up = spins > (1u << 15);  // ~2 us per look, legitimate waits are tens of us
             if ((spins & 63u) == 0)  // someone else already timed out: drain
                 give_up |= __hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
             if (give_up) {
@@ -528,15 +530,17 @@ __global__ __launch_bounds__(EMIT_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8
     __shared__ double score_tab[CRP_SCORE_TAB_N];
     __shared__ uint64_t wave_tot[EMIT_BLOCK / 64];
     __shared__ uint64_t s_excl;
-    __shared__ uint32_t s_flag, s_tile;
+    __shared__ uint32_t s_flag;
+#if CRP_CHAIN_TICKET
+    __shared__ uint32_t s_tile;
+#endif
     __shared__ uint16_t list[CAP];
 
     const int tid = threadIdx.x;
     uint32_t tile = blockIdx.x;
     if (CHAINED) {
 #if CRP_CHAIN_TICKET
-        // tile ids in START order: whatever order the hardware dispatches workgroups in, every
-        // tile a workgroup waits for has started before it
+        // tile ids in START order, whatever order the hardware dispatches workgroups in
         if (tid == 0) {
             s_flag = 0;
             s_tile = atomicAdd(reinterpret_cast<uint32_t *>(chain), 1u);

@@ -194,7 +194,7 @@ int crp_fasta_table(const uint8_t *data, uint64_t n, uint8_t *out_text, uint64_t
 /* ---- options -------------------------------------------------------------- */
 /* CRP_OPT_TWO_PASS (value 0/1, default 0): with 0 crp_scan_score is ONE kernel launch; the
  * table offsets come from a chained scan across workgroups inside it (decoupled look-back
- * over per-tile descriptors, tiles numbered in start order).  With 1 it runs the count /
+ * over per-tile descriptors; every wait is bounded).  With 1 it runs the count /
  * tile-scan / emit+score launch sequence (one more pass over the packed planes).  Results
  * are identical; the single launch is ~10 % faster on MI355X.  Should a
  * look-back ever time out, the scan is repeated with the three-launch sequence and the
