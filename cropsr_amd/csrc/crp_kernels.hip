@@ -433,6 +433,7 @@ __device__ __forceinline__ uint64_t lookback_resolve(uint64_t *desc, uint32_t ti
     while (true) {
         uint64_t contrib = 0;
         bool found = false, stall = false;
+        int64_t missing = 0;  // the nearest tile that has not published yet
 #pragma unroll
         for (int j = 0; j < LB_DEPTH; ++j) {
             const uint64_t st = v[j] >> 62;
@@ -444,22 +445,27 @@ __device__ __forceinline__ uint64_t lookback_resolve(uint64_t *desc, uint32_t ti
             if (!found && !stall) {
                 if (not_ready & need) {
                     stall = true;
+                    missing = base - 64 * j - __builtin_ctzll(not_ready & need);
                 } else {
                     if (lane <= p) contrib += desc_unpack(v[j] & DESC_VALUE);
                     found = p < 64;
                 }
             }
         }
-        if (stall) {  // some nearer tile has not published yet: look again
-            ++spins;
-            bool give_up = spins > (1u << 15);  // ~2 us per look, legitimate waits are tens of us
-            if ((spins & 63u) == 0)  // someone else already timed out: drain
-                give_up |= __hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-            if (give_up) {
-                if (lane == 0) atomicExch(fail, 1u);
-                return 0;
+        if (stall) {
+            // Wait on that ONE descriptor (a single 8-byte load per look instead of the whole
+            // window and its analysis), then read the window again.
+            while ((__hip_atomic_load(&desc[missing], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 62) == 0) {
+                ++spins;
+                bool give_up = spins > (1u << 15);  // ~2 us per look, legitimate waits are tens of us
+                if ((spins & 63u) == 0)  // someone else already timed out: drain
+                    give_up |= __hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+                if (give_up) {
+                    if (lane == 0) atomicExch(fail, 1u);
+                    return 0;
+                }
+                __builtin_amdgcn_s_sleep(8);
             }
-            __builtin_amdgcn_s_sleep(4);
         } else {
 #pragma unroll
             for (int d = 32; d > 0; d >>= 1) contrib += __shfl_xor(contrib, d, 64);
