@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -45,6 +46,7 @@ struct crp_ctx {
     uint64_t d_rows_cap = 0;
     bool two_pass = false;  // CRP_OPT_TWO_PASS
     uint64_t chain_timeouts = 0;  // single-pass scans that fell back to the three-launch sequence
+    uint32_t mute_tile = 0xffffffffu;  // test hook (environment CRP_TEST_MUTE_TILE): see crp_kernels.h
     // measurement
     int profiling = 0;  // 0 off, 1 emit kernel only, 2 all kernels
     hipEvent_t ev[6] = {};  // profiling: start/stop pair per kernel kind
@@ -131,6 +133,7 @@ int crp_init(int device_id, crp_ctx **out)
             crp_destroy(ctx);
             return CRP_ERR_HIP;
         }
+    if (const char *e = std::getenv("CRP_TEST_MUTE_TILE")) ctx->mute_tile = (uint32_t)std::strtoul(e, nullptr, 10);
     *out = ctx;
     return CRP_OK;
 }
@@ -490,7 +493,7 @@ static int scan_single_pass(crp_arena *a, const crp::Planes &pl, uint64_t eff_wo
         const crp::HitTables out = table_args(a, want_pre);
         uint64_t *cur = a->d_chain[a->chain_cur], *next = a->d_chain[a->chain_cur ^ 1];
         prof_begin(ctx, 2);
-        CRP_HIP(ctx, crp::launch_emit_chained(ctx->stream, pl, eff_words, guide_len, cur, next, out));
+        CRP_HIP(ctx, crp::launch_emit_chained(ctx->stream, pl, eff_words, guide_len, cur, next, out, ctx->mute_tile));
         prof_end(ctx, 2);
         // header: ticket | fail << 32, total '+', total '-'
         CRP_HIP(ctx, hipMemcpyAsync(a->h_totals, cur, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -533,6 +536,8 @@ int crp_scan_score(crp_arena *a, int guide_len, int want_pre, uint64_t *n_plus, 
         if (chain_failed) {  // never seen; results stay right either way
             ctx->two_pass = true;
             ctx->chain_timeouts++;
+            ctx->last_error = "single-launch scan: a chained look-back timed out; the scan was repeated with the "
+                              "count / scan / emit sequence, which this context uses from now on";
             rc = scan_two_pass(a, pl, eff_words, guide_len, want_pre, n);
         }
     }

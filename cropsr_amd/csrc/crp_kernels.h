@@ -53,8 +53,9 @@ hipError_t launch_emit(hipStream_t s, const Planes &pl, uint64_t n_words_padded,
 // must be all zero, the kernel leaves `chain_next` all zero; on return chain[0] = ticket | fail << 32,
 // chain[1], chain[2] = the '+' and '-' table totals
 size_t chain_bytes(uint32_t n_tiles);
+// mute_tile: 0xffffffff, or (tests) the index of a tile that withholds its counts so that the look-back times out
 hipError_t launch_emit_chained(hipStream_t s, const Planes &pl, uint64_t n_words_padded, int l, uint64_t *chain,
-                               uint64_t *chain_next, const HitTables &out);
+                               uint64_t *chain_next, const HitTables &out, uint32_t mute_tile);
 hipError_t launch_score30(hipStream_t s, const uint8_t *rows, uint64_t n, int order, double *pre, double *score);
 hipError_t launch_pack(hipStream_t s, const uint8_t *text, uint64_t len, uint64_t n_words, uint64_t *hi,
                        uint64_t *lo, uint64_t *up, uint64_t *ac);

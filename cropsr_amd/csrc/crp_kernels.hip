@@ -423,7 +423,7 @@ __device__ __forceinline__ void lookback_load(const uint64_t *desc, int64_t base
 // cost no wait here).  Returns the exclusive prefix in every lane and publishes the
 // inclusive one.
 __device__ __forceinline__ uint64_t lookback_resolve(uint64_t *desc, uint32_t tile, uint64_t total,
-                                                     uint64_t (&v)[LB_DEPTH], uint32_t *fail)
+                                                     uint64_t (&v)[LB_DEPTH], uint32_t *fail, bool muted)
 {
     const int lane = threadIdx.x & 63;
     if (tile == 0) return 0;
@@ -458,7 +458,7 @@ __device__ __forceinline__ uint64_t lookback_resolve(uint64_t *desc, uint32_t ti
             while ((__hip_atomic_load(&desc[missing], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 62) == 0) {
                 ++spins;
                 bool give_up = spins > (1u << 15);  // ~2 us per look, legitimate waits are tens of us
-                if ((spins & 63u) == 0)  // someone else already timed out: drain
+                if ((spins & 63u) == 1)  // someone else already timed out: drain
                     give_up |= __hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
                 if (give_up) {
                     if (lane == 0) atomicExch(fail, 1u);
@@ -475,8 +475,8 @@ __device__ __forceinline__ uint64_t lookback_resolve(uint64_t *desc, uint32_t ti
         }
         lookback_load(desc, base, v);
     }
-    if (lane == 0) __hip_atomic_store(&desc[tile], DESC_PREFIX | desc_pack(excl + total), __ATOMIC_RELAXED,
-                                      __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0 && !muted)
+        __hip_atomic_store(&desc[tile], DESC_PREFIX | desc_pack(excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return excl;
 }
 
@@ -489,11 +489,12 @@ struct ChainArgs {
     uint32_t *s_flag;   // LDS: s_excl is valid
     uint32_t tile, n_tiles;
     uint64_t total;     // this tile's (plus | minus << 32)
+    bool muted;         // test hook: this tile publishes nothing
 };
 
 __device__ __forceinline__ void chain_resolve(const ChainArgs &ch, uint64_t (&lb)[LB_DEPTH])
 {
-    const uint64_t e = lookback_resolve(ch.desc, ch.tile, ch.total, lb, ch.fail);
+    const uint64_t e = lookback_resolve(ch.desc, ch.tile, ch.total, lb, ch.fail, ch.muted);
     if ((threadIdx.x & 63) == 0) {
         *ch.s_excl = e;
         if (ch.tile == ch.n_tiles - 1) {
@@ -526,7 +527,8 @@ __device__ __forceinline__ void emit_rounds(uint64_t (*sh)[TW + 2], uint16_t *li
 template <int WPT, bool CHAINED, int LFIX>
 __global__ __launch_bounds__(EMIT_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8))) void emit_kernel(Planes pl, uint64_t n_words_padded, int l_arg,
                                                       const uint2 *__restrict__ tile_off, uint64_t *chain,
-                                                      uint64_t *__restrict__ chain_next, HitTables out)
+                                                      uint64_t *__restrict__ chain_next, HitTables out,
+                                                      uint32_t mute_tile)
 {
     const int l = LFIX > 0 ? LFIX : l_arg;
     constexpr int TW = EMIT_BLOCK * WPT;
@@ -577,9 +579,10 @@ __global__ __launch_bounds__(EMIT_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8
     ChainArgs ch{};
     if (CHAINED) {
         ch = ChainArgs{chain + CHAIN_HEADER_WORDS, reinterpret_cast<uint32_t *>(chain) + 1, chain + 1, &s_excl, &s_flag,
-                       tile, gridDim.x, total};
+                       tile, gridDim.x, total, tile == mute_tile};
         if (tid == 0) {
-            lookback_publish(ch.desc, tile, total);
+            // mute_tile (normally none): a tile that never publishes, to exercise the time-out path
+            if (tile != mute_tile) lookback_publish(ch.desc, tile, total);
             // leave the OTHER descriptor buffer zeroed for the next launch (no memset between scans)
             chain_next[CHAIN_HEADER_WORDS + tile] = 0;
             if (tile == 0) chain_next[0] = chain_next[1] = chain_next[2] = chain_next[3] = 0;
@@ -908,26 +911,26 @@ hipError_t launch_emit(hipStream_t s, const Planes &pl, uint64_t n_words_padded,
     if (n_tiles == 0) return hipSuccess;
     if (l == 20)
         hipLaunchKernelGGL((emit_kernel<TILE_WPT, false, 20>), dim3(n_tiles), dim3(EMIT_BLOCK), 0, s, pl, n_words_padded,
-                           l, tile_off, (uint64_t *)nullptr, (uint64_t *)nullptr, out);
+                           l, tile_off, (uint64_t *)nullptr, (uint64_t *)nullptr, out, 0xffffffffu);
     else
         hipLaunchKernelGGL((emit_kernel<TILE_WPT, false, 0>), dim3(n_tiles), dim3(EMIT_BLOCK), 0, s, pl, n_words_padded,
-                           l, tile_off, (uint64_t *)nullptr, (uint64_t *)nullptr, out);
+                           l, tile_off, (uint64_t *)nullptr, (uint64_t *)nullptr, out, 0xffffffffu);
     return hipGetLastError();
 }
 
 size_t chain_bytes(uint32_t n_tiles) { return (CHAIN_HEADER_WORDS + (size_t)n_tiles) * sizeof(uint64_t); }
 
 hipError_t launch_emit_chained(hipStream_t s, const Planes &pl, uint64_t n_words_padded, int l, uint64_t *chain,
-                               uint64_t *chain_next, const HitTables &out)
+                               uint64_t *chain_next, const HitTables &out, uint32_t mute_tile)
 {
     constexpr int TW = EMIT_BLOCK * TILE_WPT;
     const uint32_t n_tiles = (uint32_t)(n_words_padded / TW);
     if (l == 20)
         hipLaunchKernelGGL((emit_kernel<TILE_WPT, true, 20>), dim3(n_tiles), dim3(EMIT_BLOCK), 0, s, pl, n_words_padded,
-                           l, (const uint2 *)nullptr, chain, chain_next, out);
+                           l, (const uint2 *)nullptr, chain, chain_next, out, mute_tile);
     else
         hipLaunchKernelGGL((emit_kernel<TILE_WPT, true, 0>), dim3(n_tiles), dim3(EMIT_BLOCK), 0, s, pl, n_words_padded,
-                           l, (const uint2 *)nullptr, chain, chain_next, out);
+                           l, (const uint2 *)nullptr, chain, chain_next, out, mute_tile);
     return hipGetLastError();
 }
 

@@ -560,3 +560,31 @@ def test_randomised_arenas_vs_oracle(engine, oracle):
         l = 20 if rng.random() < 0.7 else int(rng.integers(1, 51))
         total_hits += check_contigs(engine, oracle, contigs, l, "device" if trial % 2 else "host")
     assert total_hits > 50000
+
+
+def test_chain_timeout_falls_back_to_three_launches(oracle, monkeypatch):
+    """The safety net of the single-launch mode: a tile that never publishes its counts (test hook
+    CRP_TEST_MUTE_TILE) makes every later look-back time out; the scan must come back with the
+    RIGHT tables all the same (repeated with count / scan / emit), say so in crp_last_error, and
+    the context must stay in three-launch mode."""
+    from cropsr_amd import Engine
+    from cropsr_amd import _native as nat
+    monkeypatch.setenv("CRP_TEST_MUTE_TILE", "3")
+    eng = Engine(0)
+    monkeypatch.delenv("CRP_TEST_MUTE_TILE")
+    rng = np.random.default_rng(101)
+    contigs = [rng.choice(np.frombuffer(b"ACGTacgtN", dtype=np.uint8), n).tobytes() for n in (400000, 1234, 250000)]
+    arena = eng.arena(contigs)
+    assert arena.stats()["n_words"] > 8 * 512  # more tiles than the muted one
+    got = arena.scan_score(20, want_pre=True)
+    for k, c in enumerate(contigs):
+        assert_hits_equal(got.contig(k), oracle.scan_score(c, 20), ctx=("fallback", k))
+    assert b"timed out" in nat.lib().crp_last_error(eng._ctx)
+    eng.profile(2)
+    eng.profile_read(reset=True)
+    again = arena.scan_score(20, want_pre=True)
+    prof = eng.profile_read(reset=True)
+    assert prof["count"]["launches"] == 1 and prof["tile_scan"]["launches"] == 1  # three launches now
+    assert (bits(again.score_plus) == bits(got.score_plus)).all()
+    arena.close()
+    eng.close()
