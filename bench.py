@@ -102,7 +102,13 @@ def main():
     if world > 1:
         import torch.distributed as dist
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            # a collective that cannot complete must end in an exception, not in a hang or an abort:
+            # the bench line is printed either way (the final gatherv is wrapped in try/except)
+            import datetime
+            os.environ.setdefault("TORCH_NCCL_BLOCKING_WAIT", "1")
+            os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0")
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank),
+                                    timeout=datetime.timedelta(seconds=180))
         else:
             dist.init_process_group("gloo")
 
@@ -184,6 +190,18 @@ def main():
     prof["count"], prof["tile_scan"] = side["count"], side["tile_scan"]
     eng.profile(0)
 
+    tot = torch.tensor([dt, float(scored), float(my_bases), float(n_plus + n_minus)], dtype=torch.float64,
+                       device="cuda")
+    if dist is not None:
+        mx = tot[:1].clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = tot[1:].clone()
+        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        dt = float(mx.item())
+        scored_all, bases_all, hits_all = [float(x) for x in sm.tolist()]
+    else:
+        scored_all, bases_all, hits_all = float(scored), float(my_bases), float(n_plus + n_minus)
+
     # the final exchange, once, timed on its own (barrier + sync on both sides, max over ranks)
     gather_info = None
     if gather is not None and not args.gather_every_step:
@@ -197,18 +215,6 @@ def main():
             gather_info = {"s": tg}  # rank 0 finishes last: it waits for every receive
         except Exception as e:  # keep the bench line even if the exchange fails on this node
             gather_info = {"error": repr(e)[:300]}
-
-    tot = torch.tensor([dt, float(scored), float(my_bases), float(n_plus + n_minus)], dtype=torch.float64,
-                       device="cuda")
-    if dist is not None:
-        mx = tot[:1].clone()
-        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-        sm = tot[1:].clone()
-        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
-        dt = float(mx.item())
-        scored_all, bases_all, hits_all = [float(x) for x in sm.tolist()]
-    else:
-        scored_all, bases_all, hits_all = float(scored), float(my_bases), float(n_plus + n_minus)
 
     if rank == 0:
         info = eng.device_info()
@@ -268,6 +274,9 @@ def main():
     arena.close()
     eng.close()
     if dist is not None:
+        if gather_info is not None and "error" in gather_info:
+            sys.stdout.flush()
+            os._exit(0)  # the process group is in an unknown state after a failed exchange: no collective teardown
         dist.destroy_process_group()
 
 
