@@ -264,3 +264,71 @@ def test_cli_error_behaviour_of_the_reference(oracle, tmp_path, monkeypatch):
     # argparse trips over its own usage formatter while reporting that (AssertionError instead of exit 2)
     with pytest.raises((SystemExit, AssertionError)):
         cli.build_parser().parse_args(["-g", gff, "--cas9"])
+
+
+def test_generated_scorer_sources_are_current():
+    """score_terms.inc / dense_weights.inc / exp_table.inc in the tree are what gen_score_terms.py
+    generates from doench_weights.def today (deterministic generator, gather constants included)."""
+    import importlib.util
+    csrc = os.path.join(ROOT, "cropsr_amd", "csrc")
+    spec = importlib.util.spec_from_file_location("gen_score_terms", os.path.join(csrc, "gen_score_terms.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    text, _, _ = gen.generate(os.path.join(csrc, "doench_weights.def"))
+    with open(os.path.join(csrc, "score_terms.inc")) as f:
+        assert f.read() == text
+
+
+def test_score_tables_equal_sequential_sums():
+    """Every entry of the chain-prefix tables (crp_score.h, CRP_SCORE_TAB_DATA) is the chain's start
+    value plus the weights of its set bits added in chain order with one rounding each, found at
+    the index the kernel computes; checked by re-deriving index and value from the emitted macro."""
+    import re
+    csrc = os.path.join(ROOT, "cropsr_amd", "csrc")
+    text = open(os.path.join(csrc, "score_terms.inc")).read()
+    data = [float.fromhex(x) for x in re.search(r"#define CRP_SCORE_TAB_DATA \{ \\\n(.*?)\n    \}", text, re.S).group(1)
+            .replace("\\", "").replace(",", " ").split()]
+    assert len(data) == int(re.search(r"#define CRP_SCORE_TAB_N (\d+)", text).group(1))
+    init = {m.group(1): float.fromhex(m.group(2)) for m in re.finditer(r"#define CRP_PAM_INIT_(\w\w) (\S+)", text)}
+    weights = {}
+    for line in open(os.path.join(csrc, "doench_weights.def")):
+        t = line.split("#", 1)[0].split()
+        if t and t[0] == "FIRST":
+            weights["%s%02d" % (t[1], int(t[2]))] = float(t[3])
+        elif t and t[0] == "SECOND":
+            weights["%s%s%02d" % (t[1], t[2], int(t[3]))] = float(t[4])
+    body = text[text.index("#define CRP_SCORE_BODY_PAM_TABLES"):]
+    looked_up = 0
+    for m in re.finditer(r"(\w\w) = crp_tab_at\(score_tab, (\d+), \((.*?) >> (\d+)\) & 0x([0-9a-f]+)u\); /\* (\d+) terms: (.*?) \*/", body):
+        chain, base, mul, sh, msk, k, names = m.group(1), int(m.group(2)), m.group(3), int(m.group(4)), int(m.group(5), 16), int(m.group(6)), m.group(7).split()
+        assert len(names) == k and msk == ((1 << k) - 1) << 3
+        magic = int(re.search(r", 0x([0-9a-f]+)u\)$", mul).group(1), 16)
+        assert mul.startswith("__umul24(")
+        lo = int(re.search(r">> (\d+)\), 0x", mul).group(1)) if re.search(r">> (\d+)\), 0x", mul) else 0
+        # source-word bit of every term: single-base terms sit at their position, pair terms at the position of
+        # their first base (+ the shift of their part)
+        expr = mul[len("__umul24("):mul.rindex(", 0x")]
+        bit = {}
+        if chain[0] == "f":
+            for name in names:
+                bit[name] = int(name[1:]) - 1
+        else:
+            for part in re.finditer(r"\(\(m(\w)\) & n\w & 0x([0-9a-f]+)u\)( << (\d+))?", expr):
+                b1, sel, shift = part.group(1), int(part.group(2), 16), int(part.group(4) or 0)
+                for name in names:
+                    if name[0] == b1 and (sel >> (int(name[2:]) - 1)) & 1:
+                        bit[name] = int(name[2:]) - 1 + shift
+        assert len(bit) == k and len(set(bit.values())) == k
+        seen = set()
+        for pattern in range(1 << k):
+            word = sum(1 << (bit[names[i]] - lo) for i in range(k) if (pattern >> i) & 1)
+            off = (((word * magic) & 0xFFFFFF) >> sh) & msk
+            assert off % 8 == 0 and off not in seen
+            seen.add(off)
+            v = init[chain]
+            for i in range(k):
+                if (pattern >> i) & 1:
+                    v = v + weights[names[i]]
+            assert data[base // 8 + off // 8] == v, (chain, pattern)
+        looked_up += k
+    assert looked_up >= 40
