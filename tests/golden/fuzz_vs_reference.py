@@ -87,12 +87,16 @@ def main():
     bad = 0
     for it in range(a.n):
         fa = random_fasta(rnd)
-        extra = rnd.choice([(), (), (), ("-l", "17"), ("-l", "23"), ("-l", "30")])
+        extra = rnd.choice([(), (), (), ("-l", "17"), ("-l", "23"), ("-l", "30"), ("-v",), ("-v", "-l", "21")])
         try:
             want = mg.run_reference(fa, mg.MINI_GFF, "libm", scratch, extra=extra)
         except RuntimeError as e:
             want = ("EXC", str(e).strip().splitlines()[-1].split(":")[0]), ""
         got = ours(fa, extra, scratch)
+        if "-v" in extra and not isinstance(want[0], tuple) and not isinstance(got[0], tuple):
+            from conftest import normalize_verbose  # paths and the CPU count differ by construction
+            want = (want[0], normalize_verbose(want[1]))
+            got = (got[0], normalize_verbose(got[1]))
         ok = got == want if not isinstance(want[0], tuple) else (isinstance(got[0], tuple) and got[0][1] == want[0][1])
         if not ok:
             bad += 1
