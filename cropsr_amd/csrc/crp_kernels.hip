@@ -34,15 +34,28 @@ namespace crp {
 static constexpr uint64_t ALL = ~0ull;
 
 // ------------------------------------------------------------------ helpers
-// bit k of result = bit (k + d) of the stream (cur, next), 0 < d < 64
+// 32-bit funnel shift: bits [s+31 : s] of the 64-bit value {hi, lo}, 0 <= s < 32 (v_alignbit_b32)
+__device__ __forceinline__ uint32_t funnel(uint32_t hi, uint32_t lo, int s)
+{
+    return __builtin_amdgcn_alignbit(hi, lo, (uint32_t)s);
+}
+__device__ __forceinline__ uint64_t pair64(uint32_t hi, uint32_t lo) { return ((uint64_t)hi << 32) | lo; }
+
+// bit k of result = bit (k + d) of the stream (cur, next), 0 < d < 64.  Written on 32-bit halves:
+// one v_alignbit_b32 per half instead of two 64-bit shifts and an OR.
 __device__ __forceinline__ uint64_t ahead(uint64_t cur, uint64_t next, int d)
 {
-    return (cur >> d) | (next << (64 - d));
+    const uint32_t c0 = (uint32_t)cur, c1 = (uint32_t)(cur >> 32), n0 = (uint32_t)next, n1 = (uint32_t)(next >> 32);
+    if (d < 32) return pair64(funnel(n0, c1, d), funnel(c1, c0, d));
+    return pair64(funnel(n1, n0, d - 32), funnel(n0, c1, d - 32));
 }
 // bit k of result = bit (k - e) of the stream (prev, cur), 0 < e < 64
 __device__ __forceinline__ uint64_t behind(uint64_t prev, uint64_t cur, int e)
 {
-    return (cur << e) | (prev >> (64 - e));
+    const uint32_t p0 = (uint32_t)prev, p1 = (uint32_t)(prev >> 32), c0 = (uint32_t)cur, c1 = (uint32_t)(cur >> 32);
+    if (e == 32) return pair64(c0, p1);
+    if (e < 32) return pair64(funnel(c1, c0, 32 - e), funnel(c0, p1, 32 - e));
+    return pair64(funnel(c0, p1, 64 - e), funnel(p1, p0, 64 - e));
 }
 
 struct WordTriple {
