@@ -353,16 +353,22 @@ def ids_as_bytes(ids_u1):
 _ID_LUT = np.frombuffer(b"ABCDEFGHIJKLMNOPQRSTUVWXYZ0123456789", dtype=np.uint8)
 
 
-def draw_ids(size, generator=None, piece=1 << 20, reverse=False):
+def draw_ids(size, generator=None, piece=1 << 20, reverse=False, first_row=0):
     """(size, 7) uint8 crispr ids of one write pass (CROPSR.py:316-318); with reverse=True the
     same ids last-first (the order the reference consumes them in, CROPSR.py:448-449).
 
     np.random.choice(alphanum, [size, 7]) IS alphanum[np.random.randint(0, 36, [size, 7])]
     (legacy RandomState.choice, uniform, with replacement): same draws and the same global RNG
     state afterwards, also when drawn in pieces of rows (tests/test_format.py) -- so no UCS-4
-    string array and no size x 7 int64 array are ever built.  `generator` (a numpy Generator)
+    string array and no size x 7 int64 array are ever built.  `generator` (a numpy Generator, or
+    an int: seed of the native counter-based generator, which numbers its rows from first_row)
     replaces the global legacy stream when the caller does not need the reference's draws."""
     out = np.empty((size, 7), dtype=np.uint8)
+    if isinstance(generator, int):  # counter-based native generator, seeded with this integer (crp_fill_ids)
+        from . import _native as nat
+        nat.check(nat.lib().crp_fill_ids(out.ctypes.data_as(nat.u8p), size, generator, first_row, default_threads()),
+                  "crp_fill_ids")
+        return out[::-1].copy() if reverse and size else out
     for lo in range(0, size, piece):
         m = min(piece, size - lo)
         if generator is None:
@@ -392,10 +398,12 @@ class IdStream:
 
         def work():
             try:
+                drawn = 0
                 for size in self._sizes:
                     if self._stop:
                         return
-                    self._q.put((size, draw_ids(size, generator, reverse=reverse)))
+                    self._q.put((size, draw_ids(size, generator, reverse=reverse, first_row=drawn)))
+                    drawn += size
             except BaseException as e:  # handed to the consumer
                 self._q.put((None, e))
 
