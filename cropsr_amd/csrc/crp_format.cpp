@@ -393,3 +393,51 @@ extern "C" int crp_fill_ids(uint8_t *ids, uint64_t n_rows, uint64_t seed, uint64
     return CRP_OK;
 }
 
+// The reference's own id draws, natively.  CROPSR.py:316-318 draws crispr ids with
+// np.random.choice(alphanum, [size, 7]) on numpy's global legacy RandomState, which is
+// alphanum[randint(0, 36)] = one masked-rejection draw per character: take the next MT19937
+// output, keep its low 6 bits, retry while that exceeds 35 (numpy random/src/distributions,
+// random_bounded_uint64_fill with use_masked for the legacy generator).  The caller passes the
+// MT19937 state it took from np.random.get_state() and puts the advanced state back, so the
+// global stream continues exactly as if numpy had made the draws.  reverse != 0 stores row r at
+// row n_rows - 1 - r (the order the reference consumes ids in, CROPSR.py:448-449).
+extern "C" int crp_legacy_ids(uint32_t *mt_key, int32_t *mt_pos, uint8_t *ids, uint64_t n_rows, int reverse)
+{
+    if (!mt_key || !mt_pos || (n_rows && !ids) || *mt_pos < 0 || *mt_pos > 624) return CRP_ERR_INVALID;
+    static const char kAlphabet[] = "ABCDEFGHIJKLMNOPQRSTUVWXYZ0123456789";
+    constexpr int N = 624, M = 397;
+    int pos = *mt_pos;
+    auto refill = [&]() {  // the standard MT19937 state transition
+        int k = 0;
+        for (; k < N - M; ++k) {
+            const uint32_t y = (mt_key[k] & 0x80000000u) | (mt_key[k + 1] & 0x7fffffffu);
+            mt_key[k] = mt_key[k + M] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        }
+        for (; k < N - 1; ++k) {
+            const uint32_t y = (mt_key[k] & 0x80000000u) | (mt_key[k + 1] & 0x7fffffffu);
+            mt_key[k] = mt_key[k + (M - N)] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        }
+        const uint32_t y = (mt_key[N - 1] & 0x80000000u) | (mt_key[0] & 0x7fffffffu);
+        mt_key[N - 1] = mt_key[M - 1] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        pos = 0;
+    };
+    for (uint64_t r = 0; r < n_rows; ++r) {
+        uint8_t *o = ids + 7 * (reverse ? n_rows - 1 - r : r);
+        for (int c = 0; c < 7; ++c) {
+            uint32_t v;
+            do {
+                if (pos == N) refill();
+                uint32_t y = mt_key[pos++];
+                y ^= y >> 11;
+                y ^= (y << 7) & 0x9d2c5680u;
+                y ^= (y << 15) & 0xefc60000u;
+                y ^= y >> 18;
+                v = y & 63u;
+            } while (v > 35u);
+            o[c] = (uint8_t)kAlphabet[v];
+        }
+    }
+    *mt_pos = pos;
+    return CRP_OK;
+}
+

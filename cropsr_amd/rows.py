@@ -369,6 +369,17 @@ def draw_ids(size, generator=None, piece=1 << 20, reverse=False, first_row=0):
         nat.check(nat.lib().crp_fill_ids(out.ctypes.data_as(nat.u8p), size, generator, first_row, default_threads()),
                   "crp_fill_ids")
         return out[::-1].copy() if reverse and size else out
+    if generator is None and size:  # the reference's draws, made natively on numpy's own MT19937 state
+        state = np.random.get_state(legacy=True)
+        if state[0] == "MT19937":
+            import ctypes
+            from . import _native as nat
+            key = np.ascontiguousarray(state[1], dtype=np.uint32).copy()
+            pos = ctypes.c_int32(int(state[2]))
+            nat.check(nat.lib().crp_legacy_ids(key.ctypes.data_as(nat.u32p), ctypes.byref(pos), out.ctypes.data_as(nat.u8p),
+                                               size, int(bool(reverse))), "crp_legacy_ids")
+            np.random.set_state(("MT19937", key, pos.value, state[3], state[4]))
+            return out
     for lo in range(0, size, piece):
         m = min(piece, size - lo)
         if generator is None:

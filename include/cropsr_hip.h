@@ -172,6 +172,12 @@ int crp_write_rows(int fd, const uint8_t *contig_text, uint64_t contig_len, cons
                    int guide_len, const uint32_t *pos, const uint8_t *minus, const double *score,
                    const uint8_t *ids, uint64_t n_rows, uint64_t *bytes_written, int n_threads);
 
+/* The reference's own crispr ids (CROPSR.py:316-318: np.random.choice(alphanum, [n_rows, 7]) on
+ * numpy's global legacy generator), drawn natively: mt_key[624] / *mt_pos are the MT19937 state
+ * from np.random.get_state(); on return they hold the state after the draws, for set_state().
+ * Same values, same state afterwards as numpy; reverse != 0 stores the rows last-first. */
+int crp_legacy_ids(uint32_t *mt_key, int32_t *mt_pos, uint8_t *ids, uint64_t n_rows, int reverse);
+
 /* n_rows x 7 bytes of crispr ids from a counter-based generator instead of numpy's global stream
  * (CROPSR.py:316-318 draws them with np.random.choice; same alphabet, same uniform distribution,
  * NOT the same values): row r gets the base-36 digits of a hash of (seed, first_row + r).  For

@@ -246,3 +246,25 @@ def test_native_id_generator():
     stream.close()
     assert (p1 != p2).any() and (rows.draw_ids(1000, generator=777, reverse=True) == p1).all()
     assert (rows.draw_ids(1000, generator=777)[::-1] == p1).all()
+
+
+def test_native_legacy_id_draws_equal_numpy():
+    """crp_legacy_ids continues numpy's global MT19937 stream exactly like
+    np.random.randint(0, 36, [size, 7]) does: same characters, same state afterwards -- from a fresh
+    seed, from the middle of a 624-word block, across block refills, after gaussian draws."""
+    lut = np.frombuffer(b"ABCDEFGHIJKLMNOPQRSTUVWXYZ0123456789", dtype=np.uint8)
+    for seed, warm, size in ((0, 0, 1), (1, 0, 100), (2, 3, 89), (3, 623, 200), (4, 1000, 5000), (20261003, 17, 70000)):
+        np.random.seed(seed)
+        np.random.random(warm)
+        if seed == 4:
+            np.random.normal(size=3)  # leaves a cached gaussian in the legacy state
+        before = np.random.get_state()
+        want = lut[np.random.randint(0, 36, size=[size, 7])]
+        after = np.random.get_state()
+        for reverse in (False, True):
+            np.random.set_state(before)
+            got = rows.draw_ids(size, reverse=reverse)
+            now = np.random.get_state()
+            assert (got == (want[::-1] if reverse else want)).all(), (seed, reverse)
+            assert now[0] == after[0] and (now[1] == after[1]).all() and now[2:] == after[2:]
+        assert np.random.randint(0, 1 << 30) == (np.random.set_state(after), np.random.randint(0, 1 << 30))[1]
