@@ -404,7 +404,7 @@ extern "C" int crp_fill_ids(uint8_t *ids, uint64_t n_rows, uint64_t seed, uint64
 extern "C" int crp_legacy_ids(uint32_t *mt_key, int32_t *mt_pos, uint8_t *ids, uint64_t n_rows, int reverse)
 {
     if (!mt_key || !mt_pos || (n_rows && !ids) || *mt_pos < 0 || *mt_pos > 624) return CRP_ERR_INVALID;
-    static const char kAlphabet[] = "ABCDEFGHIJKLMNOPQRSTUVWXYZ0123456789";
+    static const char kAlphabet[65] = "ABCDEFGHIJKLMNOPQRSTUVWXYZ0123456789????????????????????????????";
     constexpr int N = 624, M = 397;
     int pos = *mt_pos;
     auto refill = [&]() {  // the standard MT19937 state transition
@@ -421,22 +421,40 @@ extern "C" int crp_legacy_ids(uint32_t *mt_key, int32_t *mt_pos, uint8_t *ids, u
         mt_key[N - 1] = mt_key[M - 1] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
         pos = 0;
     };
-    for (uint64_t r = 0; r < n_rows; ++r) {
-        uint8_t *o = ids + 7 * (reverse ? n_rows - 1 - r : r);
-        for (int c = 0; c < 7; ++c) {
-            uint32_t v;
-            do {
-                if (pos == N) refill();
-                uint32_t y = mt_key[pos++];
-                y ^= y >> 11;
-                y ^= (y << 7) & 0x9d2c5680u;
-                y ^= (y << 15) & 0xefc60000u;
-                y ^= y >> 18;
-                v = y & 63u;
-            } while (v > 35u);
-            o[c] = (uint8_t)kAlphabet[v];
+    // Batches without a data-dependent branch: temper up to one state block, keep the outputs that
+    // pass the rejection test by a conditional increment, then place the characters.  A batch never
+    // takes more outputs than characters are still missing, so the stream is left exactly where
+    // numpy would leave it (the output that yields the last character is the last one consumed).
+    const uint64_t need = 7 * n_rows;
+    uint64_t produced = 0;
+    uint8_t stage[N + 8];
+    while (produced < need) {
+        if (pos == N) refill();
+        const uint64_t missing = need - produced;
+        const int take = (uint64_t)(N - pos) < missing ? N - pos : (int)missing;
+        int n = 0;
+        for (int i = 0; i < take; ++i) {
+            uint32_t y = mt_key[pos + i];
+            y ^= y >> 11;
+            y ^= (y << 7) & 0x9d2c5680u;
+            y ^= (y << 15) & 0xefc60000u;
+            y ^= y >> 18;
+            const uint32_t v = y & 63u;
+            stage[n] = (uint8_t)kAlphabet[v & 63u];  // kAlphabet is padded to 64 entries below
+            n += v <= 35u;
         }
+        pos += take;
+        std::memcpy(ids + produced, stage, (size_t)n);
+        produced += (uint64_t)n;
     }
+    if (reverse)  // rows were drawn first-to-last; hand them over last-first
+        for (uint64_t a = 0, b = n_rows; a + 1 < b; ++a) {
+            --b;
+            uint8_t t[7];
+            std::memcpy(t, ids + 7 * a, 7);
+            std::memcpy(ids + 7 * a, ids + 7 * b, 7);
+            std::memcpy(ids + 7 * b, t, 7);
+        }
     *mt_pos = pos;
     return CRP_OK;
 }
