@@ -45,7 +45,6 @@ SIGNATURES = {
     "crp_write_rows": (ctypes.c_int, [ctypes.c_int, u8p, ctypes.c_uint64, u8p, ctypes.c_uint64, ctypes.c_int, u32p, u8p,
                                       f64p, u8p, ctypes.c_uint64, u64p, ctypes.c_int]),
     "crp_legacy_ids": (ctypes.c_int, [u32p, ctypes.POINTER(ctypes.c_int32), u8p, ctypes.c_uint64, ctypes.c_int]),
-    "crp_fill_ids": (ctypes.c_int, [u8p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int]),
     "crp_fasta_table": (ctypes.c_int, [u8p, ctypes.c_uint64, u8p, ctypes.c_uint64, u64p, ctypes.c_uint64, u64p, u64p,
                                        ctypes.POINTER(ctypes.c_int), ctypes.c_int]),
     "crp_configure": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int64]),

@@ -10,7 +10,6 @@ Differences that are NOT observable in the outputs:
   * the 5 s sleep per contig (CROPSR.py:478) is kept only with --reference-sleep.
 """
 import argparse
-import os
 import sys
 import time
 from multiprocessing import cpu_count
@@ -66,9 +65,6 @@ def build_parser():
                      help="NOT reference behaviour: write every contig's rows once instead of re-writing all "
                           "earlier contigs on every pass (the reference never clears Complete_dataset, "
                           "CROPSR.py:407, which makes multi-contig genomes quadratic)")
-    eng.add_argument("--fast-ids", action="store_true",
-                     help="draw crispr_id from a native counter-based generator instead of numpy's global legacy "
-                          "stream (same alphabet and distribution, far faster; not reproducible with --seed)")
     eng.add_argument("--reference-sleep", action="store_true",
                      help="also reproduce the reference's 5 s pause per contig")
     return p
@@ -188,8 +184,7 @@ def run(args, backend=None, out=sys.stdout):
         per_contig = [int(h["pos_plus"].size + h["pos_minus"].size) for h in all_hits]
         import numpy as np
         sizes = per_contig if once else np.cumsum(per_contig).tolist()
-        fast = int.from_bytes(os.urandom(8), "little") if getattr(args, "fast_ids", False) else None  # seed of crp_fill_ids
-        ids = rows.IdStream(sizes, generator=fast, reverse=True)
+        ids = rows.IdStream(sizes, reverse=True)
     for name, s, hits in zip(names, strings, all_hits):
         print("Searching on Chromosome: ", name[:25], file=out)  # CROPSR.py:410-411
         print("With start of sequence: ", bytes(s[:25]).decode("latin-1"), file=out)

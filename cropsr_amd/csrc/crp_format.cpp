@@ -361,38 +361,6 @@ extern "C" int crp_write_rows(int fd, const uint8_t *contig_text, uint64_t conti
     }
 }
 
-// crispr ids without the reference's RNG stream (the opt-in --fast-ids of the CLI): row r of a
-// run gets the 7 base-36 digits of a splitmix64 hash of (seed, first_row + r), so any slice of
-// rows can be produced independently and by several threads.
-extern "C" int crp_fill_ids(uint8_t *ids, uint64_t n_rows, uint64_t seed, uint64_t first_row, int n_threads)
-{
-    if (n_rows && !ids) return CRP_ERR_INVALID;
-    static const char kAlphabet[] = "ABCDEFGHIJKLMNOPQRSTUVWXYZ0123456789";  // CROPSR.py:316
-    constexpr uint64_t kSpace = 78364164096ull;                               // 36^7
-    const int nt = clamp_threads(n_threads, n_rows, 1u << 16);
-    const uint64_t per = (n_rows + nt - 1) / nt;
-    try {
-        run_threads(nt, [&](int t) {
-            const uint64_t r0 = std::min<uint64_t>(n_rows, per * t), r1 = std::min<uint64_t>(n_rows, r0 + per);
-            for (uint64_t r = r0; r < r1; ++r) {
-                uint64_t x = seed + 0x9e3779b97f4a7c15ull * (first_row + r + 1);
-                x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ull;
-                x = (x ^ (x >> 27)) * 0x94d049bb133111ebull;
-                x ^= x >> 31;
-                uint64_t v = (uint64_t)(((unsigned __int128)x * kSpace) >> 64);  // uniform on [0, 36^7)
-                uint8_t *o = ids + 7 * r;
-                for (int k = 6; k >= 0; --k) {
-                    o[k] = (uint8_t)kAlphabet[v % 36];
-                    v /= 36;
-                }
-            }
-        });
-    } catch (...) {
-        return CRP_ERR_NOMEM;
-    }
-    return CRP_OK;
-}
-
 // The reference's own id draws, natively.  CROPSR.py:316-318 draws crispr ids with
 // np.random.choice(alphanum, [size, 7]) on numpy's global legacy RandomState, which is
 // alphanum[randint(0, 36)] = one masked-rejection draw per character: take the next MT19937

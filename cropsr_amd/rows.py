@@ -353,39 +353,32 @@ def ids_as_bytes(ids_u1):
 _ID_LUT = np.frombuffer(b"ABCDEFGHIJKLMNOPQRSTUVWXYZ0123456789", dtype=np.uint8)
 
 
-def draw_ids(size, generator=None, piece=1 << 20, reverse=False, first_row=0):
+def draw_ids(size, piece=1 << 20, reverse=False):
     """(size, 7) uint8 crispr ids of one write pass (CROPSR.py:316-318); with reverse=True the
     same ids last-first (the order the reference consumes them in, CROPSR.py:448-449).
 
     np.random.choice(alphanum, [size, 7]) IS alphanum[np.random.randint(0, 36, [size, 7])]
-    (legacy RandomState.choice, uniform, with replacement): same draws and the same global RNG
-    state afterwards, also when drawn in pieces of rows (tests/test_format.py) -- so no UCS-4
-    string array and no size x 7 int64 array are ever built.  `generator` (a numpy Generator, or
-    an int: seed of the native counter-based generator, which numbers its rows from first_row)
-    replaces the global legacy stream when the caller does not need the reference's draws."""
+    (legacy RandomState.choice, uniform, with replacement), and randint is one masked-rejection
+    draw per character on the global MT19937.  crp_legacy_ids makes exactly those draws on the
+    state taken from numpy and hands the advanced state back: same characters, same global RNG
+    state afterwards (tests/test_format.py), about five times faster, and no UCS-4 string array or
+    size x 7 int64 array is ever built.  (Should numpy's global generator ever not be MT19937,
+    the draws fall back to np.random.randint in pieces of rows.)"""
     out = np.empty((size, 7), dtype=np.uint8)
-    if isinstance(generator, int):  # counter-based native generator, seeded with this integer (crp_fill_ids)
+    if size == 0:
+        return out
+    state = np.random.get_state(legacy=True)
+    if state[0] == "MT19937":
         from . import _native as nat
-        nat.check(nat.lib().crp_fill_ids(out.ctypes.data_as(nat.u8p), size, generator, first_row, default_threads()),
-                  "crp_fill_ids")
-        return out[::-1].copy() if reverse and size else out
-    if generator is None and size:  # the reference's draws, made natively on numpy's own MT19937 state
-        state = np.random.get_state(legacy=True)
-        if state[0] == "MT19937":
-            import ctypes
-            from . import _native as nat
-            key = np.ascontiguousarray(state[1], dtype=np.uint32).copy()
-            pos = ctypes.c_int32(int(state[2]))
-            nat.check(nat.lib().crp_legacy_ids(key.ctypes.data_as(nat.u32p), ctypes.byref(pos), out.ctypes.data_as(nat.u8p),
-                                               size, int(bool(reverse))), "crp_legacy_ids")
-            np.random.set_state(("MT19937", key, pos.value, state[3], state[4]))
-            return out
+        key = np.ascontiguousarray(state[1], dtype=np.uint32).copy()
+        pos = ctypes.c_int32(int(state[2]))
+        nat.check(nat.lib().crp_legacy_ids(key.ctypes.data_as(nat.u32p), ctypes.byref(pos), out.ctypes.data_as(nat.u8p),
+                                           size, int(bool(reverse))), "crp_legacy_ids")
+        np.random.set_state(("MT19937", key, pos.value, state[3], state[4]))
+        return out
     for lo in range(0, size, piece):
         m = min(piece, size - lo)
-        if generator is None:
-            draws = np.random.randint(0, 36, size=[m, 7])
-        else:
-            draws = generator.integers(0, 36, size=[m, 7], dtype=np.uint8)
+        draws = np.random.randint(0, 36, size=[m, 7])
         if reverse:
             np.take(_ID_LUT, draws[::-1], out=out[size - lo - m:size - lo])
         else:
@@ -400,7 +393,7 @@ class IdStream:
     once the scan is done, so pass k+1's ids are drawn while pass k is formatted and written.
     Nothing else may touch np.random while the stream is open."""
 
-    def __init__(self, sizes, generator=None, depth=2, reverse=False):
+    def __init__(self, sizes, depth=2, reverse=False):
         import queue
         import threading
         self._sizes = list(sizes)
@@ -409,12 +402,10 @@ class IdStream:
 
         def work():
             try:
-                drawn = 0
                 for size in self._sizes:
                     if self._stop:
                         return
-                    self._q.put((size, draw_ids(size, generator, reverse=reverse, first_row=drawn)))
-                    drawn += size
+                    self._q.put((size, draw_ids(size, reverse=reverse)))
             except BaseException as e:  # handed to the consumer
                 self._q.put((None, e))
 

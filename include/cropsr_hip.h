@@ -178,12 +178,6 @@ int crp_write_rows(int fd, const uint8_t *contig_text, uint64_t contig_len, cons
  * Same values, same state afterwards as numpy; reverse != 0 stores the rows last-first. */
 int crp_legacy_ids(uint32_t *mt_key, int32_t *mt_pos, uint8_t *ids, uint64_t n_rows, int reverse);
 
-/* n_rows x 7 bytes of crispr ids from a counter-based generator instead of numpy's global stream
- * (CROPSR.py:316-318 draws them with np.random.choice; same alphabet, same uniform distribution,
- * NOT the same values): row r gets the base-36 digits of a hash of (seed, first_row + r).  For
- * callers that do not need the reference's draws; the CLI uses it only with --fast-ids. */
-int crp_fill_ids(uint8_t *ids, uint64_t n_rows, uint64_t seed, uint64_t first_row, int n_threads);
-
 /* ---- input side: FASTA bytes -> contig strings (host code, no GPU needed) ----- */
 /* The contig table import_fasta_file builds (CROPSR.py:54-74 with cropsr_functions.py:221-229
  * and :190-196) for a file in the "re-formatted" path whose records all have a header line and

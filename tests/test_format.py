@@ -216,36 +216,6 @@ def test_ids_drawn_in_pieces_and_ahead():
     with pytest.raises(RuntimeError):
         stream.next(5)
     stream.close()
-    fast = rows.draw_ids(20000, generator=np.random.default_rng(1))
-    assert fast.shape == (20000, 7) and set(np.unique(fast)) == set(lut.tolist())
-
-
-def test_native_id_generator():
-    """crp_fill_ids (the --fast-ids source): alphabet, uniformity, independence of how the rows
-    are split over calls and threads, distinct ids across passes of one IdStream."""
-    import ctypes
-    from cropsr_amd import _native as nat
-    L = nat.lib()
-    n = 300000
-    a = np.empty((n, 7), dtype=np.uint8)
-    assert L.crp_fill_ids(a.ctypes.data_as(nat.u8p), n, 12345, 0, 1) == 0
-    b = np.empty((n, 7), dtype=np.uint8)
-    for lo, hi, threads in ((0, 1000, 3), (1000, 170000, 5), (170000, n, 2)):
-        part = np.empty((hi - lo, 7), dtype=np.uint8)
-        assert L.crp_fill_ids(part.ctypes.data_as(nat.u8p), hi - lo, 12345, lo, threads) == 0
-        b[lo:hi] = part
-    assert (a == b).all()
-    lut = np.frombuffer(b"ABCDEFGHIJKLMNOPQRSTUVWXYZ0123456789", dtype=np.uint8)
-    counts = np.array([(a == c).sum() for c in lut])
-    assert counts.sum() == 7 * n and abs(counts / (7 * n / 36) - 1).max() < 0.02  # every symbol ~1/36
-    assert len({bytes(r) for r in a[:50000]}) > 49990  # 36^7 = 7.8e10 ids: (almost) no repeats
-    c = np.empty((n, 7), dtype=np.uint8)
-    assert L.crp_fill_ids(c.ctypes.data_as(nat.u8p), n, 12346, 0, 4) == 0 and (a != c).any(axis=1).mean() > 0.99
-    stream = rows.IdStream([1000, 1000], generator=777, reverse=True)
-    p1, p2 = stream.next(1000), stream.next(1000)
-    stream.close()
-    assert (p1 != p2).any() and (rows.draw_ids(1000, generator=777, reverse=True) == p1).all()
-    assert (rows.draw_ids(1000, generator=777)[::-1] == p1).all()
 
 
 def test_native_legacy_id_draws_equal_numpy():

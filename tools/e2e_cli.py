@@ -35,7 +35,6 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("workload")
     ap.add_argument("--reference-behaviour", action="store_true", help="re-emit earlier contigs like the reference")
-    ap.add_argument("--legacy-ids", action="store_true", help="ids from numpy's global legacy stream (reference draws)")
     ap.add_argument("--profile", action="store_true")
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
@@ -57,8 +56,6 @@ def main():
     argv = ["-f", fa, "-g", gff, "-o", out_csv, "--cas9", "--seed", "1"]
     if not a.reference_behaviour:
         argv.append("--each-contig-once")
-    if not a.legacy_ids:
-        argv.append("--fast-ids")
     args = cli.build_parser().parse_args(argv)
     os.chdir(tmp)
     sink = io.StringIO()
