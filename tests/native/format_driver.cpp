@@ -6,6 +6,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <random>
 #include <string>
 #include <vector>
@@ -55,6 +56,21 @@ int main(int argc, char **argv)
         const size_t got = used ? std::fread(back.data(), 1, used, f) : 0;
         std::fclose(f);
         if (got != used || !std::equal(back.begin(), back.end(), out.begin())) { std::printf("bytes differ\n"); ++failures; }
+    }
+    {  // crp_legacy_ids: forward and last-first draws from the same MT19937 state agree row for row
+        std::vector<uint32_t> key(624), key2;
+        for (auto &k : key) k = (uint32_t)rng();
+        key2 = key;
+        int32_t pos = 77, pos2 = 77;
+        const uint64_t n = 5003;
+        std::vector<uint8_t> fwd(7 * n), rev(7 * n);
+        if (crp_legacy_ids(key.data(), &pos, fwd.data(), n, 0) != CRP_OK || crp_legacy_ids(key2.data(), &pos2, rev.data(), n, 1) != CRP_OK)
+            ++failures;
+        for (uint64_t r = 0; r < n; ++r)
+            if (std::memcmp(fwd.data() + 7 * r, rev.data() + 7 * (n - 1 - r), 7) != 0) { ++failures; break; }
+        if (pos != pos2 || key != key2 || crp_legacy_ids(key.data(), &pos, nullptr, 0, 0) != CRP_OK) ++failures;
+        int32_t bad = 700;
+        if (crp_legacy_ids(key.data(), &bad, fwd.data(), 1, 0) != CRP_ERR_INVALID) ++failures;
     }
     unlink(path);
     std::printf(failures ? "FAILED\n" : "OK\n");
