@@ -546,7 +546,9 @@ def test_randomised_arenas_vs_oracle(engine, oracle):
     tile (16384) boundaries, random alphabets / decoration / guide lengths / packers."""
     rng = np.random.default_rng(20261003)
     alphabets = [b"ACGT", b"ACGTacgtN", b"GGCC", b"ACGTUZuzN')],", b"GGGGGGCCCCCCAT"]
-    anchors = [0, 1, 30, 63, 64, 65, 16383, 16384, 16385, 2 * 16384 - 1, 2 * 16384, 3 * 16384 + 7]
+    # contig lengths around word (64), half-tile and tile (512 words = 32768 positions) borders
+    anchors = [0, 1, 30, 63, 64, 65, 16383, 16384, 16385, 2 * 16384 - 1, 2 * 16384, 2 * 16384 + 1, 3 * 16384 + 7,
+               4 * 16384 - 1, 4 * 16384, 4 * 16384 + 65]
     total_hits = 0
     for trial in range(60):
         contigs = []
