@@ -6,7 +6,12 @@ exchange).  Contigs are independent in the hot loop (CROPSR.py:409 carries no
 state but the append-only list), so the path shards by contig:
 
   * partition_contigs: longest-processing-time greedy assignment of contigs to
-    ranks by length (a contig is never split, so no halo exchange is needed);
+    ranks by length;
+  * cut_contigs / piece_view / stitch_pieces: a contig longer than its fair share is
+    cut into pieces that carry HALO characters of context either side, each hit is
+    owned by the piece its match index falls in, and the pieces of a contig are
+    stitched back in order -- no halo EXCHANGE is needed, every rank reads its
+    piece (with halo) from the FASTA it already has;
   * every rank scans/scores its own arena -- no collective on the data path;
   * gather_hit_tables: the one exchange step, a gatherv of the per-rank hit
     tables to the root.  RCCL has no gatherv primitive: an all-gather of the
@@ -38,6 +43,59 @@ def partition_contigs(lengths, world_size):
         owner[k] = b
         load[b] += int(lengths[k])
     return owner
+
+
+# Everything the reference looks at around a match lies within 58 characters of it for guide
+# lengths up to 50 (keep-filter: l + 5 behind, l + 8 ahead; the 30-character scoring window),
+# so 128 characters of context make a piece's owned hits identical to the whole contig's.
+HALO = 128
+
+
+def cut_contigs(lengths, world_size, max_piece=None):
+    """[(contig index, start, end)] covering every contig: a contig longer than max_piece
+    (default: total / world_size, at least 4096) is cut into equal pieces of at most that length."""
+    total = int(sum(int(n) for n in lengths))
+    if max_piece is None:
+        max_piece = max(4096, -(-total // max(1, world_size)))
+    pieces = []
+    for k, n in enumerate(lengths):
+        n = int(n)
+        parts = max(1, -(-n // max_piece))
+        step = -(-n // parts) if parts > 1 else n
+        for q in range(parts):
+            pieces.append((k, q * step, min(n, (q + 1) * step)))
+    return pieces
+
+
+def piece_view(contig, start, end):
+    """(characters to scan, index of `start` inside them) for the piece [start, end) of a contig
+    string (bytes-like, one byte per character): the piece plus HALO characters either side."""
+    lo = max(0, start - HALO)
+    return contig[lo:min(len(contig), end + HALO)], start - lo
+
+
+def stitch_pieces(piece_hits):
+    """Hit tables of ONE contig from the tables of its pieces.
+
+    piece_hits: [(start, end, shift, hits)] in piece order, hits = dict(pos_plus, score_plus,
+    pos_minus, score_minus[, pre_*]) with positions relative to the scanned characters of
+    piece_view, shift = the second value piece_view returned.  A hit belongs to the piece whose
+    [start, end) contains its match index (the regex match position of CROPSR.py:98-104)."""
+    out = {}
+    for strand in ("plus", "minus"):
+        cols = {c: [] for c in ("pos", "score", "pre")}
+        for start, end, shift, hits in piece_hits:
+            pos = np.asarray(hits["pos_" + strand]).astype(np.int64) - shift + start  # contig coordinates
+            own = (pos >= start) & (pos < end)
+            cols["pos"].append(pos[own].astype(np.uint32))
+            cols["score"].append(np.asarray(hits["score_" + strand])[own])
+            if "pre_" + strand in hits:
+                cols["pre"].append(np.asarray(hits["pre_" + strand])[own])
+        out["pos_" + strand] = np.concatenate(cols["pos"]) if cols["pos"] else np.empty(0, np.uint32)
+        out["score_" + strand] = np.concatenate(cols["score"]) if cols["score"] else np.empty(0)
+        if cols["pre"]:
+            out["pre_" + strand] = np.concatenate(cols["pre"])
+    return out
 
 
 class _DeviceArray:

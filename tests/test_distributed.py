@@ -95,3 +95,33 @@ def test_partition_is_balanced_and_deterministic():
     assert max(load) - min(load) <= max(lens)
     assert parallel.partition_contigs([5, 4, 3], 1) == [0, 0, 0]
     assert sorted(set(parallel.partition_contigs([1] * 16, 4))) == [0, 1, 2, 3]
+
+
+@pytest.mark.parametrize("guide_len", [20, 25, 50, 5])
+def test_cut_contigs_give_the_same_hits(oracle, guide_len):
+    """parallel.cut_contigs / piece_view / stitch_pieces: a contig scanned in pieces (each with its
+    halo, hits owned by match index) gives exactly the tables of the contig scanned whole -- at
+    the true ends too, where the reference's decoration and bounds tests live."""
+    from cropsr_amd import parallel
+    rng = np.random.default_rng(guide_len)
+    a = np.frombuffer(b"ACGTacgtNGGCC", dtype=np.uint8)
+    contigs = [b"'" + rng.choice(a, n).tobytes() + b"')," for n in (50000, 300, 9000, 0, 4097)]
+    pieces = parallel.cut_contigs([len(c) for c in contigs], 4, max_piece=4096)
+    assert sum(e - s for _, s, e in pieces) == sum(len(c) for c in contigs)
+    assert max(e - s for _, s, e in pieces) <= 4096 and len([p for p in pieces if p[0] == 0]) == 13
+    for k, c in enumerate(contigs):
+        parts = []
+        for kk, start, end in pieces:
+            if kk != k:
+                continue
+            text, shift = parallel.piece_view(c, start, end)
+            parts.append((start, end, shift, oracle.scan_score(text, guide_len)))
+        got = parallel.stitch_pieces(parts)
+        want = oracle.scan_score(c, guide_len)
+        for key in want:
+            assert got[key].shape == want[key].shape, (k, key)
+            assert (np.ascontiguousarray(got[key]).view(np.uint8) == np.ascontiguousarray(want[key]).view(np.uint8)).all(), (k, key)
+    # default piece size: the fair share of one rank
+    auto = parallel.cut_contigs([1000000, 10, 20], 4)
+    assert [p for p in auto if p[0] == 0] == [(0, 0, 250000), (0, 250000, 500000), (0, 500000, 750000), (0, 750000, 1000000)]
+    assert [p for p in auto if p[0] != 0] == [(1, 0, 10), (2, 0, 20)]

@@ -467,6 +467,22 @@ def test_genome_spread_over_several_arenas(engine, oracle):
 
 
 # ------------------------------------------------------- multi-GPU plumbing
+def test_cut_contig_on_gpu_equals_whole(engine, oracle):
+    """parallel.cut_contigs: the pieces of one long contig (what several ranks would each scan,
+    halo included) through the GPU engine and stitched == the contig scanned whole == the oracle."""
+    from cropsr_amd import parallel
+    rng = np.random.default_rng(64)
+    c = b"'" + rng.choice(np.frombuffer(b"ACGTacgtNGGCC", dtype=np.uint8), 700000).tobytes() + b"')]"
+    pieces = parallel.cut_contigs([len(c)], 8)
+    assert len(pieces) == 8
+    views = [parallel.piece_view(c, s, e) for _, s, e in pieces]
+    arena = engine.arena([v for v, _ in views])
+    hits = arena.scan_score(20, want_pre=True)
+    got = parallel.stitch_pieces([(s, e, shift, hits.contig(q)) for q, ((_, s, e), (_, shift)) in enumerate(zip(pieces, views))])
+    arena.close()
+    assert_hits_equal(got, oracle.scan_score(c, 20), ctx="stitched")
+
+
 def test_device_table_views_are_zero_copy(engine):
     """parallel.device_tables_as_tensors: torch views of the library's HBM tables."""
     import torch
