@@ -332,3 +332,16 @@ def test_score_tables_equal_sequential_sums():
             assert data[base // 8 + off // 8] == v, (chain, pattern)
         looked_up += k
     assert looked_up >= 40
+
+
+def test_public_header_is_plain_c(tmp_path):
+    """include/cropsr_hip.h is the C ABI: it must compile as C99 (no C++, no HIP or torch types)."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    src = tmp_path / "t.c"
+    src.write_text('#include "cropsr_hip.h"\nint main(void) { return crp_abi_version() == 0; }\n')
+    p = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only",
+                        "-I", os.path.join(ROOT, "include"), str(src)], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
