@@ -445,6 +445,47 @@ def test_baseline_config_workloads_sampled_against_oracle(_engine, oracle, confi
     genome.close()
 
 
+def test_largest_arena(_engine, oracle):
+    """One contig that fills the largest arena the library accepts (just under 2^31 characters:
+    positions are 32-bit, the chained-scan descriptors carry 31-bit counts).  The contig is one
+    4 KiB block repeated, so every interior repeat must carry the first repeat's hits shifted by
+    a multiple of the period, with bit-identical scores; the two ends are compared with the
+    oracle; one character more is refused."""
+    from cropsr_amd import _native as nat
+    from cropsr_amd import CropsrHipError
+    _engine.configure(two_pass=False)
+    max_chars = int(nat.lib().crp_arena_max_words()) * 64 - 192  # room for the separators around the contig
+    period = 4096
+    rng = np.random.default_rng(2)
+    block = rng.choice(np.frombuffer(b"ACGTACGTACGTacgtN", dtype=np.uint8), period)
+    n_rep = max_chars // period
+    text = np.tile(block, n_rep)
+    assert text.size > 2**31 - 300000
+    arena = _engine.arena([text])
+    hits = arena.scan_score(20, want_pre=False)
+    del text
+    ref = oracle.scan_score(np.tile(block, 4).tobytes(), 20)  # repeats 1 and 2 of these 4 are "interior"
+    for strand in ("plus", "minus"):
+        pos = hits.contig(0)["pos_" + strand].astype(np.int64)
+        sc = hits.contig(0)["score_" + strand]
+        rp = ref["pos_" + strand].astype(np.int64)
+        interior = (rp >= period) & (rp < 2 * period)
+        want_pos, want_sc = rp[interior] - period, ref["score_" + strand][interior]
+        per = want_pos.size
+        assert per > 100
+        for k in (1, 2, n_rep // 2, n_rep - 3, n_rep - 2):  # repeat k of the big contig
+            a, b = np.searchsorted(pos, [k * period, (k + 1) * period])
+            assert b - a == per and (pos[a:b] - k * period == want_pos).all(), (strand, k)
+            assert (bits(sc[a:b]) == bits(want_sc)).all(), (strand, k)
+        first = rp < period  # the contig's own left end
+        a = np.searchsorted(pos, period)
+        assert (pos[:a] == rp[first]).all() and (bits(sc[:a]) == bits(ref["score_" + strand][first])).all()
+        assert abs(pos.size - per * n_rep) <= 2 * per and (np.diff(pos) > 0).all() and pos[-1] < 2**31
+    arena.close()
+    with pytest.raises((CropsrHipError, ValueError)):
+        _engine.arena([np.zeros(max_chars + 4096, dtype=np.uint8)])
+
+
 def test_genome_spread_over_several_arenas(engine, oracle):
     """Inputs beyond one arena (2^31 characters) are split contig by contig; forced here
     with a tiny per-arena limit.  Results must not depend on the split."""
