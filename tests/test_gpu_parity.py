@@ -445,6 +445,22 @@ def test_baseline_config_workloads_sampled_against_oracle(_engine, oracle, confi
     genome.close()
 
 
+def test_empty_and_degenerate_arenas(engine, oracle):
+    """No contig at all, only empty contigs, contigs shorter than any window, a contig of
+    characters that are no bases: the oracle's (mostly empty) tables, no error, in both scan modes."""
+    for contigs in ([], [b""], [b"", b"", b""], [b"A"], [b"GG"], [b"CC"], [b"'),"], [b"N" * 5000],
+                    [b"", b"ACGTTGCA" * 3, b""]):
+        arena = engine.arena(contigs)
+        hits = arena.scan_score(20, want_pre=True)
+        want = [oracle.scan_score(c, 20) for c in contigs]
+        assert hits.n_plus == sum(w["pos_plus"].size for w in want)
+        assert hits.n_minus == sum(w["pos_minus"].size for w in want)
+        for k, w in enumerate(want):
+            assert_hits_equal(hits.contig(k), w, ctx=(contigs, k))
+        assert arena.stats()["n_contigs"] == len(contigs)
+        arena.close()
+
+
 def test_largest_arena(_engine, oracle):
     """One contig that fills the largest arena the library accepts (just under 2^31 characters:
     positions are 32-bit, the chained-scan descriptors carry 31-bit counts).  The contig is one
