@@ -85,8 +85,9 @@ def main():
     rnd = random.Random(a.seed)
     scratch = tempfile.mkdtemp(prefix="fuzz_")
     bad = 0
+    degenerate = ["", "\n", ">", ">\n", ">x", ">x\n", "ACGT", "ACGTGGCCAGGTTCCAGGACGT\n", ">a\n>b\n", ">a\n\n"]
     for it in range(a.n):
-        fa = random_fasta(rnd)
+        fa = degenerate[it] if it < len(degenerate) else random_fasta(rnd)
         extra = rnd.choice([(), (), (), ("-l", "17"), ("-l", "23"), ("-l", "30"), ("-v",), ("-v", "-l", "21")])
         try:
             want = mg.run_reference(fa, mg.MINI_GFF, "libm", scratch, extra=extra)
