@@ -5,8 +5,10 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-A step = one pass of the hot path (crp_scan_score: count -> tile scan -> emit+score)
-over the rank's arena, with the packed genome already resident in HBM.  Contigs are
+A step = one pass of the hot path (crp_scan_score: ONE kernel launch that scans, compacts and
+scores, taking its table offsets from a chained scan across workgroups; --two-pass selects the
+count -> tile scan -> emit+score launch sequence instead) over the rank's arena, with the packed
+genome already resident in HBM.  Contigs are
 independent, so at N > 1 the steps run with NO collective on the data path; the
 path's one exchange -- the FINAL RCCL gatherv of the per-rank hit tables to rank 0 --
 runs once after the timed steps and is reported on its own (`gatherv`), together with
