@@ -10,6 +10,7 @@ Mirrors the two seams of the reference that the HIP library replaces:
 Everything numeric happens in libcropsr_hip.so on the GPU; this module only moves
 buffers and slices tables.  There is no CPU fallback.
 """
+import atexit
 import ctypes
 import weakref
 
@@ -126,6 +127,21 @@ class Arena:
         return Hits(self.offsets, self.lengths, guide_len, cols)
 
 
+# Engines still open when the interpreter exits are closed here, in an atexit handler: that runs
+# before module globals are torn down and before the HIP runtime's own static destructors, so no
+# __del__ ever calls into a runtime that is already gone.
+_LIVE_ENGINES = weakref.WeakSet()
+
+
+@atexit.register
+def _close_live_engines():
+    for eng in list(_LIVE_ENGINES):
+        try:
+            eng.close()
+        except Exception:
+            pass
+
+
 class Engine:
     """One HIP device opened through libcropsr_hip.so."""
 
@@ -138,6 +154,7 @@ class Engine:
             raise nat.CropsrHipError(st, "crp_init(device=%d)" % device)
         self._ctx = h
         self._arenas = weakref.WeakSet()
+        _LIVE_ENGINES.add(self)
 
     def close(self):
         if self._ctx:

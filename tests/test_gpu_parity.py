@@ -502,6 +502,33 @@ def test_largest_arena(_engine, oracle):
         _engine.arena([np.zeros(max_chars + 4096, dtype=np.uint8)])
 
 
+def test_several_arenas_and_contexts_interleaved(engine, oracle):
+    """Arenas of one context scanned alternately (each owns its descriptor buffers and tables), a
+    second context on the same device in between, different guide lengths on one arena: no scan
+    disturbs another's result."""
+    from cropsr_amd import Engine
+    rng = np.random.default_rng(91)
+    a = np.frombuffer(b"ACGTacgtNGGCC", dtype=np.uint8)
+    sets = [[rng.choice(a, n).tobytes() for n in ns] for ns in ((70000, 300), (150000,), (9, 40000, 40000))]
+    arenas = [engine.arena(cs) for cs in sets]
+    other = Engine(0)
+    other_arena = other.arena(sets[1])
+    want = {(i, l): [oracle.scan_score(c, l) for c in cs] for i, cs in enumerate(sets) for l in (20, 23)}
+    for l in (20, 23, 20):
+        got = [ar.scan_score_device(l, want_pre=True) for ar in arenas]   # all launched before any table is read
+        o = other_arena.scan_score(l, want_pre=True)
+        for i, (ar, (n_plus, n_minus)) in enumerate(zip(arenas, got)):
+            from cropsr_amd.engine import Hits
+            hits = Hits(ar.offsets, ar.lengths, l, ar.fetch(n_plus, n_minus, want_pre=True))
+            for k in range(len(sets[i])):
+                assert_hits_equal(hits.contig(k), want[(i, l)][k], ctx=(i, l, k))
+        assert_hits_equal(o.contig(0), want[(1, l)][0], ctx=("other", l))
+    other_arena.close()
+    other.close()
+    for ar in arenas:
+        ar.close()
+
+
 def test_genome_spread_over_several_arenas(engine, oracle):
     """Inputs beyond one arena (2^31 characters) are split contig by contig; forced here
     with a tiny per-arena limit.  Results must not depend on the split."""
