@@ -241,7 +241,10 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": genomes[0].name, "genomes": world, "contigs_per_genome": len(genomes[0].specs),
                        "bases_total": int(bases_all), "kept_hits_total": int(hits_all),
-                       "guide_len": 20, "launches_per_step": 3 if args.two_pass else 1, "parallelism": ("contigs by LPT over %d ranks" % world) +
+                       "guide_len": 20,
+                       # a look-back time-out would switch the context to the three-launch sequence for good
+                       "launches_per_step": 3 if (args.two_pass or side["count"]["launches"] > 0) else 1,
+                       "parallelism": ("contigs by LPT over %d ranks" % world) +
                        ("" if gather is None else (" + %s gatherv to rank 0 " % ("RCCL" if args.backend == "nccl" else "gloo (host-staged)") +
                                                    ("every step" if args.gather_every_step else "once, after the steps"))),
                        "device": info["name"].strip()},
