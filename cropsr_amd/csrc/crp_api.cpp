@@ -119,7 +119,11 @@ int crp_init(int device_id, crp_ctx **out)
     if (!ctx) return CRP_ERR_NOMEM;
     ctx->device = device_id;
     hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) {
+    if (hipGetDeviceProperties(&prop, device_id) != hipSuccess || std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        delete ctx;  // the library carries gfx950 code objects only
+        return CRP_ERR_NO_DEVICE;
+    }
+    {
         std::snprintf(ctx->name, sizeof ctx->name, "%s (%s)", prop.name, prop.gcnArchName);
         ctx->n_cu = prop.multiProcessorCount;
         ctx->hbm = prop.totalGlobalMem;

@@ -43,7 +43,7 @@ extern "C" {
 typedef enum crp_status {
     CRP_OK = 0,
     CRP_ERR_INVALID = -1,     /* bad argument */
-    CRP_ERR_NO_DEVICE = -2,   /* no usable HIP device (never falls back to CPU) */
+    CRP_ERR_NO_DEVICE = -2,   /* no usable HIP device: none, or not a gfx950 (never falls back to CPU) */
     CRP_ERR_HIP = -3,         /* a HIP runtime call failed; see crp_last_error */
     CRP_ERR_NOMEM = -4,       /* host or device allocation failed */
     CRP_ERR_STATE = -5,       /* call out of order (e.g. scan before seal) */
