@@ -56,7 +56,8 @@ def build_parser():
     p.add_argument("-v", "--verbose", action="store_true",
                    help="prints visual indicators for each iteration")
     eng = p.add_argument_group("MI355X engine")
-    eng.add_argument("--device", type=int, default=0, help="HIP device index, default = 0")
+    eng.add_argument("--device", type=int, default=None,
+                     help="HIP device index, default = 0 (LOCAL_RANK under torch.distributed.run)")
     eng.add_argument("--seed", type=int, default=None,
                      help="seed numpy's global RNG so crispr_id is reproducible (reference: unseeded)")
     eng.add_argument("--csv-writer", choices=["native", "python"], default="native",
@@ -105,12 +106,41 @@ class EngineBackend:
         genome.close()
         return out
 
+    def scan_tables(self, texts, guide_len):
+        """The same scan with the tables left in HBM, for parallel.sharded_scan: torch views of the
+        library's device tables (zero copy), the arena layout, and a release callback."""
+        from . import parallel
+        arena = self.engine.arena(texts)
+        n_plus, n_minus = arena.scan_score_device(guide_len, want_pre=False)
+        tables = parallel.device_tables_as_tensors(arena, n_plus, n_minus)
+        return tables, list(zip(arena.offsets, arena.lengths)), arena.close
+
     def rescore(self, rows_u8, order):
         """Seam 2 on a few rows in one of the BLAS tail orders (rows.Dataset.rows)."""
         return self.engine.score_30mers(rows_u8, order)[1]
 
     def close(self):
         self.engine.close()
+
+
+def _distributed():
+    """(rank, world) when launched by torch.distributed.run with more than one process, else None.
+    One process per GPU; the process group is RCCL (backend "nccl") unless CROPSR_DIST_BACKEND
+    names another one (gloo: CPU rehearsals and the tests)."""
+    import os
+    if int(os.environ.get("WORLD_SIZE", "1")) <= 1:
+        return None
+    import torch  # noqa: F401  (before the engine: PyTorch-ROCm brings its own HIP runtime)
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        name = os.environ.get("CROPSR_DIST_BACKEND", "nccl")
+        if name == "nccl":
+            local = int(os.environ.get("LOCAL_RANK", "0"))
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(name)
+    return dist.get_rank(), dist.get_world_size()
 
 
 def run(args, backend=None, out=sys.stdout):
@@ -124,6 +154,23 @@ def run(args, backend=None, out=sys.stdout):
     begin = time.time()
     if not args.cas9:
         sys.exit("Please select at least one CRISPR system: Cas9")  # CROPSR.py:335-336
+    shard = _distributed()
+    if shard is not None and shard[0] != 0:
+        # Ranks other than 0 of a multi-GPU run (python -m torch.distributed.run ... -m cropsr_amd):
+        # read the same FASTA, scan their share of the contigs, hand the tables to rank 0 -- which
+        # alone prints, draws ids and writes files -- and leave.
+        import os
+        from . import parallel
+        table = fasta.table_from_bytes(fasta.read_text_bytes(args.f))
+        own_backend = backend is None
+        if own_backend:
+            device = getattr(args, "device", None)
+            backend = EngineBackend(int(os.environ.get("LOCAL_RANK", "0")) if device is None else device)
+        parallel.sharded_scan(backend, [v for _, v in table], args.l,
+                              max_piece=int(os.environ.get("CROPSR_DIST_MAX_PIECE", "0")) or None)
+        if own_backend:
+            backend.close()
+        return
     verbose = args.verbose
     if verbose:
         print(BANNER + f"""
@@ -171,8 +218,18 @@ def run(args, backend=None, out=sys.stdout):
     strings = [v for _, v in table]  # contig strings as bytes, one byte per character
     own_backend = backend is None
     if own_backend:
-        backend = EngineBackend(getattr(args, "device", 0))
-    all_hits = backend.scan(strings, args.l)  # seam 1 + 2 for every contig, one GPU pass
+        import os
+        device = getattr(args, "device", None)
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", "0")) if shard is not None else 0
+        backend = EngineBackend(device)
+    if shard is None:
+        all_hits = backend.scan(strings, args.l)  # seam 1 + 2 for every contig, one GPU pass
+    else:  # contigs (cut where longer than a rank's share) over all GPUs, tables gathered here
+        import os
+        from . import parallel
+        all_hits = parallel.sharded_scan(backend, strings, args.l,
+                                         max_piece=int(os.environ.get("CROPSR_DIST_MAX_PIECE", "0")) or None)
 
     native = getattr(args, "csv_writer", "native") == "native"
     once = getattr(args, "each_contig_once", False)

@@ -214,3 +214,45 @@ def merge_gathered(gathered, owners, per_rank_contigs):
             out[k] = dict(pos_plus=pp[a:b] - np.uint32(off), score_plus=np.asarray(t["score_plus"])[a:b],
                           pos_minus=pm[c:d] - np.uint32(off), score_minus=np.asarray(t["score_minus"])[c:d])
     return out
+
+
+def sharded_scan(backend, strings, guide_len, dst=0, group=None, max_piece=None):
+    """The scan of `strings` (the same list on every rank) spread over the ranks of `group`.
+
+    Contigs are cut into pieces of at most a rank's fair share (cut_contigs), the pieces are dealt
+    to the ranks by LPT (partition_contigs), every rank scans its pieces -- with their halo, no
+    exchange -- through backend.scan_tables, and the one exchange of the path, the gatherv of the
+    per-rank hit tables (TableGather: RCCL on GPUs), brings them to `dst`, where the pieces of each
+    contig are stitched back.  Returns on `dst` what backend.scan(strings, guide_len) returns on
+    one GPU -- a list of hit dicts, one per contig, bit for bit -- and None on the other ranks.
+
+    backend.scan_tables(texts, guide_len) -> (tables, layout, release): tables = dict of the four
+    COLUMNS as 1-D torch tensors (positions are arena positions), layout = [(offset, length)] of
+    every text in that arena, release() frees what the tensors view."""
+    import torch.distributed as dist
+    rank = dist.get_rank(group)
+    world = dist.get_world_size(group)
+    pieces = cut_contigs([len(s) for s in strings], world, max_piece)
+    owner = partition_contigs([e - s for _, s, e in pieces], world)
+    mine = [q for q, o in enumerate(owner) if o == rank]
+    views = [piece_view(strings[pieces[q][0]], pieces[q][1], pieces[q][2]) for q in mine]
+    tables, layout, release = backend.scan_tables([v for v, _ in views], guide_len)
+    mine_layout = [(q, int(off), int(ln)) for q, (off, ln) in zip(mine, layout)]
+    layouts = [None] * world
+    dist.all_gather_object(layouts, mine_layout, group=group)
+    gathered = TableGather(dst, group)(tables)
+    if rank != dst:
+        release()
+        return None
+    as_numpy = [{c: t.cpu().numpy() for c, t in g.items()} for g in gathered]
+    release()
+    per_piece = merge_gathered(as_numpy, None, layouts)
+    out = []
+    for k in range(len(strings)):
+        parts = []
+        for q, (kk, start, end) in enumerate(pieces):
+            if kk == k:
+                parts.append((start, end, start - max(0, start - HALO), per_piece[q]))
+        out.append(stitch_pieces(parts))
+    return out
+

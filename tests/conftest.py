@@ -90,6 +90,28 @@ class OracleBackend:
     def scan(self, strings, l):
         return [self.orc.scan_score(s.encode("ascii", "replace") if isinstance(s, str) else s, l) for s in strings]
 
+    def scan_tables(self, texts, l):
+        """What EngineBackend.scan_tables returns, from the oracle: CPU tensors with arena positions
+        (texts at 64-aligned offsets separated like the device arena), for parallel.sharded_scan."""
+        import numpy as np
+        import torch
+        off, layout = 64, []
+        cols = {c: [] for c in ("pos_plus", "score_plus", "pos_minus", "score_minus")}
+        for t in texts:
+            h = self.orc.scan_score(bytes(t), l)
+            layout.append((off, len(t)))
+            cols["pos_plus"].append(h["pos_plus"] + np.uint32(off))
+            cols["pos_minus"].append(h["pos_minus"] + np.uint32(off))
+            cols["score_plus"].append(h["score_plus"])
+            cols["score_minus"].append(h["score_minus"])
+            off += ((len(t) + 63) // 64 + 1) * 64
+        cat = lambda xs, dt: np.concatenate(xs).astype(dt) if xs else np.empty(0, dtype=dt)
+        tables = {"pos_plus": torch.from_numpy(cat(cols["pos_plus"], np.uint32).view(np.int32)),
+                  "score_plus": torch.from_numpy(cat(cols["score_plus"], np.float64)),
+                  "pos_minus": torch.from_numpy(cat(cols["pos_minus"], np.uint32).view(np.int32)),
+                  "score_minus": torch.from_numpy(cat(cols["score_minus"], np.float64))}
+        return tables, layout, lambda: None
+
     def rescore(self, rows_u8, order):
         return self.orc.score30_order(rows_u8, order)[1]
 

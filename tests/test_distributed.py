@@ -125,3 +125,44 @@ def test_cut_contigs_give_the_same_hits(oracle, guide_len):
     auto = parallel.cut_contigs([1000000, 10, 20], 4)
     assert [p for p in auto if p[0] == 0] == [(0, 0, 250000), (0, 250000, 500000), (0, 500000, 750000), (0, 750000, 1000000)]
     assert [p for p in auto if p[0] != 0] == [(1, 0, 10), (2, 0, 20)]
+
+
+def _cli_worker(rank, world, port, probe, max_piece, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), CROPSR_DIST_BACKEND="gloo", CROPSR_DIST_MAX_PIECE=str(max_piece))
+    import io
+    import json
+    from conftest import GOLDEN, OracleBackend
+    from cropsr_amd import cli
+    from oracle import oracle
+    oracle.lib()
+    seed = json.load(open(os.path.join(GOLDEN, "manifest.json")))["seed"]
+    work = os.path.join(out_dir, "rank%d" % rank)
+    os.makedirs(work)
+    os.chdir(work)
+    args = cli.build_parser().parse_args(["-f", os.path.join(GOLDEN, "probe_%s.fa" % probe), "-g", os.path.join(GOLDEN, "sample_head.gff"),
+                                          "-o", os.path.join(work, "out.csv"), "--cas9", "--seed", str(seed)])
+    buf = io.StringIO()
+    cli.run(args, backend=OracleBackend(oracle), out=buf)
+    with open(os.path.join(work, "stdout.txt"), "w") as f:
+        f.write(buf.getvalue())
+
+
+@pytest.mark.parametrize("probe,world,max_piece", [("multi", 2, 0), ("mixed", 3, 100), ("tiny", 2, 40)])
+def test_cli_under_torch_distributed_equals_reference(probe, world, max_piece, manifest, tmp_path):
+    """python -m cropsr_amd launched as `world` processes (what torch.distributed.run does): contigs
+    are cut and dealt to the ranks, every rank scans its share, the tables are gathered to rank 0,
+    and rank 0 alone writes -- the reference's bytes and stdout, as on one GPU.  Here with gloo and the
+    oracle as hit provider; max_piece forces cuts inside contigs (pieces of 40 / 100 characters)."""
+    import torch.multiprocessing as mp
+    from conftest import read_golden_csv
+    port = _free_port()
+    mp.spawn(_cli_worker, args=(world, port, probe, max_piece, str(tmp_path)), nprocs=world, join=True)
+    with open(tmp_path / "rank0" / "out.csv", "rb") as f:
+        assert f.read() == read_golden_csv(probe)
+    assert (tmp_path / "rank0" / "stdout.txt").read_text() == manifest["cases"][probe]["stdout"]
+    for r in range(1, world):  # the other ranks wrote nothing and printed nothing
+        assert sorted(os.listdir(tmp_path / ("rank%d" % r))) == ["stdout.txt"]
+        assert (tmp_path / ("rank%d" % r) / "stdout.txt").read_text() == ""

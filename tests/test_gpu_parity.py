@@ -618,6 +618,26 @@ def test_gather_runs_on_rccl_backend(tmp_path):
     assert open(out).read() == "ok"
 
 
+def test_cli_multi_process_on_gpu(manifest, tmp_path):
+    """`python -m torch.distributed.run --nproc-per-node 2 -m cropsr_amd ...`: two processes, contigs
+    cut into 100-character pieces and dealt to them, HIP tables gathered to rank 0, which writes the
+    reference's bytes.  One GPU here, so both ranks use device 0 and the exchange runs on gloo
+    (host-staged); on a multi-GPU node the same command without CROPSR_DIST_BACKEND uses RCCL."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    out_csv = tmp_path / "out.csv"
+    env = dict(os.environ, CROPSR_DIST_BACKEND="gloo", CROPSR_DIST_MAX_PIECE="100", PYTHONPATH=ROOT)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", "-m", "cropsr_amd", "-f", os.path.join(GOLDEN, "probe_mixed.fa"),
+           "-g", os.path.join(GOLDEN, "sample_head.gff"), "-o", str(out_csv), "--cas9", "--seed", str(manifest["seed"]),
+           "--device", "0"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=str(tmp_path), env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert out_csv.read_bytes() == read_golden_csv("mixed")
+    assert manifest["cases"]["mixed"]["stdout"] in p.stdout
+
+
 def test_bench_line_contract():
     """bench.py prints ONE JSON line with the contract's keys (tiny workload)."""
     import json
