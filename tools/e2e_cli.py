@@ -36,6 +36,9 @@ def main():
     ap.add_argument("workload")
     ap.add_argument("--reference-behaviour", action="store_true", help="re-emit earlier contigs like the reference")
     ap.add_argument("--profile", action="store_true")
+    ap.add_argument("--procs", type=int, default=1,
+                    help="run the CLI as that many torch.distributed processes (all on device 0, exchange on gloo: a "
+                         "rehearsal of the multi-GPU mode on a one-GPU box)")
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
     import bench_workload as bw
@@ -51,11 +54,26 @@ def main():
     with open(gff, "w") as f:
         f.write("##gff-version 3\n")
     t_gen = time.time() - t0
-    import torch  # noqa: F401  (the bundled HIP runtime must come up before the engine's)
-    from cropsr_amd import cli
     argv = ["-f", fa, "-g", gff, "-o", out_csv, "--cas9", "--seed", "1"]
     if not a.reference_behaviour:
         argv.append("--each-contig-once")
+    if a.procs > 1:
+        import subprocess
+        env = dict(os.environ, CROPSR_DIST_BACKEND="gloo", PYTHONPATH=ROOT)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.procs),
+               "--master-addr", "127.0.0.1", "--master-port", "29551", "-m", "cropsr_amd"] + argv + ["--device", "0"]
+        t0 = time.time()
+        p = subprocess.run(cmd, cwd=tmp, env=env, capture_output=True, text=True)
+        wall = time.time() - t0
+        if p.returncode != 0:
+            sys.exit(p.stderr[-3000:])
+        size = os.path.getsize(out_csv)
+        print(json.dumps({"workload": wl.name, "procs": a.procs, "csv_bytes": size, "wall_incl_process_start_s": round(wall, 3)}))
+        os.remove(out_csv)
+        os.remove(fa)
+        return
+    import torch  # noqa: F401  (the bundled HIP runtime must come up before the engine's)
+    from cropsr_amd import cli
     args = cli.build_parser().parse_args(argv)
     os.chdir(tmp)
     sink = io.StringIO()
