@@ -109,7 +109,13 @@ class EngineBackend:
     def scan_tables(self, texts, guide_len):
         """The same scan with the tables left in HBM, for parallel.sharded_scan: torch views of the
         library's device tables (zero copy), the arena layout, and a release callback."""
+        from . import _native as nat
         from . import parallel
+        L = nat.lib()
+        need = sum(int(L.crp_arena_words_for(len(t))) for t in texts)
+        if int(L.crp_arena_words_total(need)) > int(L.crp_arena_max_words()):
+            raise ValueError("this rank's share of the genome (%d characters) does not fit one arena of 2^31 "
+                             "characters: run on more GPUs" % sum(len(t) for t in texts))
         arena = self.engine.arena(texts)
         n_plus, n_minus = arena.scan_score_device(guide_len, want_pre=False)
         tables = parallel.device_tables_as_tensors(arena, n_plus, n_minus)
