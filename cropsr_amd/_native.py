@@ -47,7 +47,28 @@ SIGNATURES = {
     "crp_legacy_ids": (ctypes.c_int, [u32p, ctypes.POINTER(ctypes.c_int32), u8p, ctypes.c_uint64, ctypes.c_int]),
     "crp_fasta_table": (ctypes.c_int, [u8p, ctypes.c_uint64, u8p, ctypes.c_uint64, u64p, ctypes.c_uint64, u64p, u64p,
                                        ctypes.POINTER(ctypes.c_int), ctypes.c_int]),
+    "crp_write_rows_ex": (ctypes.c_int, [ctypes.c_int, u8p, ctypes.c_uint64, u8p, ctypes.c_uint64, ctypes.c_int, u32p, u8p,
+                                         f64p, u8p, ctypes.c_uint64, u8p, u64p, u32p, u32p, u64p, ctypes.c_int]),
+    "crp_comm_unique_id": (ctypes.c_int, [u8p]),
+    "crp_comm_init": (ctypes.c_int, [ctypes.c_void_p, u8p, ctypes.c_int, ctypes.c_int]),
+    "crp_comm_destroy": (ctypes.c_int, [ctypes.c_void_p]),
+    "crp_comm_barrier": (ctypes.c_int, [ctypes.c_void_p]),
+    "crp_comm_allreduce_f64": (ctypes.c_int, [ctypes.c_void_p, f64p, ctypes.c_int, ctypes.c_int]),
+    "crp_gather_hits": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, u64p]),
+    "crp_gathered_fetch": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, u32p, f64p, u32p, u32p, f64p, u32p]),
+    "crp_offtarget_hist_get": (ctypes.c_int, [ctypes.c_void_p, u32p]),
+    "crp_offtarget_hist_set": (ctypes.c_int, [ctypes.c_void_p, u32p]),
+    "crp_offtarget_reset": (ctypes.c_int, [ctypes.c_void_p]),
+    "crp_offtarget_add": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, u64p, ctypes.c_uint64, u64p]),
+    "crp_offtarget_reduce": (ctypes.c_int, [ctypes.c_void_p]),
+    "crp_offtarget_solve": (ctypes.c_int, [ctypes.c_void_p]),
+    "crp_offtarget_counts": (ctypes.c_int, [ctypes.c_void_p, u32p, u32p]),
+    "crp_offtarget_seeds": (ctypes.c_int, [ctypes.c_void_p, u32p, u32p]),
     "crp_configure": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int64]),
+    "crp_query": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int64)]),
+    "crp_build_id": (ctypes.c_char_p, []),
+    "crp_profile_read_kind": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, f64p, u64p, ctypes.c_int]),
+    "crp_count_scored": (ctypes.c_int, [ctypes.c_void_p, u64p]),
     "crp_profile_enable": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "crp_profile_read": (ctypes.c_int, [ctypes.c_void_p, f64p, u64p, ctypes.c_int]),
     "crp_synchronize": (ctypes.c_int, [ctypes.c_void_p]),
@@ -55,9 +76,18 @@ SIGNATURES = {
 
 CRP_OK = 0
 ORDER_BODY4, ORDER_TAIL2, ORDER_DOT1 = 0, 1, 2
-OPT_TWO_PASS = 1
+OPT_TWO_PASS, OPT_CHAIN_TIMEOUT_US = 1, 2
+Q_CHAIN_TIMEOUTS, Q_TWO_PASS_ACTIVE, Q_COMM_WORLD, Q_COMM_RANK = 1, 2, 3, 4
+KINDS = ("count", "tile_scan", "emit_score", "ot_seed", "ot_ball", "ot_lookup", "gatherv", "ot_reduce")  # CRP_K_*
+REDUCE_SUM, REDUCE_MAX = 0, 1
+COMM_ID_BYTES = 128
+GATHER_OFFTARGET, GATHER_PRE = 1, 2
+OT_SEEDS = 1 << 24
+OT_NOT_A_SITE, OT_NOT_OWNED = 0xFFFFFFFF, 0xFFFFFFFE
+ABI_VERSION = 2
 CRP_ERR_NO_DEVICE = -2
 CRP_ERR_IO = -8
+CRP_ERR_COMM = -9
 
 _lib = None
 
@@ -84,7 +114,7 @@ def lib():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
-        if L.crp_abi_version() != 1:
+        if L.crp_abi_version() != ABI_VERSION:
             raise ImportError("libcropsr_hip.so ABI version mismatch")
         _lib = L
     return _lib

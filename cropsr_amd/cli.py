@@ -14,6 +14,8 @@ import sys
 import time
 from multiprocessing import cpu_count
 
+import numpy as np
+
 from . import fasta, rows
 
 __version__ = "1.11b"  # the CROPSR version whose behaviour is reproduced
@@ -68,6 +70,22 @@ def build_parser():
                           "CROPSR.py:407, which makes multi-contig genomes quadratic)")
     eng.add_argument("--reference-sleep", action="store_true",
                      help="also reproduce the reference's 5 s pause per contig")
+    eng.add_argument("--score-finalize", choices=["gpu", "host"], default="gpu",
+                     help="gpu (default): on_site_score comes from the GPU, whose exp is glibc's -- the bytes the "
+                          "reference prints on a host without AVX-512; host: the GPU delivers the pre-sigmoid sum "
+                          "(CROPSR.py:312) and THIS host's numpy applies 1/(1+np.exp(.)) (CROPSR.py:313), so the CSV "
+                          "equals what the reference prints on this very host (numpy's exp differs in the last bit "
+                          "between CPU families)")
+    eng.add_argument("--offtarget", action="store_true",
+                     help="NOT in the reference: genome-wide off-target seed scan; appends four columns "
+                          "offtarget_seed_mm0..3 (other PAM-adjacent sites whose 12-nt PAM-proximal seed differs in "
+                          "0..3 places; -1 where the guide has no 12-base seed)")
+    eng.add_argument("--annotate", action="store_true",
+                     help="NOT in the reference (which parses the GFF and drops it, CROPSR.py:375): fill the "
+                          "`features` column with the gene/CDS rows of the GFF (-g) that contain the cut site, "
+                          "named through the Phytozome annotation_info file (-p) when given")
+    eng.add_argument("--bench-json", metavar="PATH", default=None,
+                     help="write stage timings of this run (read, upload+scan, fetch, format+write) as one JSON object")
     return p
 
 
@@ -91,91 +109,205 @@ def import_gff_file(gff, verbose, out=sys.stdout):
     return table
 
 
+class EngineResident:
+    """Hit tables of this rank's texts, still in HBM (parallel.sharded_scan's Resident)."""
+
+    def __init__(self, backend, genome, counts, guide_len, want_pre):
+        self.backend, self.genome, self.counts = backend, genome, counts
+        self.guide_len, self.want_pre = guide_len, want_pre
+        self.layout = []
+        for k in range(genome.n_contigs):
+            a, j = genome._where[k]
+            self.layout.append((a, int(genome.arenas[a].offsets[j]), int(genome.arenas[a].lengths[j])))
+        self._ot = False
+
+    def offtarget(self, group, own_by_arena):
+        eng = self.backend.engine
+        eng.offtarget_reset()
+        for a, arena in enumerate(self.genome.arenas):
+            own = own_by_arena[a] if a < len(own_by_arena) else []
+            arena.offtarget_add(self.guide_len, np.asarray(own, dtype=np.uint64).reshape(-1, 2))
+        if self.backend.transport == "rccl":
+            eng.offtarget_reduce()  # the histogram is summed over the ranks on xGMI
+        else:  # ranks sharing a GPU: sum the (sparse) histograms over the control sockets
+            h = eng.offtarget_hist()
+            idx = np.flatnonzero(h)
+            total = np.zeros_like(h)
+            for i, v in group.all_gather((idx, h[idx])):
+                np.add.at(total, i, v)
+            eng.offtarget_hist(total)
+        eng.offtarget_solve()
+        for arena, (n_plus, n_minus) in zip(self.genome.arenas, self.counts):
+            arena.offtarget_counts(n_plus, n_minus, fetch=False)
+        self._ot = True
+
+    def _host_cols(self, arena, n_plus, n_minus, offtarget):
+        c = arena.fetch(n_plus, n_minus, self.want_pre)
+        cols = {"pos_plus": c[0], "score_plus": c[1] if self.want_pre else c[2],
+                "pos_minus": c[3], "score_minus": c[4] if self.want_pre else c[5]}
+        if offtarget:
+            cols["ot_plus"], cols["ot_minus"] = arena.offtarget_counts(n_plus, n_minus)
+        return cols
+
+    def gather(self, group, dst, offtarget):
+        """[rank][arena] -> column dict on dst.  With want_pre the f64 column carries the pre-sigmoid
+        sum (the root finalises the score on its host)."""
+        from . import parallel
+        eng = self.backend.engine
+        if self.backend.transport != "rccl":
+            mine = [self._host_cols(a, n[0], n[1], offtarget) for a, n in zip(self.genome.arenas, self.counts)]
+            return parallel.gather_host(group, mine, dst, offtarget)
+        n_arenas = group.all_gather(len(self.genome.arenas))
+        out = [[] for _ in range(group.world)]
+        for rnd in range(max(n_arenas)):
+            arena = self.genome.arenas[rnd] if rnd < len(self.genome.arenas) else None
+            err, counts = None, None
+            try:
+                counts = eng.gather_hits(arena, dst, offtarget, pre=self.want_pre)
+            except Exception as e:
+                err = "%s: %s" % (type(e).__name__, e)
+            group.check(err)
+            if group.rank == dst:
+                for r in range(group.world):
+                    if rnd < n_arenas[r]:
+                        out[r].append(eng.gathered_fetch(r, counts, offtarget))
+        return out if group.rank == dst else None
+
+    def release(self):
+        self.genome.close()
+
+
 class EngineBackend:
     """The product's hit provider: libcropsr_hip.so on one MI355X."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, group=None, finalize="gpu"):
+        import os
         from .engine import Engine
         self.engine = Engine(device)
+        self.finalize = finalize
+        self.group = group
+        # rccl: the tables cross xGMI inside the library; host: every rank copies its tables over its
+        # own PCIe link and the control sockets carry them (ranks sharing one GPU, where RCCL cannot run)
+        self.transport = os.environ.get("CROPSR_GATHER", "rccl")
 
-    def scan(self, contig_strings, guide_len):
+    def connect(self):
+        """Collective over the group: create the RCCL communicator (transport "rccl")."""
+        if self.group is not None and self.transport == "rccl":
+            self.engine.comm_init(self.group)
+
+    def _finalize(self, hits):
+        """--score-finalize=host: CROPSR.py:313 on this host's numpy, from the GPU's pre-sigmoid sum."""
+        for strand in ("plus", "minus"):
+            pre = hits.pop("pre_" + strand, None)
+            if pre is not None and self.finalize == "host":
+                hits["score_" + strand] = host_sigmoid(pre)
+        return hits
+
+    def scan(self, contig_strings, guide_len, offtarget=False):
         """One arena pass on the GPU for all contig strings (seam 1 + 2)."""
         genome = self.engine.genome(contig_strings)  # as many arenas as the genome needs
-        hits = genome.scan_score(guide_len, want_pre=False)
-        out = [hits.contig(k) for k in range(len(contig_strings))]
+        hits = genome.scan_score(guide_len, want_pre=self.finalize == "host", offtarget=offtarget)
+        out = [self._finalize(hits.contig(k)) for k in range(len(contig_strings))]
         genome.close()
         return out
 
-    def scan_tables(self, texts, guide_len):
-        """The same scan with the tables left in HBM, for parallel.sharded_scan: torch views of the
-        library's device tables (zero copy), the arena layout, and a release callback."""
-        from . import _native as nat
-        from . import parallel
-        L = nat.lib()
-        need = sum(int(L.crp_arena_words_for(len(t))) for t in texts)
-        if int(L.crp_arena_words_total(need)) > int(L.crp_arena_max_words()):
-            raise ValueError("this rank's share of the genome (%d characters) does not fit one arena of 2^31 "
-                             "characters: run on more GPUs" % sum(len(t) for t in texts))
-        arena = self.engine.arena(texts)
-        n_plus, n_minus = arena.scan_score_device(guide_len, want_pre=False)
-        tables = parallel.device_tables_as_tensors(arena, n_plus, n_minus)
-        return tables, list(zip(arena.offsets, arena.lengths)), arena.close
+    def scan_resident(self, texts, guide_len):
+        """The same scan with the tables left in HBM, for parallel.sharded_scan."""
+        want_pre = self.finalize == "host"
+        genome = self.engine.genome(texts)
+        counts = [a.scan_score_device(guide_len, want_pre) for a in genome.arenas]
+        return EngineResident(self, genome, counts, guide_len, want_pre)
+
+    def finalize_gathered(self, all_hits):
+        """Root, after a sharded scan with --score-finalize=host: the gathered f64 column is `pre`."""
+        if self.finalize == "host":
+            for h in all_hits:
+                for strand in ("plus", "minus"):
+                    h["score_" + strand] = host_sigmoid(h["score_" + strand])
+        return all_hits
 
     def rescore(self, rows_u8, order):
         """Seam 2 on a few rows in one of the BLAS tail orders (rows.Dataset.rows)."""
-        return self.engine.score_30mers(rows_u8, order)[1]
+        pre, score = self.engine.score_30mers(rows_u8, order)
+        return host_sigmoid(pre) if self.finalize == "host" else score
 
     def close(self):
         self.engine.close()
 
 
+def host_sigmoid(pre):
+    """`1/(1+np.exp(score))` of CROPSR.py:313 -- the reference's own expression, evaluated by the numpy
+    of the host this runs on (so its last bit is this host's, like the reference's)."""
+    with np.errstate(over="ignore"):
+        return 1 / (1 + np.exp(np.asarray(pre, dtype=np.float64)))
+
+
 def _distributed():
-    """(rank, world) when launched by torch.distributed.run with more than one process, else None.
-    One process per GPU; the process group is RCCL (backend "nccl") unless CROPSR_DIST_BACKEND
-    names another one (gloo: CPU rehearsals and the tests)."""
-    import os
-    if int(os.environ.get("WORLD_SIZE", "1")) <= 1:
-        return None
-    import torch  # noqa: F401  (before the engine: PyTorch-ROCm brings its own HIP runtime)
-    import torch.distributed as dist
-    if not dist.is_initialized():
-        name = os.environ.get("CROPSR_DIST_BACKEND", "nccl")
-        if name == "nccl":
-            local = int(os.environ.get("LOCAL_RANK", "0"))
-            torch.cuda.set_device(local)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-        else:
-            dist.init_process_group(name)
-    return dist.get_rank(), dist.get_world_size()
+    """The rendezvous.Group of a multi-process launch (python -m torch.distributed.run ... -m cropsr_amd
+    or any launcher that exports RANK / WORLD_SIZE / LOCAL_RANK / MASTER_PORT), else None.  One process
+    per GPU; no PyTorch: the control plane is rendezvous.py, the data plane RCCL inside the library."""
+    from . import rendezvous
+    return rendezvous.Group.from_env()
 
 
-def run(args, backend=None, out=sys.stdout):
+def check_guide_length(l):
+    """The engine scans guide lengths 1..50 (the reference takes any integer; lengths outside that
+    range give it no rows, or Python-slice artefacts).  Checked before ANY side effect, on every rank."""
+    if not 1 <= l <= 50:
+        sys.exit("cropsr_amd: -l/--length must be between 1 and 50 (got %d)" % l)
+
+
+def run(args, backend=None, out=sys.stdout, group=None):
     """main() of the reference (CROPSR.py:333-486) with the hot path swapped out.
 
     `backend` provides scan(contig_strings, guide_len) -> [hits dict per contig]
     and rescore(rows_u8, order) -> scores; it defaults to the HIP engine.  The CPU
     test-suite injects the oracle here to pin this host logic against the golden
-    CSVs without a GPU.
+    CSVs without a GPU.  `group`: the rendezvous.Group of a multi-process run
+    (default: from the launcher's environment).
     """
+    import os
     begin = time.time()
     if not args.cas9:
         sys.exit("Please select at least one CRISPR system: Cas9")  # CROPSR.py:335-336
-    shard = _distributed()
-    if shard is not None and shard[0] != 0:
-        # Ranks other than 0 of a multi-GPU run (python -m torch.distributed.run ... -m cropsr_amd):
-        # read the same FASTA, scan their share of the contigs, hand the tables to rank 0 -- which
-        # alone prints, draws ids and writes files -- and leave.
-        import os
+    check_guide_length(args.l)
+    offtarget = bool(getattr(args, "offtarget", False))
+    finalize = getattr(args, "score_finalize", "gpu")
+    stages = {}  # --bench-json
+    own_group = group is None
+    if own_group:
+        group = _distributed()
+    max_piece = int(os.environ.get("CROPSR_DIST_MAX_PIECE", "0")) or None
+
+    def make_backend():
+        device = getattr(args, "device", None)
+        if device is None:
+            device = group.local_rank if group is not None else 0
+        return EngineBackend(device, group, finalize)
+
+    if group is not None and group.rank != 0:
+        # Ranks other than 0 of a multi-GPU run: read the same FASTA, scan their share of the contigs,
+        # hand the tables to rank 0 -- which alone prints, draws ids and writes files -- and leave.
+        # Whatever fails here is reported to every rank (group.check inside sharded_scan).
         from . import parallel
-        table = fasta.table_from_bytes(fasta.read_text_bytes(args.f))
         own_backend = backend is None
-        if own_backend:
-            device = getattr(args, "device", None)
-            backend = EngineBackend(int(os.environ.get("LOCAL_RANK", "0")) if device is None else device)
-        parallel.sharded_scan(backend, [v for _, v in table], args.l,
-                              max_piece=int(os.environ.get("CROPSR_DIST_MAX_PIECE", "0")) or None)
-        if own_backend:
-            backend.close()
+        err, strings = None, []
+        try:
+            strings = [v for _, v in fasta.table_from_bytes(fasta.read_text_bytes(args.f))]
+            if own_backend:
+                backend = make_backend()
+        except Exception as e:
+            err = "%s: %s" % (type(e).__name__, e)
+        try:
+            group.check(err)
+            if hasattr(backend, "connect"):
+                backend.connect()
+            parallel.sharded_scan(backend, strings, args.l, group, max_piece=max_piece, offtarget=offtarget)
+        finally:
+            if own_backend and backend is not None:
+                backend.close()
+            if own_group:
+                group.close()
         return
     verbose = args.verbose
     if verbose:
@@ -197,14 +329,17 @@ def run(args, backend=None, out=sys.stdout):
     timing = open("time.txt", "w")  # CROPSR.py:371 (CWD side effect, kept)
 
     # CROPSR.py:374, 54-74 -- read as text mode would (universal newlines), kept as bytes
+    t_stage = time.perf_counter()
     data = fasta.read_text_bytes(args.f)
     if verbose:
         print(f"Genome file {args.f} successfully imported", file=out)
         if 2 * data.count(b">") != data.count(b"\n") + 1:
             print("formatting genome", file=out)
             print(f"Genome file {args.f} successfully formatted", file=out)
+    formatted = 2 * data.count(b">") != data.count(b"\n") + 1 if getattr(args, "annotate", False) else None
     table = fasta.table_from_bytes(data)  # == fasta.contig_table(text).items(), without printing the genome
     del data
+    stages["read_fasta_s"] = time.perf_counter() - t_stage
     if verbose:
         print("The genome was successfully converted to a dictionary", file=out)
     import_gff_file(args.g, verbose, out)  # CROPSR.py:375 (raises like the reference if -g is missing)
@@ -215,27 +350,38 @@ def run(args, backend=None, out=sys.stdout):
               "            Please wait, this may take a while...\n            ", file=out)
 
     if getattr(args, "seed", None) is not None:
-        import numpy as np
         np.random.seed(args.seed)
 
-    rows.write_header(args.o)  # CROPSR.py:402-405
+    rows.write_header(args.o, offtarget=offtarget)  # CROPSR.py:402-405
 
     names = [k for k, _ in table]
     strings = [v for _, v in table]  # contig strings as bytes, one byte per character
     own_backend = backend is None
-    if own_backend:
-        import os
-        device = getattr(args, "device", None)
-        if device is None:
-            device = int(os.environ.get("LOCAL_RANK", "0")) if shard is not None else 0
-        backend = EngineBackend(device)
-    if shard is None:
-        all_hits = backend.scan(strings, args.l)  # seam 1 + 2 for every contig, one GPU pass
+    t_stage = time.perf_counter()
+    if group is None:
+        if own_backend:
+            backend = make_backend()
+        all_hits = backend.scan(strings, args.l, offtarget=offtarget) if offtarget else backend.scan(strings, args.l)
     else:  # contigs (cut where longer than a rank's share) over all GPUs, tables gathered here
-        import os
         from . import parallel
-        all_hits = parallel.sharded_scan(backend, strings, args.l,
-                                         max_piece=int(os.environ.get("CROPSR_DIST_MAX_PIECE", "0")) or None)
+        err = None
+        try:
+            if own_backend:
+                backend = make_backend()
+        except Exception as e:
+            err = "%s: %s" % (type(e).__name__, e)
+        group.check(err)
+        if hasattr(backend, "connect"):
+            backend.connect()
+        all_hits = parallel.sharded_scan(backend, strings, args.l, group, max_piece=max_piece, offtarget=offtarget)
+        if hasattr(backend, "finalize_gathered"):
+            all_hits = backend.finalize_gathered(all_hits)
+    stages["upload_scan_fetch_s"] = time.perf_counter() - t_stage
+
+    annot = None
+    if getattr(args, "annotate", False):
+        from . import annotate
+        annot = annotate.Annotation(args.g, args.p)
 
     native = getattr(args, "csv_writer", "native") == "native"
     once = getattr(args, "each_contig_once", False)
@@ -245,13 +391,16 @@ def run(args, backend=None, out=sys.stdout):
         # every pass draws its ids from one RNG stream, in order; the pass sizes are known now,
         # so a worker draws pass k+1's ids while pass k is formatted and written
         per_contig = [int(h["pos_plus"].size + h["pos_minus"].size) for h in all_hits]
-        import numpy as np
         sizes = per_contig if once else np.cumsum(per_contig).tolist()
         ids = rows.IdStream(sizes, reverse=True)
+    t_stage = time.perf_counter()
+    n_rows_written = 0
     for name, s, hits in zip(names, strings, all_hits):
         print("Searching on Chromosome: ", name[:25], file=out)  # CROPSR.py:410-411
         print("With start of sequence: ", bytes(s[:25]).decode("latin-1"), file=out)
-        block = rows.ContigTable(name, s, hits, args.l) if native else rows.ContigRows(name, bytes(s).decode("latin-1"), hits, args.l)
+        feats = annot.for_contig(name, hits, args.l, 1 if formatted else 0, len(s)) if annot is not None else None
+        block = (rows.ContigTable(name, s, hits, args.l, features=feats) if native
+                 else rows.ContigRows(name, bytes(s).decode("latin-1"), hits, args.l, features=feats))
         if once:
             dataset = rows.NativeDataset() if native else rows.Dataset()  # opt-in fix of CROPSR.py:407
         dataset.append(block)
@@ -267,17 +416,30 @@ def run(args, backend=None, out=sys.stdout):
             rows.write_pass_native(args.o, dataset, backend.rescore, ids)
         else:
             rows.write_pass(args.o, dataset, backend.rescore)
+        n_rows_written += len(dataset)
         end = time.time()
         timing.write("Total runtime of the program is " + str(end - begin))  # CROPSR.py:477
         if getattr(args, "reference_sleep", False):
             time.sleep(5)  # CROPSR.py:478
+    stages["format_write_s"] = time.perf_counter() - t_stage
     timing.close()
     if ids is not None:
         ids.close()
     if own_backend:
         backend.close()
+    if own_group and group is not None:
+        group.close()
     if verbose:
         print(f"The output file has been generated at {args.o}", file=out)
+    if getattr(args, "bench_json", None):
+        import json
+        kept = int(sum(h["pos_plus"].size + h["pos_minus"].size for h in all_hits))
+        stages.update(total_s=time.time() - begin, contigs=len(strings), characters=int(sum(len(v) for v in strings)),
+                      kept_hits=kept, rows_written=int(n_rows_written), world=1 if group is None else group.world,
+                      gRNAs_per_s_end_to_end=kept / max(1e-9, time.time() - begin))
+        with open(args.bench_json, "w") as f:
+            json.dump(stages, f)
+            f.write("\n")
 
 
 def main(argv=None):

@@ -18,7 +18,7 @@
 #include <thread>
 #include <vector>
 
-#include "crp_kernels.h"
+#include "crp_internal.h"
 
 namespace {
 
@@ -31,63 +31,19 @@ inline uint64_t round_up(uint64_t x, uint64_t m) { return (x + m - 1) / m * m; }
 
 }  // namespace
 
-struct crp_ctx {
-    int device = -1;
-    hipStream_t stream = nullptr;
-    std::string last_error;
-    char name[128] = {0};
-    int n_cu = 0;
-    uint64_t hbm = 0;
-    // upload staging (characters) and seam-2 scratch
-    uint8_t *d_text = nullptr;
-    uint64_t d_text_cap = 0;
-    uint8_t *d_rows = nullptr;
-    double *d_rpre = nullptr, *d_rscore = nullptr;
-    uint64_t d_rows_cap = 0;
-    bool two_pass = false;  // CRP_OPT_TWO_PASS
-    uint64_t chain_timeouts = 0;  // single-pass scans that fell back to the three-launch sequence
-    uint32_t mute_tile = 0xffffffffu;  // test hook (environment CRP_TEST_MUTE_TILE): see crp_kernels.h
-    // measurement
-    int profiling = 0;  // 0 off, 1 emit kernel only, 2 all kernels
-    hipEvent_t ev[6] = {};  // profiling: start/stop pair per kernel kind
-    double ms[3] = {0, 0, 0};
-    uint64_t launches[3] = {0, 0, 0};
-};
-
-struct crp_arena {
-    crp_ctx *ctx = nullptr;
-    uint64_t cap_words = 0;     // what the caller asked for
-    uint64_t padded_words = 0;  // allocation per plane
-    uint64_t *d_plane[4] = {nullptr, nullptr, nullptr, nullptr};
-    uint64_t used_words = 1;    // word 0 is the leading separator
-    uint64_t n_contigs = 0, n_chars = 0;
-    bool sealed = false;
-    // per-tile scratch
-    uint2 *d_tile_cnt = nullptr, *d_tile_off = nullptr;
-    uint64_t *d_chain[2] = {nullptr, nullptr};  // single-pass mode: header + tile descriptors, used alternately
-    int chain_cur = 0;                          // the buffer the next single-pass launch uses (all zero)
-    uint64_t *d_totals = nullptr;
-    uint64_t *h_totals = nullptr;  // pinned
-    uint32_t n_tiles = 0;
-    // hit tables: [0] = '+', [1] = '-'
-    uint32_t *d_pos[2] = {nullptr, nullptr};
-    double *d_score[2] = {nullptr, nullptr};
-    double *d_pre[2] = {nullptr, nullptr};
-    uint64_t tab_cap[2] = {0, 0};
-    uint64_t pre_cap[2] = {0, 0};
-    uint64_t n_hits[2] = {0, 0};
-    bool have_hits = false, have_pre = false;
-};
-
-#define CRP_HIP(ctx, call)                                                              \
-    do {                                                                                \
-        hipError_t e__ = (call);                                                        \
-        if (e__ != hipSuccess) {                                                        \
-            (ctx)->last_error = std::string(#call) + ": " + hipGetErrorString(e__);     \
-            return e__ == hipErrorOutOfMemory ? CRP_ERR_NOMEM : CRP_ERR_HIP;            \
-        }                                                                               \
-    } while (0)
-
+namespace crp {
+int grow(crp_ctx *ctx, void **p, uint64_t *cap, uint64_t need, size_t elem)
+{
+    if (*cap >= need && *p) return CRP_OK;
+    (void)hipFree(*p);
+    *p = nullptr;
+    *cap = 0;
+    const uint64_t n = std::max<uint64_t>(need + need / 16, 64);
+    CRP_HIP(ctx, hipMalloc(p, n * elem));
+    *cap = n;
+    return CRP_OK;
+}
+}  // namespace crp
 extern "C" {
 
 int crp_abi_version(void) { return CRP_ABI_VERSION; }
@@ -137,6 +93,11 @@ int crp_init(int device_id, crp_ctx **out)
             crp_destroy(ctx);
             return CRP_ERR_HIP;
         }
+    if (hipMalloc(reinterpret_cast<void **>(&ctx->d_scalar), 8 * sizeof(uint64_t)) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void **>(&ctx->h_scalar), 8 * sizeof(uint64_t), hipHostMallocDefault) != hipSuccess) {
+        crp_destroy(ctx);
+        return CRP_ERR_NOMEM;
+    }
     if (const char *e = std::getenv("CRP_TEST_MUTE_TILE")) ctx->mute_tile = (uint32_t)std::strtoul(e, nullptr, 10);
     *out = ctx;
     return CRP_OK;
@@ -153,6 +114,11 @@ int crp_destroy(crp_ctx *ctx)
     (void)hipFree(ctx->d_rows);
     (void)hipFree(ctx->d_rpre);
     (void)hipFree(ctx->d_rscore);
+    (void)hipFree(ctx->d_scalar);
+    if (ctx->h_scalar) (void)hipHostFree(ctx->h_scalar);
+    (void)hipFree(ctx->d_ot_hist);
+    (void)hipFree(ctx->d_ot_ball);
+    crp::comm_release(ctx);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return CRP_OK;
@@ -255,6 +221,7 @@ int crp_arena_destroy(crp_arena *a)
     if (!a) return CRP_OK;
     (void)hipSetDevice(a->ctx->device);
     (void)hipStreamSynchronize(a->ctx->stream);
+    crp::comm_forget_arena(a->ctx, a);
     for (int p = 0; p < 4; ++p) (void)hipFree(a->d_plane[p]);
     (void)hipFree(a->d_tile_cnt);
     (void)hipFree(a->d_tile_off);
@@ -266,7 +233,10 @@ int crp_arena_destroy(crp_arena *a)
         (void)hipFree(a->d_pos[s]);
         (void)hipFree(a->d_score[s]);
         (void)hipFree(a->d_pre[s]);
+        (void)hipFree(a->d_ot_seed[s]);
+        (void)hipFree(a->d_ot_cnt[s]);
     }
+    (void)hipFree(a->d_ot_own);
     delete a;
     return CRP_OK;
 }
@@ -375,38 +345,10 @@ int crp_arena_stats(const crp_arena *a, uint64_t *n_contigs, uint64_t *n_chars, 
 }
 
 // --------------------------------------------------------------- scan+score
-static int grow(crp_ctx *ctx, void **p, uint64_t *cap, uint64_t need, size_t elem)
-{
-    if (*cap >= need && *p) return CRP_OK;
-    (void)hipFree(*p);
-    *p = nullptr;
-    *cap = 0;
-    const uint64_t n = std::max<uint64_t>(need + need / 16, 64);
-    CRP_HIP(ctx, hipMalloc(p, n * elem));
-    *cap = n;
-    return CRP_OK;
-}
-
-// event pair per kind: 0 = count, 1 = tile scan, 2 = emit (the whole scan in single-launch mode)
-// profiling level 1 brackets only the emit kernel (the one the roofline is quoted on; two event
-// records per step), level 2 all kernels
-static bool prof_on(const crp_ctx *ctx, int kind) { return ctx->profiling >= 2 || (ctx->profiling == 1 && kind == 2); }
-static void prof_begin(crp_ctx *ctx, int kind)
-{
-    if (prof_on(ctx, kind)) (void)hipEventRecord(ctx->ev[kind * 2], ctx->stream);
-}
-static void prof_end(crp_ctx *ctx, int kind)
-{
-    if (prof_on(ctx, kind)) (void)hipEventRecord(ctx->ev[kind * 2 + 1], ctx->stream);
-}
-static void prof_collect(crp_ctx *ctx, int kind)
-{
-    float ms = 0.f;
-    if (prof_on(ctx, kind) && hipEventElapsedTime(&ms, ctx->ev[kind * 2], ctx->ev[kind * 2 + 1]) == hipSuccess) {
-        ctx->ms[kind] += ms;
-        ctx->launches[kind] += 1;
-    }
-}
+using crp::grow;
+using crp::prof_begin;
+using crp::prof_collect;
+using crp::prof_end;
 
 static int reserve_tables(crp_arena *a, const uint64_t n[2], int want_pre)
 {
@@ -497,7 +439,8 @@ static int scan_single_pass(crp_arena *a, const crp::Planes &pl, uint64_t eff_wo
         const crp::HitTables out = table_args(a, want_pre);
         uint64_t *cur = a->d_chain[a->chain_cur], *next = a->d_chain[a->chain_cur ^ 1];
         prof_begin(ctx, 2);
-        CRP_HIP(ctx, crp::launch_emit_chained(ctx->stream, pl, eff_words, guide_len, cur, next, out, ctx->mute_tile));
+        CRP_HIP(ctx, crp::launch_emit_chained(ctx->stream, pl, eff_words, guide_len, cur, next, out, ctx->mute_tile,
+                                                  ctx->chain_timeout_ticks));
         prof_end(ctx, 2);
         // header: ticket | fail << 32, total '+', total '-'
         CRP_HIP(ctx, hipMemcpyAsync(a->h_totals, cur, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -532,17 +475,23 @@ int crp_scan_score(crp_arena *a, int guide_len, int want_pre, uint64_t *n_plus, 
     crp::Planes pl{{a->d_plane[0], a->d_plane[1], a->d_plane[2], a->d_plane[3]}};
     uint64_t n[2] = {0, 0};
     int rc;
-    if (ctx->two_pass) {
+    if (ctx->two_pass || ctx->two_pass_latched) {
         rc = scan_two_pass(a, pl, eff_words, guide_len, want_pre, n);
     } else {
         bool chain_failed = false;
         rc = scan_single_pass(a, pl, eff_words, guide_len, want_pre, n, &chain_failed);
-        if (chain_failed) {  // never seen; results stay right either way
-            ctx->two_pass = true;
+        if (chain_failed) {
+            // A workgroup waited longer than CRP_OPT_CHAIN_TIMEOUT_US for a predecessor's counts (a
+            // shared or pre-empted GPU can do that; a wrong assumption about dispatch order would
+            // too).  Nothing of that launch is used: this scan runs again as three launches.  The
+            // next scan tries the single launch again; three failures in a row latch.
             ctx->chain_timeouts++;
-            ctx->last_error = "single-launch scan: a chained look-back timed out; the scan was repeated with the "
-                              "count / scan / emit sequence, which this context uses from now on";
+            if (++ctx->timeout_streak >= 3) ctx->two_pass_latched = true;
+            ctx->last_error = "single-launch scan: a chained look-back timed out; this scan was repeated with the "
+                              "count / scan / emit sequence";
             rc = scan_two_pass(a, pl, eff_words, guide_len, want_pre, n);
+        } else if (rc == CRP_OK) {
+            ctx->timeout_streak = 0;
         }
     }
     if (rc != CRP_OK) return rc;
@@ -639,13 +588,67 @@ int crp_profile_read(crp_ctx *ctx, double ms[3], uint64_t launches[3], int reset
     return CRP_OK;
 }
 
+int crp_profile_read_kind(crp_ctx *ctx, int kind, double *ms, uint64_t *launches, int reset)
+{
+    if (!ctx || kind < 0 || kind >= CRP_K_KINDS) return CRP_ERR_INVALID;
+    if (ms) *ms = ctx->ms[kind];
+    if (launches) *launches = ctx->launches[kind];
+    if (reset) {
+        ctx->ms[kind] = 0;
+        ctx->launches[kind] = 0;
+    }
+    return CRP_OK;
+}
+
 int crp_configure(crp_ctx *ctx, int option, int64_t value)
 {
     if (!ctx) return CRP_ERR_INVALID;
     switch (option) {
-        case CRP_OPT_TWO_PASS: ctx->two_pass = value != 0; return CRP_OK;
+        case CRP_OPT_TWO_PASS:
+            ctx->two_pass = value != 0;
+            if (!ctx->two_pass) {  // asking for the single launch again clears a latch
+                ctx->two_pass_latched = false;
+                ctx->timeout_streak = 0;
+            }
+            return CRP_OK;
+        case CRP_OPT_CHAIN_TIMEOUT_US:
+            if (value < 1 || value > 10000000) return CRP_ERR_INVALID;
+            ctx->chain_timeout_ticks = (uint32_t)(value * 100);  // 100 MHz counter
+            return CRP_OK;
         default: return CRP_ERR_INVALID;
     }
+}
+
+int crp_query(const crp_ctx *ctx, int what, int64_t *value)
+{
+    if (!ctx || !value) return CRP_ERR_INVALID;
+    switch (what) {
+        case CRP_Q_CHAIN_TIMEOUTS: *value = (int64_t)ctx->chain_timeouts; return CRP_OK;
+        case CRP_Q_TWO_PASS_ACTIVE: *value = (ctx->two_pass || ctx->two_pass_latched) ? 1 : 0; return CRP_OK;
+        case CRP_Q_COMM_WORLD: *value = crp::comm_world(ctx); return CRP_OK;
+        case CRP_Q_COMM_RANK: *value = crp::comm_rank(ctx); return CRP_OK;
+        default: return CRP_ERR_INVALID;
+    }
+}
+
+#ifndef CRP_BUILD_ID
+#define CRP_BUILD_ID "unknown"
+#endif
+const char *crp_build_id(void) { return CRP_BUILD_ID; }
+
+int crp_count_scored(crp_arena *a, uint64_t *n_scored)
+{
+    if (!a || !n_scored) return CRP_ERR_INVALID;
+    if (!a->have_hits) return CRP_ERR_STATE;
+    crp_ctx *ctx = a->ctx;
+    CRP_HIP(ctx, hipSetDevice(ctx->device));
+    CRP_HIP(ctx, hipMemsetAsync(ctx->d_scalar, 0, sizeof(uint64_t), ctx->stream));
+    for (int s = 0; s < 2; ++s)
+        CRP_HIP(ctx, crp::launch_count_scored(ctx->stream, a->d_score[s], a->n_hits[s], ctx->d_scalar));
+    CRP_HIP(ctx, hipMemcpyAsync(ctx->h_scalar, ctx->d_scalar, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    CRP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *n_scored = ctx->h_scalar[0];
+    return CRP_OK;
 }
 
 int crp_synchronize(crp_ctx *ctx)

@@ -1,0 +1,345 @@
+// crp_comm.cpp -- the multi-GPU exchange of the path, on RCCL, inside the library.
+//
+// One process per GPU.  The scan itself needs no collective (contigs are independent,
+// CROPSR.py:409); what crosses xGMI is
+//   * crp_gather_hits      the final gatherv of the per-rank hit tables to a root.  RCCL has no
+//                          gatherv primitive: ncclAllGather of the two counts, then
+//                          ncclGroupStart / ncclSend (peers) | ncclRecv (root), one per column /
+//                          ncclGroupEnd.  Every peer->root transfer rides its own point-to-point
+//                          xGMI link, so the step is bounded by one link, not by a ring;
+//   * crp_offtarget_reduce (crp_offtarget.hip) the all-reduce of the 64 MiB site histogram;
+//   * crp_comm_barrier / crp_comm_allreduce_f64: bench fences and sums.
+// librccl.so is loaded with dlopen on the first crp_comm_* call -- a single-GPU process never
+// pays for it, and the library has no link-time dependency on RCCL.  The communicator's unique id is
+// created here (rank 0) and carried to the other ranks by the host (cropsr_amd/rendezvous.py).
+#include <dlfcn.h>
+
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <vector>
+
+#include <rccl/rccl.h>
+
+#include "crp_internal.h"
+
+namespace {
+
+struct Rccl {
+    void *handle = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommAbort) CommAbort = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    std::string error;
+};
+
+Rccl g_rccl;
+std::once_flag g_rccl_once;
+
+template <class F>
+bool bind(void *h, const char *name, F &fn)
+{
+    fn = reinterpret_cast<F>(dlsym(h, name));
+    return fn != nullptr;
+}
+
+const Rccl *rccl()
+{
+    std::call_once(g_rccl_once, [] {
+        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        void *h = nullptr;
+        for (const char *n : names)
+            if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+        if (!h) {
+            g_rccl.error = std::string("dlopen(librccl.so.1): ") + (dlerror() ? dlerror() : "not found");
+            return;
+        }
+        Rccl &r = g_rccl;
+        const bool ok = bind(h, "ncclGetUniqueId", r.GetUniqueId) && bind(h, "ncclCommInitRank", r.CommInitRank) &&
+                        bind(h, "ncclCommDestroy", r.CommDestroy) && bind(h, "ncclCommAbort", r.CommAbort) &&
+                        bind(h, "ncclAllGather", r.AllGather) && bind(h, "ncclAllReduce", r.AllReduce) &&
+                        bind(h, "ncclSend", r.Send) && bind(h, "ncclRecv", r.Recv) &&
+                        bind(h, "ncclGroupStart", r.GroupStart) && bind(h, "ncclGroupEnd", r.GroupEnd) &&
+                        bind(h, "ncclGetErrorString", r.GetErrorString);
+        if (!ok) {
+            g_rccl.error = "librccl.so lacks a required symbol";
+            return;
+        }
+        r.handle = h;
+    });
+    return g_rccl.handle ? &g_rccl : nullptr;
+}
+
+}  // namespace
+
+struct crp_comm {
+    ncclComm_t comm = nullptr;
+    int rank = 0, world = 0;
+    // scratch in HBM: counts (2 per rank) and small reductions
+    uint64_t *d_counts = nullptr;  // 2 * world
+    double *d_small = nullptr;     // 64 doubles in, 64 out
+    std::vector<uint64_t> counts;  // last gather: {n_plus, n_minus} per rank
+    // root's receive side of the last crp_gather_hits: column-wise, peers back to back in rank order
+    uint32_t *d_gpos[2] = {nullptr, nullptr};
+    double *d_gscore[2] = {nullptr, nullptr};
+    uint4 *d_got[2] = {nullptr, nullptr};  // CRP_GATHER_OFFTARGET: per-hit counts
+    uint64_t gpos_cap[2] = {0, 0}, gscore_cap[2] = {0, 0}, got_cap[2] = {0, 0};
+    int gflags = 0;
+    std::vector<uint64_t> goff[2];  // element offset of every rank's slice (root's own slice: unused)
+    int groot = -1;
+    crp_arena *garena = nullptr;    // root's own contribution stays in its arena
+    bool have_gather = false;
+};
+
+#define CRP_NCCL(ctx, call)                                                                       \
+    do {                                                                                          \
+        ncclResult_t r__ = (call);                                                                \
+        if (r__ != ncclSuccess) {                                                                 \
+            (ctx)->last_error = std::string(#call) + ": " + rccl()->GetErrorString(r__);          \
+            return CRP_ERR_COMM;                                                                  \
+        }                                                                                         \
+    } while (0)
+
+namespace crp {
+
+void comm_release(crp_ctx *ctx)
+{
+    crp_comm *c = ctx->comm;
+    if (!c) return;
+    if (c->comm && rccl()) (void)rccl()->CommDestroy(c->comm);
+    (void)hipFree(c->d_counts);
+    (void)hipFree(c->d_small);
+    for (int s = 0; s < 2; ++s) {
+        (void)hipFree(c->d_gpos[s]);
+        (void)hipFree(c->d_gscore[s]);
+        (void)hipFree(c->d_got[s]);
+    }
+    delete c;
+    ctx->comm = nullptr;
+}
+
+// crp_arena_destroy: the root's own rows of the last gather lived in this arena
+void comm_forget_arena(crp_ctx *ctx, const crp_arena *a)
+{
+    if (ctx->comm && ctx->comm->garena == a) {
+        ctx->comm->garena = nullptr;
+        ctx->comm->have_gather = false;
+    }
+}
+
+int comm_world(const crp_ctx *ctx) { return ctx->comm ? ctx->comm->world : 0; }
+int comm_rank(const crp_ctx *ctx) { return ctx->comm ? ctx->comm->rank : 0; }
+
+// used by crp_offtarget.hip: in-place sum of n uint32 over all ranks (no-op without a communicator)
+int comm_allreduce_u32(crp_ctx *ctx, uint32_t *d_buf, uint64_t n)
+{
+    crp_comm *c = ctx->comm;
+    if (!c || c->world == 1) return CRP_OK;
+    CRP_NCCL(ctx, rccl()->AllReduce(d_buf, d_buf, n, ncclUint32, ncclSum, c->comm, ctx->stream));
+    return CRP_OK;
+}
+
+}  // namespace crp
+
+extern "C" {
+
+int crp_comm_unique_id(uint8_t id[CRP_COMM_ID_BYTES])
+{
+    static_assert(CRP_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "unique id size");
+    if (!id) return CRP_ERR_INVALID;
+    const Rccl *r = rccl();
+    if (!r) return CRP_ERR_COMM;
+    ncclUniqueId u;
+    if (r->GetUniqueId(&u) != ncclSuccess) return CRP_ERR_COMM;
+    std::memcpy(id, u.internal, CRP_COMM_ID_BYTES);
+    return CRP_OK;
+}
+
+int crp_comm_init(crp_ctx *ctx, const uint8_t id[CRP_COMM_ID_BYTES], int rank, int world)
+{
+    if (!ctx || !id || world < 1 || rank < 0 || rank >= world) return CRP_ERR_INVALID;
+    if (ctx->comm) return CRP_ERR_STATE;
+    const Rccl *r = rccl();
+    if (!r) {
+        ctx->last_error = g_rccl.error;
+        return CRP_ERR_COMM;
+    }
+    CRP_HIP(ctx, hipSetDevice(ctx->device));
+    crp_comm *c = new (std::nothrow) crp_comm();
+    if (!c) return CRP_ERR_NOMEM;
+    c->rank = rank;
+    c->world = world;
+    ctx->comm = c;
+    ncclUniqueId u;
+    std::memcpy(u.internal, id, CRP_COMM_ID_BYTES);
+    ncclResult_t st = r->CommInitRank(&c->comm, world, u, rank);
+    if (st != ncclSuccess) {
+        ctx->last_error = std::string("ncclCommInitRank: ") + r->GetErrorString(st);
+        c->comm = nullptr;
+        crp::comm_release(ctx);
+        return CRP_ERR_COMM;
+    }
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&c->d_counts), 2 * (size_t)world * sizeof(uint64_t));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->d_small), 128 * sizeof(double));
+    if (e != hipSuccess) {
+        ctx->last_error = std::string("communicator scratch: ") + hipGetErrorString(e);
+        crp::comm_release(ctx);
+        return CRP_ERR_NOMEM;
+    }
+    c->counts.assign(2 * (size_t)world, 0);
+    return CRP_OK;
+}
+
+int crp_comm_destroy(crp_ctx *ctx)
+{
+    if (!ctx) return CRP_ERR_INVALID;
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    crp::comm_release(ctx);
+    return CRP_OK;
+}
+
+int crp_comm_allreduce_f64(crp_ctx *ctx, double *values, int n, int op)
+{
+    if (!ctx || !values || n < 1 || n > 64 || (op != CRP_REDUCE_SUM && op != CRP_REDUCE_MAX)) return CRP_ERR_INVALID;
+    crp_comm *c = ctx->comm;
+    if (!c) return CRP_ERR_STATE;
+    CRP_HIP(ctx, hipSetDevice(ctx->device));
+    CRP_HIP(ctx, hipMemcpyAsync(c->d_small, values, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    CRP_NCCL(ctx, rccl()->AllReduce(c->d_small, c->d_small + 64, (size_t)n, ncclDouble, op == CRP_REDUCE_SUM ? ncclSum : ncclMax,
+                                    c->comm, ctx->stream));
+    CRP_HIP(ctx, hipMemcpyAsync(values, c->d_small + 64, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    CRP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CRP_OK;
+}
+
+int crp_comm_barrier(crp_ctx *ctx)
+{
+    double one = 1.0;
+    return crp_comm_allreduce_f64(ctx, &one, 1, CRP_REDUCE_SUM);
+}
+
+int crp_gather_hits(crp_ctx *ctx, crp_arena *a, int root, int flags, uint64_t *counts_all)
+{
+    if (!ctx) return CRP_ERR_INVALID;
+    crp_comm *c = ctx->comm;
+    if (!c) return CRP_ERR_STATE;
+    if (root < 0 || root >= c->world || (flags & ~(CRP_GATHER_OFFTARGET | CRP_GATHER_PRE))) return CRP_ERR_INVALID;
+    if (a && (a->ctx != ctx || !a->have_hits)) return CRP_ERR_STATE;
+    const bool send_pre = (flags & CRP_GATHER_PRE) != 0;
+    if (send_pre && a && !a->have_pre) return CRP_ERR_STATE;
+    const bool with_ot = (flags & CRP_GATHER_OFFTARGET) != 0;
+    if (with_ot && a && (!ctx->ot_solved || a->ot_epoch != ctx->ot_epoch)) return CRP_ERR_STATE;
+    const Rccl *r = rccl();
+    CRP_HIP(ctx, hipSetDevice(ctx->device));
+    c->have_gather = false;
+    const uint64_t mine[2] = {a ? a->n_hits[0] : 0, a ? a->n_hits[1] : 0};
+    crp::prof_begin(ctx, CRP_K_GATHER);
+    // 1. everyone learns every rank's two counts
+    CRP_HIP(ctx, hipMemcpyAsync(c->d_counts + 2 * c->rank, mine, sizeof mine, hipMemcpyHostToDevice, ctx->stream));
+    CRP_NCCL(ctx, r->AllGather(c->d_counts + 2 * c->rank, c->d_counts, 2, ncclUint64, c->comm, ctx->stream));
+    CRP_HIP(ctx, hipMemcpyAsync(c->counts.data(), c->d_counts, 2 * (size_t)c->world * sizeof(uint64_t),
+                                hipMemcpyDeviceToHost, ctx->stream));
+    CRP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (counts_all) std::memcpy(counts_all, c->counts.data(), 2 * (size_t)c->world * sizeof(uint64_t));
+    // 2. the tables: grouped point-to-point, peers -> root
+    if (c->rank == root) {
+        for (int s = 0; s < 2; ++s) {
+            c->goff[s].assign((size_t)c->world, 0);
+            uint64_t total = 0;
+            for (int p = 0; p < c->world; ++p) {
+                c->goff[s][(size_t)p] = total;
+                if (p != root) total += c->counts[2 * (size_t)p + s];
+            }
+            int rc = crp::grow(ctx, reinterpret_cast<void **>(&c->d_gpos[s]), &c->gpos_cap[s], total, sizeof(uint32_t));
+            if (rc == CRP_OK)
+                rc = crp::grow(ctx, reinterpret_cast<void **>(&c->d_gscore[s]), &c->gscore_cap[s], total, sizeof(double));
+            if (rc == CRP_OK && with_ot)
+                rc = crp::grow(ctx, reinterpret_cast<void **>(&c->d_got[s]), &c->got_cap[s], total, sizeof(uint4));
+            if (rc != CRP_OK) return rc;  // (the peers' sends then fail with the communicator: the caller aborts)
+        }
+    }
+    CRP_NCCL(ctx, r->GroupStart());
+    ncclResult_t st = ncclSuccess;
+    if (c->rank == root) {
+        for (int p = 0; p < c->world && st == ncclSuccess; ++p) {
+            if (p == root) continue;
+            for (int s = 0; s < 2 && st == ncclSuccess; ++s) {
+                const uint64_t n = c->counts[2 * (size_t)p + s];
+                if (!n) continue;
+                st = r->Recv(c->d_gpos[s] + c->goff[s][(size_t)p], n, ncclUint32, p, c->comm, ctx->stream);
+                if (st == ncclSuccess)
+                    st = r->Recv(c->d_gscore[s] + c->goff[s][(size_t)p], n, ncclDouble, p, c->comm, ctx->stream);
+                if (st == ncclSuccess && with_ot)
+                    st = r->Recv(c->d_got[s] + c->goff[s][(size_t)p], 4 * n, ncclUint32, p, c->comm, ctx->stream);
+            }
+        }
+    } else {
+        for (int s = 0; s < 2 && st == ncclSuccess; ++s) {
+            if (!mine[s]) continue;
+            st = r->Send(a->d_pos[s], mine[s], ncclUint32, root, c->comm, ctx->stream);
+            if (st == ncclSuccess)
+                st = r->Send(send_pre ? a->d_pre[s] : a->d_score[s], mine[s], ncclDouble, root, c->comm, ctx->stream);
+            if (st == ncclSuccess && with_ot) st = r->Send(a->d_ot_cnt[s], 4 * mine[s], ncclUint32, root, c->comm, ctx->stream);
+        }
+    }
+    const ncclResult_t st_end = r->GroupEnd();
+    if (st != ncclSuccess || st_end != ncclSuccess) {
+        ctx->last_error = std::string("gatherv send/recv: ") + r->GetErrorString(st != ncclSuccess ? st : st_end);
+        return CRP_ERR_COMM;
+    }
+    crp::prof_end(ctx, CRP_K_GATHER);
+    // the sends read the arena's tables: they must have left before the caller may scan or destroy it
+    CRP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    crp::prof_collect(ctx, CRP_K_GATHER);
+    c->groot = root;
+    c->gflags = flags;
+    c->garena = a;
+    c->have_gather = true;
+    return CRP_OK;
+}
+
+int crp_gathered_fetch(crp_ctx *ctx, int rank, uint32_t *pos_plus, double *score_plus, uint32_t *ot_plus,
+                       uint32_t *pos_minus, double *score_minus, uint32_t *ot_minus)
+{
+    if (!ctx) return CRP_ERR_INVALID;
+    crp_comm *c = ctx->comm;
+    if (!c || !c->have_gather || c->rank != c->groot) return CRP_ERR_STATE;
+    if (rank < 0 || rank >= c->world) return CRP_ERR_INVALID;
+    CRP_HIP(ctx, hipSetDevice(ctx->device));
+    uint32_t *hp[2] = {pos_plus, pos_minus};
+    double *hs[2] = {score_plus, score_minus};
+    uint32_t *ho[2] = {ot_plus, ot_minus};
+    if ((ot_plus || ot_minus) && !(c->gflags & CRP_GATHER_OFFTARGET)) return CRP_ERR_STATE;
+    for (int s = 0; s < 2; ++s) {
+        const uint64_t n = c->counts[2 * (size_t)rank + s];
+        if (!n) continue;
+        const uint32_t *dp;
+        const double *ds;
+        const uint4 *dt = nullptr;
+        if (rank == c->groot) {  // root's own rows never moved
+            if (!c->garena || !c->garena->have_hits) return CRP_ERR_STATE;
+            dp = c->garena->d_pos[s];
+            ds = (c->gflags & CRP_GATHER_PRE) ? c->garena->d_pre[s] : c->garena->d_score[s];
+            dt = c->garena->d_ot_cnt[s];
+        } else {
+            dp = c->d_gpos[s] + c->goff[s][(size_t)rank];
+            ds = c->d_gscore[s] + c->goff[s][(size_t)rank];
+            if (c->gflags & CRP_GATHER_OFFTARGET) dt = c->d_got[s] + c->goff[s][(size_t)rank];
+        }
+        if (ho[s]) CRP_HIP(ctx, hipMemcpyAsync(ho[s], dt, n * sizeof(uint4), hipMemcpyDeviceToHost, ctx->stream));
+        if (hp[s]) CRP_HIP(ctx, hipMemcpyAsync(hp[s], dp, n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        if (hs[s]) CRP_HIP(ctx, hipMemcpyAsync(hs[s], ds, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    CRP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CRP_OK;
+}
+
+}  // extern "C"

@@ -165,6 +165,11 @@ struct Job {
     const uint8_t *minus;
     const double *score;
     const uint8_t *ids;
+    // opt-in extensions (crp_write_rows_ex); all null for the reference's rows
+    const uint8_t *feat_blob = nullptr;
+    const uint64_t *feat_off = nullptr;
+    const uint32_t *feat_idx = nullptr;
+    const uint32_t *offtarget = nullptr;
     std::string chrom_field;  // the chromosome column as csv writes it
     size_t row_bound;         // no row is longer than this
 
@@ -220,10 +225,23 @@ char *format_range(const Job &j, uint64_t r0, uint64_t r1, char *o)
             o = put_int(o, end - 3);
             o = minus ? PUT_LIT(o, ",-,") : PUT_LIT(o, ",+,");
             o = put_repr(o, j.score[r]);
-            o = PUT_LIT(o, ",,completed\r\n");
+            *o++ = ',';
+            if (j.feat_idx && j.feat_idx[r] != 0xffffffffu) {  // opt-in: the reference writes ''
+                const uint64_t f0 = j.feat_off[j.feat_idx[r]], f1 = j.feat_off[j.feat_idx[r] + 1];
+                o = put_field(o, j.feat_blob + f0, (size_t)(f1 - f0));
+            }
+            o = PUT_LIT(o, ",completed");
         } else {         // 11 fields, literal -1
-            o = minus ? PUT_LIT(o, "-,-1,,completed\r\n") : PUT_LIT(o, "+,-1,,completed\r\n");
+            o = minus ? PUT_LIT(o, "-,-1,,completed") : PUT_LIT(o, "+,-1,,completed");
         }
+        if (j.offtarget) {  // opt-in: four more columns
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t v = j.offtarget[4 * r + k];
+                *o++ = ',';
+                o = v == 0xffffffffu ? PUT_LIT(o, "-1") : put_int(o, (int64_t)v);
+            }
+        }
+        o = PUT_LIT(o, "\r\n");
     }
     return o;
 }
@@ -305,17 +323,30 @@ extern "C" int crp_format_rows(const uint8_t *contig_text, uint64_t contig_len, 
     }
 }
 
-extern "C" int crp_write_rows(int fd, const uint8_t *contig_text, uint64_t contig_len, const uint8_t *chrom,
-                              uint64_t chrom_len, int guide_len, const uint32_t *pos, const uint8_t *minus,
-                              const double *score, const uint8_t *ids, uint64_t n_rows, uint64_t *bytes_written,
-                              int n_threads)
+extern "C" int crp_write_rows_ex(int fd, const uint8_t *contig_text, uint64_t contig_len, const uint8_t *chrom,
+                                 uint64_t chrom_len, int guide_len, const uint32_t *pos, const uint8_t *minus,
+                                 const double *score, const uint8_t *ids, uint64_t n_rows, const uint8_t *feat_blob,
+                                 const uint64_t *feat_off, const uint32_t *feat_idx, const uint32_t *offtarget,
+                                 uint64_t *bytes_written, int n_threads)
 {
     if (fd < 0 || bad_args(contig_text, chrom, chrom_len, guide_len, pos, minus, score, ids, n_rows))
         return CRP_ERR_INVALID;
+    if (feat_idx && (!feat_off || !feat_blob)) return CRP_ERR_INVALID;
     if (bytes_written) *bytes_written = 0;
     if (n_rows == 0) return CRP_OK;
     try {
-        const Job job(contig_text, contig_len, chrom, chrom_len, guide_len, pos, minus, score, ids);
+        Job job(contig_text, contig_len, chrom, chrom_len, guide_len, pos, minus, score, ids);
+        job.feat_blob = feat_blob;
+        job.feat_off = feat_off;
+        job.feat_idx = feat_idx;
+        job.offtarget = offtarget;
+        if (offtarget) job.row_bound += 4 * 11;
+        if (feat_idx) {  // the longest features entry a row can carry, quoted
+            uint64_t longest = 0;
+            for (uint64_t r = 0; r < n_rows; ++r)
+                if (feat_idx[r] != 0xffffffffu) longest = std::max(longest, feat_off[feat_idx[r] + 1] - feat_off[feat_idx[r]]);
+            job.row_bound += 2 * (size_t)longest + 2;
+        }
         constexpr uint64_t kBlockRows = 16384;
         const uint64_t n_blocks = (n_rows + kBlockRows - 1) / kBlockRows;
         const int nt = (int)std::min<uint64_t>((uint64_t)(n_threads < 1 ? 1 : n_threads), n_blocks);
@@ -359,6 +390,15 @@ extern "C" int crp_write_rows(int fd, const uint8_t *contig_text, uint64_t conti
     } catch (...) {
         return CRP_ERR_NOMEM;
     }
+}
+
+extern "C" int crp_write_rows(int fd, const uint8_t *contig_text, uint64_t contig_len, const uint8_t *chrom,
+                              uint64_t chrom_len, int guide_len, const uint32_t *pos, const uint8_t *minus,
+                              const double *score, const uint8_t *ids, uint64_t n_rows, uint64_t *bytes_written,
+                              int n_threads)
+{
+    return crp_write_rows_ex(fd, contig_text, contig_len, chrom, chrom_len, guide_len, pos, minus, score, ids, n_rows,
+                             nullptr, nullptr, nullptr, nullptr, bytes_written, n_threads);
 }
 
 // The reference's own id draws, natively.  CROPSR.py:316-318 draws crispr ids with

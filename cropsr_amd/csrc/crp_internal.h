@@ -1,0 +1,123 @@
+// crp_internal.h -- the two opaque handles of the C ABI (include/cropsr_hip.h), shared by the
+// translation units that implement it: crp_api.cpp (arena, scan), crp_comm.cpp (RCCL),
+// crp_offtarget.hip (off-target seed scan).
+#pragma once
+#include "cropsr_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+
+#include "crp_kernels.h"
+
+struct crp_comm;  // crp_comm.cpp: the RCCL communicator and its scratch
+
+struct crp_ctx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    std::string last_error;
+    char name[128] = {0};
+    int n_cu = 0;
+    uint64_t hbm = 0;
+    // upload staging (characters) and seam-2 scratch
+    uint8_t *d_text = nullptr;
+    uint64_t d_text_cap = 0;
+    uint8_t *d_rows = nullptr;
+    double *d_rpre = nullptr, *d_rscore = nullptr;
+    uint64_t d_rows_cap = 0;
+    bool two_pass = false;          // CRP_OPT_TWO_PASS as configured
+    bool two_pass_latched = false;  // three look-back time-outs in a row: stay with three launches
+    int timeout_streak = 0;
+    uint64_t chain_timeouts = 0;    // single-launch scans that were repeated with three launches
+    uint32_t chain_timeout_ticks = 2000000;  // CRP_OPT_CHAIN_TIMEOUT_US in ticks of the 100 MHz real-time counter
+    uint32_t mute_tile = 0xffffffffu;  // test hook (environment CRP_TEST_MUTE_TILE): see crp_kernels.h
+    // measurement
+    int profiling = 0;  // 0 off, 1 emit kernel only, 2 all kernels
+    hipEvent_t ev[2 * CRP_K_KINDS] = {};  // start/stop pair per kernel kind
+    double ms[CRP_K_KINDS] = {};
+    uint64_t launches[CRP_K_KINDS] = {};
+    uint64_t *d_scalar = nullptr;  // 8 x u64 device scratch for small reductions
+    uint64_t *h_scalar = nullptr;  // pinned mirror
+    // off-target seed scan (crp_offtarget.hip)
+    uint32_t *d_ot_hist = nullptr;  // 4^12 site counts
+    uint4 *d_ot_ball = nullptr;     // 4^12 x {sites at distance 0, 1, 2, 3}
+    bool ot_solved = false;
+    uint64_t ot_epoch = 0;          // bumped by crp_offtarget_reset: arenas added before it are stale
+    // multi-GPU (crp_comm.cpp)
+    crp_comm *comm = nullptr;
+};
+
+struct crp_arena {
+    crp_ctx *ctx = nullptr;
+    uint64_t cap_words = 0;     // what the caller asked for
+    uint64_t padded_words = 0;  // allocation per plane
+    uint64_t *d_plane[4] = {nullptr, nullptr, nullptr, nullptr};
+    uint64_t used_words = 1;    // word 0 is the leading separator
+    uint64_t n_contigs = 0, n_chars = 0;
+    bool sealed = false;
+    // per-tile scratch
+    uint2 *d_tile_cnt = nullptr, *d_tile_off = nullptr;
+    uint64_t *d_chain[2] = {nullptr, nullptr};  // single-pass mode: header + tile descriptors, used alternately
+    int chain_cur = 0;                          // the buffer the next single-pass launch uses (all zero)
+    uint64_t *d_totals = nullptr;
+    uint64_t *h_totals = nullptr;  // pinned
+    uint32_t n_tiles = 0;
+    // hit tables: [0] = '+', [1] = '-'
+    uint32_t *d_pos[2] = {nullptr, nullptr};
+    double *d_score[2] = {nullptr, nullptr};
+    double *d_pre[2] = {nullptr, nullptr};
+    uint64_t tab_cap[2] = {0, 0};
+    uint64_t pre_cap[2] = {0, 0};
+    uint64_t n_hits[2] = {0, 0};
+    bool have_hits = false, have_pre = false;
+    // off-target: per-hit seed codes and counts, same order as the hit tables
+    uint32_t *d_ot_seed[2] = {nullptr, nullptr};
+    uint4 *d_ot_cnt[2] = {nullptr, nullptr};
+    uint64_t ot_cap[2] = {0, 0};
+    uint64_t *d_ot_own = nullptr;  // own_ranges of the last crp_offtarget_add
+    uint64_t ot_own_cap = 0;
+    uint64_t ot_epoch = 0;         // ctx->ot_epoch at the time of crp_offtarget_add (0: never added)
+};
+
+#define CRP_HIP(ctx, call)                                                              \
+    do {                                                                                \
+        hipError_t e__ = (call);                                                        \
+        if (e__ != hipSuccess) {                                                        \
+            (ctx)->last_error = std::string(#call) + ": " + hipGetErrorString(e__);     \
+            return e__ == hipErrorOutOfMemory ? CRP_ERR_NOMEM : CRP_ERR_HIP;            \
+        }                                                                               \
+    } while (0)
+
+namespace crp {
+
+// HIP-event bracket of one kernel kind (CRP_K_*) on the context's stream
+inline bool prof_on(const crp_ctx *ctx, int kind) { return ctx->profiling >= 2 || (ctx->profiling == 1 && kind == CRP_K_EMIT); }
+inline void prof_begin(crp_ctx *ctx, int kind)
+{
+    if (prof_on(ctx, kind)) (void)hipEventRecord(ctx->ev[kind * 2], ctx->stream);
+}
+inline void prof_end(crp_ctx *ctx, int kind)
+{
+    if (prof_on(ctx, kind)) (void)hipEventRecord(ctx->ev[kind * 2 + 1], ctx->stream);
+}
+// after the stream has been synchronised
+inline void prof_collect(crp_ctx *ctx, int kind)
+{
+    float ms = 0.f;
+    if (prof_on(ctx, kind) && hipEventElapsedTime(&ms, ctx->ev[kind * 2], ctx->ev[kind * 2 + 1]) == hipSuccess) {
+        ctx->ms[kind] += ms;
+        ctx->launches[kind] += 1;
+    }
+}
+
+// grow-only device buffer: *p holds at least `need` elements of `elem` bytes afterwards
+int grow(crp_ctx *ctx, void **p, uint64_t *cap, uint64_t need, size_t elem);
+
+void comm_release(crp_ctx *ctx);  // crp_comm.cpp; called by crp_destroy
+void comm_forget_arena(crp_ctx *ctx, const crp_arena *a);
+int comm_allreduce_u32(crp_ctx *ctx, uint32_t *d_buf, uint64_t n);  // in-place sum over the ranks; no-op without a communicator
+int comm_world(const crp_ctx *ctx);  // 0 without a communicator
+int comm_rank(const crp_ctx *ctx);
+
+}  // namespace crp

@@ -54,8 +54,11 @@ hipError_t launch_emit(hipStream_t s, const Planes &pl, uint64_t n_words_padded,
 // chain[1], chain[2] = the '+' and '-' table totals
 size_t chain_bytes(uint32_t n_tiles);
 // mute_tile: 0xffffffff, or (tests) the index of a tile that withholds its counts so that the look-back times out
+// timeout_ticks: how long a look-back may wait, in ticks of the 100 MHz real-time counter
 hipError_t launch_emit_chained(hipStream_t s, const Planes &pl, uint64_t n_words_padded, int l, uint64_t *chain,
-                               uint64_t *chain_next, const HitTables &out, uint32_t mute_tile);
+                               uint64_t *chain_next, const HitTables &out, uint32_t mute_tile, uint32_t timeout_ticks);
+// adds the number of entries of score[0..n) that are not -1 to *out (device memory)
+hipError_t launch_count_scored(hipStream_t s, const double *score, uint64_t n, uint64_t *out);
 hipError_t launch_score30(hipStream_t s, const uint8_t *rows, uint64_t n, int order, double *pre, double *score);
 hipError_t launch_pack(hipStream_t s, const uint8_t *text, uint64_t len, uint64_t n_words, uint64_t *hi,
                        uint64_t *lo, uint64_t *up, uint64_t *ac);

@@ -436,13 +436,15 @@ __device__ __forceinline__ void lookback_load(const uint64_t *desc, int64_t base
 // cost no wait here).  Returns the exclusive prefix in every lane and publishes the
 // inclusive one.
 __device__ __forceinline__ uint64_t lookback_resolve(uint64_t *desc, uint32_t tile, uint64_t total,
-                                                     uint64_t (&v)[LB_DEPTH], uint32_t *fail, bool muted)
+                                                     uint64_t (&v)[LB_DEPTH], uint32_t *fail, bool muted,
+                                                     uint32_t timeout_ticks)
 {
     const int lane = threadIdx.x & 63;
     if (tile == 0) return 0;
     uint64_t excl = 0;
     int64_t base = (int64_t)tile - 1;
     uint32_t spins = 0;
+    uint64_t t_first_stall = 0;  // 100 MHz real-time counter at the first stalled look of this tile
     while (true) {
         uint64_t contrib = 0;
         bool found = false, stall = false;
@@ -469,10 +471,17 @@ __device__ __forceinline__ uint64_t lookback_resolve(uint64_t *desc, uint32_t ti
             // Wait on that ONE descriptor (a single 8-byte load per look instead of the whole
             // window and its analysis), then read the window again.
             while ((__hip_atomic_load(&desc[missing], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 62) == 0) {
-                ++spins;
-                bool give_up = spins > (1u << 15);  // ~2 us per look, legitimate waits are tens of us
-                if ((spins & 63u) == 1)  // someone else already timed out: drain
+                // The bound is WALL TIME (legitimate waits are tens of microseconds; the default
+                // allowance is 20 ms), read every 16th look from the constant-rate counter, so it
+                // means the same on a throttled, shared or pre-empted GPU.
+                bool give_up = false;
+                if ((spins++ & 15u) == 0) {
+                    const uint64_t now = __builtin_amdgcn_s_memrealtime();
+                    if (t_first_stall == 0) t_first_stall = now | 1;
+                    give_up = now - t_first_stall > timeout_ticks;
+                    // someone else already timed out: drain
                     give_up |= __hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+                }
                 if (give_up) {
                     if (lane == 0) atomicExch(fail, 1u);
                     return 0;
@@ -503,11 +512,12 @@ struct ChainArgs {
     uint32_t tile, n_tiles;
     uint64_t total;     // this tile's (plus | minus << 32)
     bool muted;         // test hook: this tile publishes nothing
+    uint32_t timeout_ticks;  // look-back allowance in ticks of the 100 MHz real-time counter
 };
 
 __device__ __forceinline__ void chain_resolve(const ChainArgs &ch, uint64_t (&lb)[LB_DEPTH])
 {
-    const uint64_t e = lookback_resolve(ch.desc, ch.tile, ch.total, lb, ch.fail, ch.muted);
+    const uint64_t e = lookback_resolve(ch.desc, ch.tile, ch.total, lb, ch.fail, ch.muted, ch.timeout_ticks);
     if ((threadIdx.x & 63) == 0) {
         *ch.s_excl = e;
         if (ch.tile == ch.n_tiles - 1) {
@@ -541,7 +551,7 @@ template <int WPT, bool CHAINED, int LFIX>
 __global__ __launch_bounds__(EMIT_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8))) void emit_kernel(Planes pl, uint64_t n_words_padded, int l_arg,
                                                       const uint2 *__restrict__ tile_off, uint64_t *chain,
                                                       uint64_t *__restrict__ chain_next, HitTables out,
-                                                      uint32_t mute_tile)
+                                                      uint32_t mute_tile, uint32_t timeout_ticks)
 {
     const int l = LFIX > 0 ? LFIX : l_arg;
     constexpr int TW = EMIT_BLOCK * WPT;
@@ -592,7 +602,7 @@ __global__ __launch_bounds__(EMIT_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8
     ChainArgs ch{};
     if (CHAINED) {
         ch = ChainArgs{chain + CHAIN_HEADER_WORDS, reinterpret_cast<uint32_t *>(chain) + 1, chain + 1, &s_excl, &s_flag,
-                       tile, gridDim.x, total, tile == mute_tile};
+                       tile, gridDim.x, total, tile == mute_tile, timeout_ticks};
         if (tid == 0) {
             // mute_tile (normally none): a tile that never publishes, to exercise the time-out path
             if (tile != mute_tile) lookback_publish(ch.desc, tile, total);
@@ -924,26 +934,26 @@ hipError_t launch_emit(hipStream_t s, const Planes &pl, uint64_t n_words_padded,
     if (n_tiles == 0) return hipSuccess;
     if (l == 20)
         hipLaunchKernelGGL((emit_kernel<TILE_WPT, false, 20>), dim3(n_tiles), dim3(EMIT_BLOCK), 0, s, pl, n_words_padded,
-                           l, tile_off, (uint64_t *)nullptr, (uint64_t *)nullptr, out, 0xffffffffu);
+                           l, tile_off, (uint64_t *)nullptr, (uint64_t *)nullptr, out, 0xffffffffu, 0u);
     else
         hipLaunchKernelGGL((emit_kernel<TILE_WPT, false, 0>), dim3(n_tiles), dim3(EMIT_BLOCK), 0, s, pl, n_words_padded,
-                           l, tile_off, (uint64_t *)nullptr, (uint64_t *)nullptr, out, 0xffffffffu);
+                           l, tile_off, (uint64_t *)nullptr, (uint64_t *)nullptr, out, 0xffffffffu, 0u);
     return hipGetLastError();
 }
 
 size_t chain_bytes(uint32_t n_tiles) { return (CHAIN_HEADER_WORDS + (size_t)n_tiles) * sizeof(uint64_t); }
 
 hipError_t launch_emit_chained(hipStream_t s, const Planes &pl, uint64_t n_words_padded, int l, uint64_t *chain,
-                               uint64_t *chain_next, const HitTables &out, uint32_t mute_tile)
+                               uint64_t *chain_next, const HitTables &out, uint32_t mute_tile, uint32_t timeout_ticks)
 {
     constexpr int TW = EMIT_BLOCK * TILE_WPT;
     const uint32_t n_tiles = (uint32_t)(n_words_padded / TW);
     if (l == 20)
         hipLaunchKernelGGL((emit_kernel<TILE_WPT, true, 20>), dim3(n_tiles), dim3(EMIT_BLOCK), 0, s, pl, n_words_padded,
-                           l, (const uint2 *)nullptr, chain, chain_next, out, mute_tile);
+                           l, (const uint2 *)nullptr, chain, chain_next, out, mute_tile, timeout_ticks);
     else
         hipLaunchKernelGGL((emit_kernel<TILE_WPT, true, 0>), dim3(n_tiles), dim3(EMIT_BLOCK), 0, s, pl, n_words_padded,
-                           l, (const uint2 *)nullptr, chain, chain_next, out, mute_tile);
+                           l, (const uint2 *)nullptr, chain, chain_next, out, mute_tile, timeout_ticks);
     return hipGetLastError();
 }
 
@@ -969,6 +979,29 @@ hipError_t launch_pack(hipStream_t s, const uint8_t *text, uint64_t len, uint64_
     const uint64_t iters = ((n_words + 63) / 64 + BLOCK / 64 - 1) / (BLOCK / 64);
     const uint32_t grid = (uint32_t)(iters < 4096 ? iters : 4096);
     hipLaunchKernelGGL(pack_kernel, dim3(grid), dim3(BLOCK), 0, s, text, len, n_words, hi, lo, up, ac);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------- scored-row counter
+// rows of a score table that carry a real score (the reference writes -1 for the others,
+// CROPSR.py:466-468): the unit of the "gRNAs scored" metric, counted where the table lives.
+__global__ __launch_bounds__(BLOCK) void count_scored_kernel(const double *__restrict__ score, uint64_t n,
+                                                              unsigned long long *__restrict__ out)
+{
+    uint64_t c = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * BLOCK)
+        c += score[i] != -1.0;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, (unsigned long long)c);
+}
+
+hipError_t launch_count_scored(hipStream_t s, const double *score, uint64_t n, uint64_t *out)
+{
+    if (n == 0) return hipSuccess;
+    const uint64_t blocks = (n + BLOCK - 1) / BLOCK;
+    hipLaunchKernelGGL(count_scored_kernel, dim3((uint32_t)(blocks < 2048 ? blocks : 2048)), dim3(BLOCK), 0, s, score, n,
+                       reinterpret_cast<unsigned long long *>(out));
     return hipGetLastError();
 }
 

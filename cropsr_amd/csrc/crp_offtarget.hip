@@ -1,0 +1,363 @@
+// crp_offtarget.hip -- genome-wide off-target seed scan (BASELINE.json configs[4]).
+//
+// The reference has no off-target step at all (its only alignment code is the dead bowtie2
+// shell-out of prmrdsgn2.py:139-160), so the DEFINITION is this engine's own, stated on the
+// reference's own strings (include/cropsr_hip.h):
+//   site   a kept hit (CROPSR.py:419 / :430) whose `sequence` column (CROPSR.py:420 / :431) starts
+//          with 12 bases -- after the scoring transform of CROPSR.py:458 -- next to the PAM
+//   count  c_k(g), k = 0..3: the OTHER sites whose 12-base seed differs from g's in exactly k places
+//
+// Method (exact, no pairwise comparison):
+//   1. ot_seed_kernel     one lane per kept hit: 12 characters next to the PAM out of the arena's
+//                         bit-planes (two 64-bit words per plane), oriented like the scoring string
+//                         (crp_kernels.hip emit_rounds), Morton-coded to 24 bits; the site is added
+//                         to a histogram of the 4^12 seeds (one atomic per site);
+//   2. ot_ball_kernel x3  the Hamming-ball sums of that histogram for ALL seeds at once.  With
+//                         F_p[x][d] = sum of hist[y] over the y that agree with x on positions >= p
+//                         and differ in exactly d of the positions < p,
+//                             F_{p+1}[x][d] = F_p[x][d] + S_p[x][d-1] - F_p[x][d-1],
+//                             S_p[x][d] = sum over the 4 bases b at position p of F_p[x with b at p][d]
+//                         -- a group of 4 entries per step.  Four positions (8 index bits) per
+//                         pass, 4096-seed tiles through LDS: pass 0 walks contiguous tiles, passes 1
+//                         and 2 walk 256-byte pieces at strides of 4 KiB and 1 MiB;
+//   3. ot_lookup_kernel   one 16-byte read of the ball table per hit, minus the hit itself.
+// Cost: one pass over the hit positions, 1.3 GB of table traffic whatever the genome, one 16-byte
+// gather per hit: HBM-bound like the scan, no MFMA (sums of integers).
+// Multi-GPU: every rank adds its own sites; the histogram is summed over the ranks by one RCCL
+// all-reduce (64 MiB, crp_comm.cpp) between steps 1 and 2 -- the one bandwidth-heavy xGMI collective
+// of the engine -- and every rank then solves and looks up its own hits.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+
+#include "crp_internal.h"
+
+namespace crp {
+
+constexpr uint32_t OT_SEEDS = 1u << (2 * CRP_OT_SEED_LEN);  // 4^12
+constexpr uint32_t OT_NOT_A_SITE = 0xffffffffu;
+constexpr uint32_t OT_NOT_OWNED = 0xfffffffeu;
+
+// 12 consecutive arena positions starting at q, from one bit-plane
+__device__ __forceinline__ uint32_t window12(const uint64_t *plane, uint64_t q)
+{
+    const uint64_t w = q >> 6;
+    const uint32_t sh = (uint32_t)q & 63u;
+    uint64_t v = plane[w] >> sh;
+    if (sh > 52) v |= plane[w + 1] << (64 - sh);
+    return (uint32_t)v & 0xfffu;
+}
+
+// bit k of x -> bit 2k
+__device__ __forceinline__ uint32_t spread12(uint32_t x)
+{
+    x = (x | (x << 8)) & 0x00ff00ffu;
+    x = (x | (x << 4)) & 0x0f0f0f0fu;
+    x = (x | (x << 2)) & 0x33333333u;
+    x = (x | (x << 1)) & 0x55555555u;
+    return x;
+}
+
+// Seed of the hit at arena position p.  Seed character k (k = 0 next to the PAM) is character k of
+// the `sequence` column after .replace('U','T').upper():
+//   '+'  sequence = get_gRNA_sequence(s[i-l:i])  (CROPSR.py:420,128): s[i-1-k], upper-case bases
+//        complemented, lower-case ones only reversed
+//   '-'  sequence = get_gRNA_sequence(get_reverse_complement(s[j+3:j+3+l]))  (:431): s[j+3+k]
+// A character is a base iff it is one of acgtACGT, U (== A) or Z (== C) -- `ac | up` of the planes,
+// exactly the scorer's `valid` mask; anything else, or the end of the string (void), is not.
+template <bool MINUS>
+__global__ __launch_bounds__(BLOCK) void ot_seed_kernel(Planes pl, const uint32_t *__restrict__ pos, uint64_t n,
+                                                         const uint64_t *__restrict__ own, uint32_t n_own,
+                                                         uint32_t *__restrict__ seeds, uint32_t *__restrict__ hist,
+                                                         unsigned long long *__restrict__ n_sites)
+{
+    uint32_t added = 0;
+    for (uint64_t t = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; t < n; t += (uint64_t)gridDim.x * BLOCK) {
+        const uint64_t p = pos[t];
+        const uint64_t q = MINUS ? p + 3 : p - CRP_OT_SEED_LEN;
+        uint32_t h = window12(pl.plane[0], q), w = window12(pl.plane[1], q);
+        const uint32_t u = window12(pl.plane[2], q), a = window12(pl.plane[3], q);
+        const bool valid = ((a | u) & 0xfffu) == 0xfffu;
+        if (!MINUS) {
+            w ^= u;  // complement = flip the low code bit, upper case only
+            h = __brev(h) >> 20;
+            w = __brev(w) >> 20;
+        }
+        uint32_t code = OT_NOT_A_SITE;
+        if (valid) {
+            code = (spread12(h) << 1) | spread12(w);
+            bool mine = true;
+            if (n_own) {  // the range with the largest begin <= p
+                uint32_t lo = 0, hi = n_own;
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (own[2 * mid] <= p) lo = mid + 1;
+                    else hi = mid;
+                }
+                mine = lo > 0 && p < own[2 * (lo - 1) + 1];
+            }
+            if (mine) {
+                atomicAdd(&hist[code], 1u);
+                ++added;
+            } else {
+                code = OT_NOT_OWNED;
+            }
+        }
+        seeds[t] = code;
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) added += __shfl_down(added, d, 64);
+    if ((threadIdx.x & 63) == 0 && added) atomicAdd(n_sites, (unsigned long long)added);
+}
+
+// One pass of the ball recurrence over the four seed positions whose index bits are
+// [FIELD_SHIFT, FIELD_SHIFT + 8).  A tile = all 256 values of that field x 16 consecutive values of
+// the bits below it (FIRST: field at bit 0, a tile is 4096 consecutive seeds).  LDS holds the tile
+// as f[d][m * 16 + r] (m: field value, r: the 16 neighbours; FIRST: f[d][seed & 4095]).
+template <int FIELD_SHIFT, bool FIRST>
+__global__ __launch_bounds__(1024) void ot_ball_kernel(const uint32_t *__restrict__ hist, uint4 *__restrict__ ball)
+{
+    constexpr int TILE = 4096;
+    __shared__ uint32_t f[4][TILE];
+    const int tid = threadIdx.x;
+    const uint32_t tile = blockIdx.x;
+    // local bit layout: FIRST: the field is local bits 0..7; otherwise local bits 4..11 (r below it)
+    constexpr int LOCAL_FIELD = FIRST ? 0 : 4;
+    uint32_t gbase = 0;
+    if constexpr (FIRST) {
+        gbase = tile * TILE;
+        // 4096 counts = 1024 x 16 bytes
+        const uint4 v = reinterpret_cast<const uint4 *>(hist + gbase)[tid];
+        reinterpret_cast<uint4 *>(f[0])[tid] = v;
+#pragma unroll
+        for (int d = 1; d < 4; ++d) reinterpret_cast<uint4 *>(f[d])[tid] = make_uint4(0, 0, 0, 0);
+    } else {
+        constexpr uint32_t N_LO = 1u << (FIELD_SHIFT - 4);  // tiles that share the bits above the field
+        const uint32_t t_lo = tile % N_LO, t_hi = tile / N_LO;
+        gbase = (t_hi << (FIELD_SHIFT + 8)) | (t_lo << 4);
+#pragma unroll
+        for (int it = 0; it < TILE / 1024; ++it) {
+            const int e = tid + it * 1024;  // e = m * 16 + r: 16 lanes read 256 contiguous bytes
+            const uint4 v = ball[gbase | ((uint32_t)(e >> 4) << FIELD_SHIFT) | (uint32_t)(e & 15)];
+            f[0][e] = v.x;
+            f[1][e] = v.y;
+            f[2][e] = v.z;
+            f[3][e] = v.w;
+        }
+    }
+    __syncthreads();
+    // four steps, one seed position each; 1024 groups of 4 entries per step = one per thread
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int low = LOCAL_FIELD + 2 * p;  // the group's members differ in local bits low, low + 1
+        const uint32_t g = (uint32_t)tid;
+        const uint32_t base = ((g >> low) << (low + 2)) | (g & ((1u << low) - 1u));
+        uint32_t v[4][4], s[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                v[b][d] = f[d][base + ((uint32_t)b << low)];
+                s[d] += v[b][d];
+            }
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int d = 1; d < 4; ++d) f[d][base + ((uint32_t)b << low)] = v[b][d] + s[d - 1] - v[b][d - 1];
+        __syncthreads();
+    }
+    if constexpr (FIRST) {
+#pragma unroll
+        for (int it = 0; it < TILE / 1024; ++it) {
+            const int e = tid + it * 1024;
+            ball[gbase + e] = make_uint4(f[0][e], f[1][e], f[2][e], f[3][e]);
+        }
+    } else {
+#pragma unroll
+        for (int it = 0; it < TILE / 1024; ++it) {
+            const int e = tid + it * 1024;
+            ball[gbase | ((uint32_t)(e >> 4) << FIELD_SHIFT) | (uint32_t)(e & 15)] = make_uint4(f[0][e], f[1][e], f[2][e], f[3][e]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void ot_lookup_kernel(const uint32_t *__restrict__ seeds, uint64_t n,
+                                                           const uint4 *__restrict__ ball, uint4 *__restrict__ out)
+{
+    for (uint64_t t = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; t < n; t += (uint64_t)gridDim.x * BLOCK) {
+        const uint32_t s = seeds[t];
+        uint4 v = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
+        if (s < OT_SEEDS) {
+            v = ball[s];
+            v.x -= 1;  // the hit itself is one of the sites at distance 0
+        }
+        out[t] = v;
+    }
+}
+
+static uint32_t grid_for(uint64_t n)
+{
+    const uint64_t b = (n + BLOCK - 1) / BLOCK;
+    return (uint32_t)std::min<uint64_t>(b, 16384);
+}
+
+}  // namespace crp
+
+extern "C" {
+
+int crp_offtarget_reset(crp_ctx *ctx)
+{
+    if (!ctx) return CRP_ERR_INVALID;
+    CRP_HIP(ctx, hipSetDevice(ctx->device));
+    if (!ctx->d_ot_hist) CRP_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_ot_hist), (size_t)crp::OT_SEEDS * sizeof(uint32_t)));
+    if (!ctx->d_ot_ball) CRP_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_ot_ball), (size_t)crp::OT_SEEDS * sizeof(uint4)));
+    CRP_HIP(ctx, hipMemsetAsync(ctx->d_ot_hist, 0, (size_t)crp::OT_SEEDS * sizeof(uint32_t), ctx->stream));
+    ctx->ot_solved = false;
+    ctx->ot_epoch += 1;
+    return CRP_OK;
+}
+
+int crp_offtarget_add(crp_arena *a, int guide_len, const uint64_t *own_ranges, uint64_t n_ranges, uint64_t *n_sites)
+{
+    if (!a || (n_ranges && !own_ranges) || n_ranges > 0x7fffffffu) return CRP_ERR_INVALID;
+    if (guide_len < 1 || guide_len > 50) return CRP_ERR_UNSUPPORTED;
+    crp_ctx *ctx = a->ctx;
+    if (!a->have_hits || !ctx->d_ot_hist || ctx->ot_solved) return CRP_ERR_STATE;
+    if (a->ot_epoch == ctx->ot_epoch) return CRP_ERR_STATE;  // already added since the last reset
+    for (uint64_t r = 0; r < n_ranges; ++r) {
+        if (own_ranges[2 * r] > own_ranges[2 * r + 1]) return CRP_ERR_INVALID;
+        if (r && own_ranges[2 * r] < own_ranges[2 * r - 1]) return CRP_ERR_INVALID;  // ascending, disjoint
+    }
+    CRP_HIP(ctx, hipSetDevice(ctx->device));
+    for (int s = 0; s < 2; ++s) {
+        uint64_t cap_seed = a->ot_cap[s], cap_cnt = a->ot_cap[s];
+        int rc = crp::grow(ctx, reinterpret_cast<void **>(&a->d_ot_seed[s]), &cap_seed, a->n_hits[s], sizeof(uint32_t));
+        if (rc == CRP_OK) rc = crp::grow(ctx, reinterpret_cast<void **>(&a->d_ot_cnt[s]), &cap_cnt, a->n_hits[s], sizeof(uint4));
+        if (rc != CRP_OK) {
+            a->ot_cap[s] = 0;
+            return rc;
+        }
+        a->ot_cap[s] = std::min(cap_seed, cap_cnt);
+    }
+    if (n_ranges) {
+        int rc = crp::grow(ctx, reinterpret_cast<void **>(&a->d_ot_own), &a->ot_own_cap, 2 * n_ranges, sizeof(uint64_t));
+        if (rc != CRP_OK) return rc;
+        CRP_HIP(ctx, hipMemcpyAsync(a->d_ot_own, own_ranges, 2 * n_ranges * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+    }
+    CRP_HIP(ctx, hipMemsetAsync(ctx->d_scalar, 0, sizeof(uint64_t), ctx->stream));
+    crp::Planes pl{{a->d_plane[0], a->d_plane[1], a->d_plane[2], a->d_plane[3]}};
+    unsigned long long *d_n = reinterpret_cast<unsigned long long *>(ctx->d_scalar);
+    crp::prof_begin(ctx, CRP_K_OT_SEED);
+    if (guide_len < CRP_OT_SEED_LEN) {
+        // `sequence` has fewer than 12 characters: no hit is a site
+        for (int s = 0; s < 2; ++s)
+            if (a->n_hits[s]) CRP_HIP(ctx, hipMemsetAsync(a->d_ot_seed[s], 0xff, a->n_hits[s] * sizeof(uint32_t), ctx->stream));
+    } else {
+        if (a->n_hits[0])
+            hipLaunchKernelGGL(crp::ot_seed_kernel<false>, dim3(crp::grid_for(a->n_hits[0])), dim3(crp::BLOCK), 0, ctx->stream, pl,
+                               a->d_pos[0], a->n_hits[0], a->d_ot_own, (uint32_t)n_ranges, a->d_ot_seed[0], ctx->d_ot_hist, d_n);
+        if (a->n_hits[1])
+            hipLaunchKernelGGL(crp::ot_seed_kernel<true>, dim3(crp::grid_for(a->n_hits[1])), dim3(crp::BLOCK), 0, ctx->stream, pl,
+                               a->d_pos[1], a->n_hits[1], a->d_ot_own, (uint32_t)n_ranges, a->d_ot_seed[1], ctx->d_ot_hist, d_n);
+        CRP_HIP(ctx, hipGetLastError());
+    }
+    crp::prof_end(ctx, CRP_K_OT_SEED);
+    CRP_HIP(ctx, hipMemcpyAsync(ctx->h_scalar, ctx->d_scalar, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    CRP_HIP(ctx, hipStreamSynchronize(ctx->stream));  // own_ranges may be freed by the caller; *n_sites is read
+    crp::prof_collect(ctx, CRP_K_OT_SEED);
+    if (n_sites) *n_sites = ctx->h_scalar[0];
+    a->ot_epoch = ctx->ot_epoch;
+    return CRP_OK;
+}
+
+int crp_offtarget_reduce(crp_ctx *ctx)
+{
+    if (!ctx) return CRP_ERR_INVALID;
+    if (!ctx->d_ot_hist || ctx->ot_solved) return CRP_ERR_STATE;
+    CRP_HIP(ctx, hipSetDevice(ctx->device));
+    crp::prof_begin(ctx, CRP_K_OT_REDUCE);
+    const int rc = crp::comm_allreduce_u32(ctx, ctx->d_ot_hist, crp::OT_SEEDS);
+    if (rc != CRP_OK) return rc;
+    crp::prof_end(ctx, CRP_K_OT_REDUCE);
+    CRP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    crp::prof_collect(ctx, CRP_K_OT_REDUCE);
+    return CRP_OK;
+}
+
+int crp_offtarget_hist_get(crp_ctx *ctx, uint32_t *hist)
+{
+    if (!ctx || !hist) return CRP_ERR_INVALID;
+    if (!ctx->d_ot_hist) return CRP_ERR_STATE;
+    CRP_HIP(ctx, hipSetDevice(ctx->device));
+    CRP_HIP(ctx, hipMemcpyAsync(hist, ctx->d_ot_hist, (size_t)crp::OT_SEEDS * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    CRP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CRP_OK;
+}
+
+int crp_offtarget_hist_set(crp_ctx *ctx, const uint32_t *hist)
+{
+    if (!ctx || !hist) return CRP_ERR_INVALID;
+    if (!ctx->d_ot_hist || ctx->ot_solved) return CRP_ERR_STATE;
+    CRP_HIP(ctx, hipSetDevice(ctx->device));
+    CRP_HIP(ctx, hipMemcpyAsync(ctx->d_ot_hist, hist, (size_t)crp::OT_SEEDS * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    CRP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CRP_OK;
+}
+
+int crp_offtarget_solve(crp_ctx *ctx)
+{
+    if (!ctx) return CRP_ERR_INVALID;
+    if (!ctx->d_ot_hist) return CRP_ERR_STATE;
+    if (ctx->ot_solved) return CRP_OK;
+    CRP_HIP(ctx, hipSetDevice(ctx->device));
+    constexpr uint32_t TILES = crp::OT_SEEDS / 4096;
+    crp::prof_begin(ctx, CRP_K_OT_BALL);
+    hipLaunchKernelGGL((crp::ot_ball_kernel<0, true>), dim3(TILES), dim3(1024), 0, ctx->stream, ctx->d_ot_hist, ctx->d_ot_ball);
+    hipLaunchKernelGGL((crp::ot_ball_kernel<8, false>), dim3(TILES), dim3(1024), 0, ctx->stream, ctx->d_ot_hist, ctx->d_ot_ball);
+    hipLaunchKernelGGL((crp::ot_ball_kernel<16, false>), dim3(TILES), dim3(1024), 0, ctx->stream, ctx->d_ot_hist, ctx->d_ot_ball);
+    CRP_HIP(ctx, hipGetLastError());
+    crp::prof_end(ctx, CRP_K_OT_BALL);
+    CRP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    crp::prof_collect(ctx, CRP_K_OT_BALL);
+    ctx->ot_solved = true;
+    return CRP_OK;
+}
+
+int crp_offtarget_counts(crp_arena *a, uint32_t *counts_plus, uint32_t *counts_minus)
+{
+    if (!a) return CRP_ERR_INVALID;
+    crp_ctx *ctx = a->ctx;
+    if (!ctx->ot_solved || !a->have_hits || a->ot_epoch != ctx->ot_epoch) return CRP_ERR_STATE;
+    CRP_HIP(ctx, hipSetDevice(ctx->device));
+    crp::prof_begin(ctx, CRP_K_OT_LOOKUP);
+    for (int s = 0; s < 2; ++s)
+        if (a->n_hits[s])
+            hipLaunchKernelGGL(crp::ot_lookup_kernel, dim3(crp::grid_for(a->n_hits[s])), dim3(crp::BLOCK), 0, ctx->stream,
+                               a->d_ot_seed[s], a->n_hits[s], ctx->d_ot_ball, a->d_ot_cnt[s]);
+    CRP_HIP(ctx, hipGetLastError());
+    crp::prof_end(ctx, CRP_K_OT_LOOKUP);
+    uint32_t *host[2] = {counts_plus, counts_minus};
+    for (int s = 0; s < 2; ++s)
+        if (host[s] && a->n_hits[s])
+            CRP_HIP(ctx, hipMemcpyAsync(host[s], a->d_ot_cnt[s], a->n_hits[s] * sizeof(uint4), hipMemcpyDeviceToHost, ctx->stream));
+    CRP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    crp::prof_collect(ctx, CRP_K_OT_LOOKUP);
+    return CRP_OK;
+}
+
+int crp_offtarget_seeds(crp_arena *a, uint32_t *seeds_plus, uint32_t *seeds_minus)
+{
+    if (!a) return CRP_ERR_INVALID;
+    crp_ctx *ctx = a->ctx;
+    if (!a->have_hits || a->ot_epoch != ctx->ot_epoch || a->ot_epoch == 0) return CRP_ERR_STATE;
+    CRP_HIP(ctx, hipSetDevice(ctx->device));
+    uint32_t *host[2] = {seeds_plus, seeds_minus};
+    for (int s = 0; s < 2; ++s)
+        if (host[s] && a->n_hits[s])
+            CRP_HIP(ctx, hipMemcpyAsync(host[s], a->d_ot_seed[s], a->n_hits[s] * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    CRP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CRP_OK;
+}
+
+}  // extern "C"

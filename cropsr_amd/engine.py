@@ -45,6 +45,7 @@ class Hits:
         self.guide_len = guide_len
         self.pos_plus, self.pre_plus, self.score_plus = cols[0:3]
         self.pos_minus, self.pre_minus, self.score_minus = cols[3:6]
+        self.ot_plus = self.ot_minus = None  # (n, 4) uint32 once an off-target scan has run
         ends = offsets + lengths
         self._cut_plus = (np.searchsorted(self.pos_plus, offsets, "left"),
                           np.searchsorted(self.pos_plus, ends, "left"))
@@ -64,11 +65,14 @@ class Hits:
         a, b = int(self._cut_plus[0][k]), int(self._cut_plus[1][k])
         c, d = int(self._cut_minus[0][k]), int(self._cut_minus[1][k])
         sl = lambda arr, x, y: None if arr is None else arr[x:y]
-        return dict(
+        out = dict(
             pos_plus=(self.pos_plus[a:b] - np.uint32(off)), pre_plus=sl(self.pre_plus, a, b),
             score_plus=self.score_plus[a:b],
             pos_minus=(self.pos_minus[c:d] - np.uint32(off)), pre_minus=sl(self.pre_minus, c, d),
             score_minus=self.score_minus[c:d])
+        if self.ot_plus is not None:  # off-target counts travel with the rows they belong to
+            out["ot_plus"], out["ot_minus"] = self.ot_plus[a:b], self.ot_minus[c:d]
+        return out
 
 
 class Arena:
@@ -125,6 +129,42 @@ class Arena:
         n_plus, n_minus = self.scan_score_device(guide_len, want_pre)
         cols = self.fetch(n_plus, n_minus, want_pre)
         return Hits(self.offsets, self.lengths, guide_len, cols)
+
+    def count_scored(self):
+        """Rows of the last scan that carry a real score (counted on the GPU)."""
+        n = ctypes.c_uint64()
+        nat.check(nat.lib().crp_count_scored(self._h, ctypes.byref(n)), "crp_count_scored", self._engine._ctx)
+        return n.value
+
+    # ---- off-target seed scan (opt-in; include/cropsr_hip.h)
+    def offtarget_add(self, guide_len=20, own_ranges=None):
+        """Add the sites of the last scan to the engine's seed histogram; own_ranges: (n, 2) arena
+        positions [begin, end) whose hits count (default: all).  Returns the number of sites."""
+        n = ctypes.c_uint64()
+        if own_ranges is None:
+            ptr, k = None, 0
+        else:
+            own = np.ascontiguousarray(own_ranges, dtype=np.uint64).reshape(-1, 2)
+            ptr, k = own.ctypes.data_as(nat.u64p), own.shape[0]
+        nat.check(nat.lib().crp_offtarget_add(self._h, int(guide_len), ptr, k, ctypes.byref(n)),
+                  "crp_offtarget_add", self._engine._ctx)
+        return n.value
+
+    def offtarget_counts(self, n_plus, n_minus, fetch=True):
+        """(n, 4) uint32 per strand: other sites at seed distance 0..3 (0xFFFFFFFF: not a site)."""
+        if not fetch:
+            nat.check(nat.lib().crp_offtarget_counts(self._h, None, None), "crp_offtarget_counts", self._engine._ctx)
+            return None
+        cp, cm = np.empty((n_plus, 4), dtype=np.uint32), np.empty((n_minus, 4), dtype=np.uint32)
+        nat.check(nat.lib().crp_offtarget_counts(self._h, cp.ctypes.data_as(nat.u32p), cm.ctypes.data_as(nat.u32p)),
+                  "crp_offtarget_counts", self._engine._ctx)
+        return cp, cm
+
+    def offtarget_seeds(self, n_plus, n_minus):
+        sp, sm = np.empty(n_plus, dtype=np.uint32), np.empty(n_minus, dtype=np.uint32)
+        nat.check(nat.lib().crp_offtarget_seeds(self._h, sp.ctypes.data_as(nat.u32p), sm.ctypes.data_as(nat.u32p)),
+                  "crp_offtarget_seeds", self._engine._ctx)
+        return sp, sm
 
 
 # Engines still open when the interpreter exits are closed here, in an atexit handler: that runs
@@ -254,12 +294,105 @@ class Engine:
             score[base:base + 2] = self.score_30mers(sequences[base:base + 2], nat.ORDER_TAIL2)[1]
         return score
 
-    def configure(self, two_pass=None):
+    def configure(self, two_pass=None, chain_timeout_us=None):
         """two_pass=False (the default): one launch per scan, table offsets from the chained
         scan inside the emit kernel; True: the count / tile-scan / emit launch sequence.
-        Same results either way (every GPU parity test runs in both modes)."""
+        Same results either way (every GPU parity test runs in both modes).
+        chain_timeout_us: how long a single-launch workgroup may wait for a predecessor."""
         if two_pass is not None:
             nat.check(nat.lib().crp_configure(self._ctx, nat.OPT_TWO_PASS, int(bool(two_pass))), "crp_configure")
+        if chain_timeout_us is not None:
+            nat.check(nat.lib().crp_configure(self._ctx, nat.OPT_CHAIN_TIMEOUT_US, int(chain_timeout_us)), "crp_configure")
+
+    def query(self):
+        """Fallback and communicator state: chain_timeouts (single-launch scans repeated as three
+        launches), two_pass_active, comm_world, comm_rank."""
+        out = {}
+        for name, what in (("chain_timeouts", nat.Q_CHAIN_TIMEOUTS), ("two_pass_active", nat.Q_TWO_PASS_ACTIVE),
+                           ("comm_world", nat.Q_COMM_WORLD), ("comm_rank", nat.Q_COMM_RANK)):
+            v = ctypes.c_int64()
+            nat.check(nat.lib().crp_query(self._ctx, what, ctypes.byref(v)), "crp_query")
+            out[name] = int(v.value)
+        return out
+
+    # ---- multi-GPU: RCCL inside the library (crp_comm.cpp); `group` is a rendezvous.Group
+    def comm_init(self, group):
+        """Create the RCCL communicator of this engine: rank 0 draws the unique id, the group's
+        control sockets carry it to the others.  Errors are agreed on before anyone proceeds."""
+        L = nat.lib()
+        ident, err = None, None
+        if group.rank == 0:
+            buf = (ctypes.c_uint8 * nat.COMM_ID_BYTES)()
+            st = L.crp_comm_unique_id(buf)
+            if st != nat.CRP_OK:
+                err = "crp_comm_unique_id: " + L.crp_strerror(st).decode()
+            ident = bytes(buf)
+        ident = group.bcast(ident)
+        if ident is not None and err is None:
+            buf = (ctypes.c_uint8 * nat.COMM_ID_BYTES).from_buffer_copy(ident)
+            st = L.crp_comm_init(self._ctx, buf, group.rank, group.world)
+            if st != nat.CRP_OK:
+                err = "crp_comm_init: %s [%s]" % (L.crp_strerror(st).decode(), L.crp_last_error(self._ctx).decode())
+        group.check(err)
+
+    def comm_barrier(self):
+        nat.check(nat.lib().crp_comm_barrier(self._ctx), "crp_comm_barrier", self._ctx)
+
+    def comm_allreduce(self, values, op="sum"):
+        a = (ctypes.c_double * len(values))(*[float(v) for v in values])
+        nat.check(nat.lib().crp_comm_allreduce_f64(self._ctx, a, len(values), nat.REDUCE_MAX if op == "max" else nat.REDUCE_SUM),
+                  "crp_comm_allreduce_f64", self._ctx)
+        return list(a)
+
+    def gather_hits(self, arena, root=0, offtarget=False, pre=False):
+        """The gatherv of the path (crp_gather_hits): every rank's tables of `arena` (None: empty) into
+        root's HBM.  pre=True: the f64 column is the pre-sigmoid sum instead of the score.  Returns
+        the (world, 2) counts every rank contributed."""
+        world = self.query()["comm_world"]
+        counts = np.zeros((world, 2), dtype=np.uint64)
+        flags = (nat.GATHER_OFFTARGET if offtarget else 0) | (nat.GATHER_PRE if pre else 0)
+        nat.check(nat.lib().crp_gather_hits(self._ctx, arena._h if arena is not None else None, int(root),
+                                            flags, counts.ctypes.data_as(nat.u64p)),
+                  "crp_gather_hits", self._ctx)
+        return counts
+
+    def gathered_fetch(self, rank, counts, offtarget=False):
+        """Root: host copies of what `rank` contributed to the last gather_hits -> column dict."""
+        n_plus, n_minus = int(counts[rank][0]), int(counts[rank][1])
+        out = {"pos_plus": np.empty(n_plus, np.uint32), "score_plus": np.empty(n_plus, np.float64),
+               "pos_minus": np.empty(n_minus, np.uint32), "score_minus": np.empty(n_minus, np.float64)}
+        if offtarget:
+            out["ot_plus"] = np.empty((n_plus, 4), np.uint32)
+            out["ot_minus"] = np.empty((n_minus, 4), np.uint32)
+        ptr = lambda k, t: out[k].ctypes.data_as(t) if k in out else None
+        nat.check(nat.lib().crp_gathered_fetch(self._ctx, int(rank), ptr("pos_plus", nat.u32p), ptr("score_plus", nat.f64p),
+                                               ptr("ot_plus", nat.u32p), ptr("pos_minus", nat.u32p),
+                                               ptr("score_minus", nat.f64p), ptr("ot_minus", nat.u32p)),
+                  "crp_gathered_fetch", self._ctx)
+        return out
+
+    # ---- off-target seed scan, engine-wide steps (per-arena steps: Arena.offtarget_*)
+    def offtarget_reset(self):
+        nat.check(nat.lib().crp_offtarget_reset(self._ctx), "crp_offtarget_reset", self._ctx)
+
+    def offtarget_reduce(self):
+        """RCCL all-reduce of the site histogram over the communicator (no-op without one)."""
+        nat.check(nat.lib().crp_offtarget_reduce(self._ctx), "crp_offtarget_reduce", self._ctx)
+
+    def offtarget_solve(self):
+        nat.check(nat.lib().crp_offtarget_solve(self._ctx), "crp_offtarget_solve", self._ctx)
+
+    def offtarget_hist(self, new=None):
+        """The 4^12 site histogram as a uint32 array; new: replace it (before solve)."""
+        if new is not None:
+            a = np.ascontiguousarray(new, dtype=np.uint32)
+            if a.size != nat.OT_SEEDS:
+                raise ValueError("the histogram has 4^12 entries")
+            nat.check(nat.lib().crp_offtarget_hist_set(self._ctx, a.ctypes.data_as(nat.u32p)), "crp_offtarget_hist_set", self._ctx)
+            return a
+        a = np.empty(nat.OT_SEEDS, dtype=np.uint32)
+        nat.check(nat.lib().crp_offtarget_hist_get(self._ctx, a.ctypes.data_as(nat.u32p)), "crp_offtarget_hist_get", self._ctx)
+        return a
 
     # ---- measurement
     def profile(self, on=2):
@@ -268,11 +401,14 @@ class Engine:
         nat.check(nat.lib().crp_profile_enable(self._ctx, level), "crp_profile_enable")
 
     def profile_read(self, reset=True):
-        ms = (ctypes.c_double * 3)()
-        n = (ctypes.c_uint64 * 3)()
-        nat.check(nat.lib().crp_profile_read(self._ctx, ms, n, int(reset)), "crp_profile_read")
-        names = ("count", "tile_scan", "emit_score")
-        return {names[k]: dict(ms=ms[k], launches=int(n[k])) for k in range(3)}
+        """{kernel kind: {ms, launches}} since the last reset, for every kind of nat.KINDS."""
+        out = {}
+        for k, name in enumerate(nat.KINDS):
+            ms, n = ctypes.c_double(), ctypes.c_uint64()
+            nat.check(nat.lib().crp_profile_read_kind(self._ctx, k, ctypes.byref(ms), ctypes.byref(n), int(reset)),
+                      "crp_profile_read_kind")
+            out[name] = dict(ms=ms.value, launches=int(n.value))
+        return out
 
 
 class ArenaBuilder:
@@ -317,6 +453,7 @@ class Genome:
     def __init__(self, engine, contigs, max_words=None, pack="device"):
         L = nat.lib()
         limit = int(max_words) if max_words else int(L.crp_arena_max_words())
+        self._engine = engine
         bufs = [_as_u8(c) for c in contigs]
         groups, cur, used = [], [], 1
         for k, b in enumerate(bufs):
@@ -337,8 +474,25 @@ class Genome:
                 self._where[k] = (a, j)
         self.n_contigs = len(bufs)
 
-    def scan_score(self, guide_len=20, want_pre=False):
-        return GenomeHits(self, [a.scan_score(guide_len, want_pre) for a in self.arenas])
+    def scan_score(self, guide_len=20, want_pre=False, offtarget=False):
+        """Seam 1 + 2 for every contig.  offtarget=True also runs the genome-wide seed scan over all
+        arenas (single process: no reduce) and attaches (n, 4) counts to every contig's hits."""
+        if not offtarget:
+            return GenomeHits(self, [a.scan_score(guide_len, want_pre) for a in self.arenas])
+        eng = self._engine
+        eng.offtarget_reset()
+        counts, per_arena = [], []
+        for a in self.arenas:
+            n = a.scan_score_device(guide_len, want_pre)
+            a.offtarget_add(guide_len)
+            counts.append(n)
+        eng.offtarget_solve()
+        for a, (n_plus, n_minus) in zip(self.arenas, counts):
+            # (the tables of an arena stay valid until its next scan)
+            h = Hits(a.offsets, a.lengths, guide_len, a.fetch(n_plus, n_minus, want_pre))
+            h.ot_plus, h.ot_minus = a.offtarget_counts(n_plus, n_minus)
+            per_arena.append(h)
+        return GenomeHits(self, per_arena)
 
     def close(self):
         for a in self.arenas:

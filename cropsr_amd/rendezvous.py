@@ -1,0 +1,212 @@
+"""Process group of a multi-GPU run, without PyTorch: one process per GPU on one node.
+
+The reference is a single process (its only hint of parallelism is the dead
+cropsr_functions.py:256-273), so nothing here mirrors reference code.  The DATA of
+the path moves over xGMI inside libcropsr_hip.so (RCCL: crp_gather_hits,
+crp_offtarget_reduce).  This module is the small CONTROL plane around it:
+
+  * find the other ranks: RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT
+    as `python -m torch.distributed.run` (or any launcher) exports them.  Rank 0
+    listens on an ephemeral TCP port of 127.0.0.1 and publishes it in a file
+    keyed by the launcher (its pid and MASTER_PORT); the others poll that file.
+    (MASTER_PORT itself belongs to the launcher's own store.)  CROPSR_RDZV_ENDPOINT=
+    host:port names the listening socket explicitly instead (no file);
+  * carry the RCCL unique id from rank 0 to the others (bcast);
+  * exchange small Python objects (all_gather), agree on errors before a data
+    collective (check), fence (barrier), sum/max a few numbers (allreduce);
+  * send_array / recv_array: numpy arrays over the same sockets -- the host
+    transport of the gatherv, used by the CPU tests and by rehearsals that put
+    several ranks on one GPU, where RCCL cannot run.
+
+Star topology through rank 0; every operation is a collective that all ranks
+call in the same order.  Messages: 8-byte length + pickle (arrays: raw bytes).
+"""
+import json
+import os
+import pickle
+import socket
+import struct
+import tempfile
+import time
+
+import numpy as np
+
+_TIMEOUT_S = float(os.environ.get("CROPSR_RDZV_TIMEOUT", "300"))
+
+
+def _send_msg(sock, payload):
+    sock.sendall(struct.pack("<Q", len(payload)))
+    sock.sendall(payload)
+
+
+def _recv_exact(sock, n):
+    buf = bytearray(n)
+    view = memoryview(buf)
+    got = 0
+    while got < n:
+        k = sock.recv_into(view[got:], n - got)
+        if k == 0:
+            raise ConnectionError("peer closed the control connection")
+        got += k
+    return buf
+
+
+def _recv_msg(sock):
+    (n,) = struct.unpack("<Q", _recv_exact(sock, 8))
+    return _recv_exact(sock, n)
+
+
+class RankError(RuntimeError):
+    """Raised on EVERY rank by Group.check when any rank reported an error."""
+
+
+class Group:
+    """world processes; rank 0 is the hub."""
+
+    def __init__(self, rank, world, local_rank=0, endpoint=None, rdzv_file=None):
+        self.rank, self.world, self.local_rank = int(rank), int(world), int(local_rank)
+        self._peers = {}     # hub: rank -> socket
+        self._hub = None     # others: socket to rank 0
+        self._listener = None
+        self._file = None
+        if self.world == 1:
+            return
+        if self.rank == 0:
+            self._listener = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            self._listener.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            if endpoint:
+                host, port = endpoint.rsplit(":", 1)
+                self._listener.bind((host, int(port)))
+            else:
+                self._listener.bind(("127.0.0.1", 0))
+            self._listener.listen(self.world)
+            self._listener.settimeout(_TIMEOUT_S)
+            if not endpoint:
+                host, port = self._listener.getsockname()
+                tmp = rdzv_file + ".%d.tmp" % os.getpid()
+                with open(tmp, "w") as f:
+                    json.dump({"host": host, "port": port, "world": self.world, "pid": os.getpid()}, f)
+                os.replace(tmp, rdzv_file)  # atomic: a reader never sees half a file
+                self._file = rdzv_file
+            while len(self._peers) < self.world - 1:
+                conn, _ = self._listener.accept()
+                conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                conn.settimeout(_TIMEOUT_S)
+                hello = pickle.loads(_recv_msg(conn))
+                if hello.get("world") != self.world or hello.get("rank") in self._peers or not 0 < hello.get("rank", 0) < self.world:
+                    conn.close()  # a stray client of another run
+                    continue
+                self._peers[hello["rank"]] = conn
+            for r in sorted(self._peers):
+                _send_msg(self._peers[r], pickle.dumps("welcome"))
+        else:
+            deadline = time.time() + _TIMEOUT_S
+            while True:
+                try:
+                    if endpoint:
+                        host, port = endpoint.rsplit(":", 1)
+                    else:
+                        with open(rdzv_file) as f:
+                            info = json.load(f)
+                        if info.get("world") != self.world:
+                            raise OSError("stale rendezvous file")
+                        host, port = info["host"], info["port"]
+                    s = socket.create_connection((host, int(port)), timeout=5)
+                    s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                    s.settimeout(_TIMEOUT_S)
+                    _send_msg(s, pickle.dumps({"rank": self.rank, "world": self.world}))
+                    if pickle.loads(_recv_msg(s)) != "welcome":
+                        raise OSError("unexpected greeting")
+                    self._hub = s
+                    break
+                except (OSError, ValueError, ConnectionError):
+                    if time.time() > deadline:
+                        raise TimeoutError("rank %d: no rendezvous with rank 0 within %.0f s" % (self.rank, _TIMEOUT_S))
+                    time.sleep(0.05)
+
+    # ------------------------------------------------------------------ set-up
+    @classmethod
+    def from_env(cls, env=None):
+        """The group torch.distributed.run (or a compatible launcher) describes in the
+        environment; None for a single process."""
+        env = os.environ if env is None else env
+        world = int(env.get("WORLD_SIZE", "1"))
+        if world <= 1:
+            return None
+        rank = int(env.get("RANK", "0"))
+        local = int(env.get("LOCAL_RANK", str(rank)))
+        endpoint = env.get("CROPSR_RDZV_ENDPOINT")
+        path = None
+        if not endpoint:
+            # all ranks are children of one launcher process: its pid and port name the run
+            key = env.get("CROPSR_RDZV_KEY") or "%s_%s" % (os.getppid(), env.get("MASTER_PORT", "0"))
+            path = os.path.join(env.get("CROPSR_RDZV_DIR") or tempfile.gettempdir(), "cropsr_rdzv_%s.json" % key)
+        return cls(rank, world, local, endpoint, path)
+
+    def close(self):
+        for s in list(self._peers.values()) + [self._hub, self._listener]:
+            if s is not None:
+                try:
+                    s.close()
+                except OSError:
+                    pass
+        self._peers, self._hub, self._listener = {}, None, None
+        if self._file:
+            try:
+                os.unlink(self._file)
+            except OSError:
+                pass
+            self._file = None
+
+    # ------------------------------------------------------------- collectives
+    def all_gather(self, obj):
+        """[obj of rank 0, obj of rank 1, ...] on every rank."""
+        if self.world == 1:
+            return [obj]
+        if self.rank == 0:
+            objs = [obj] + [None] * (self.world - 1)
+            for r, s in self._peers.items():
+                objs[r] = pickle.loads(_recv_msg(s))
+            blob = pickle.dumps(objs)
+            for s in self._peers.values():
+                _send_msg(s, blob)
+            return objs
+        _send_msg(self._hub, pickle.dumps(obj))
+        return pickle.loads(_recv_msg(self._hub))
+
+    def bcast(self, obj, src=0):
+        return self.all_gather(obj if self.rank == src else None)[src]
+
+    def barrier(self):
+        self.all_gather(None)
+
+    def allreduce(self, values, op="sum"):
+        """Element-wise sum or max of a short list of numbers over all ranks."""
+        rows = self.all_gather([float(v) for v in values])
+        f = max if op == "max" else sum
+        return [f(col) for col in zip(*rows)]
+
+    def check(self, error=None):
+        """Call on every rank BEFORE a data collective, with this rank's error (or None).  If any
+        rank has one, every rank raises RankError with the same text -- no rank is left waiting
+        in a collective its peers never enter."""
+        errors = self.all_gather(None if error is None else str(error))
+        bad = [(r, e) for r, e in enumerate(errors) if e is not None]
+        if bad:
+            raise RankError("; ".join("rank %d: %s" % (r, e) for r, e in bad))
+
+    # -------------------------------------------------- arrays (host transport)
+    def send_array(self, arr, dst=0):
+        """rank != dst: one numpy array to dst (must be the hub, rank 0)."""
+        if dst != 0 or self.rank == 0:
+            raise ValueError("arrays travel to rank 0 only")
+        a = np.ascontiguousarray(arr)
+        _send_msg(self._hub, pickle.dumps((a.dtype.str, a.shape)))
+        _send_msg(self._hub, memoryview(a).cast("B") if a.size else b"")
+
+    def recv_array(self, src):
+        """rank 0: the array rank `src` sent."""
+        s = self._peers[src]
+        dtype, shape = pickle.loads(_recv_msg(s))
+        raw = _recv_msg(s)
+        return np.frombuffer(raw, dtype=np.dtype(dtype)).reshape(shape)

@@ -23,6 +23,8 @@ import numpy as np
 
 HEADER = ["crispr_id", "crispr_sys", "sequence", "long_sequence", "chromosome", "start_pos",
           "end_pos", "cutsite", "strand", "on_site_score", "features", "status"]
+OFFTARGET_HEADER = ["offtarget_seed_mm0", "offtarget_seed_mm1", "offtarget_seed_mm2", "offtarget_seed_mm3"]  # --offtarget
+NO_FEATURE = 0xFFFFFFFF
 CHUNK = 1000000  # CROPSR.py:453
 ORDER_BODY4, ORDER_TAIL2, ORDER_DOT1 = 0, 1, 2  # include/cropsr_hip.h CRP_ORDER_*
 
@@ -67,9 +69,16 @@ class ContigRows:
     """The rows one contig contributes to Complete_dataset, in reference order
     (all '+' hits ascending, then all '-' hits ascending; CROPSR.py:417-434)."""
 
-    def __init__(self, name_token, s, hits, guide_len):
+    def __init__(self, name_token, s, hits, guide_len, features=None):
+        """features (opt-in, --annotate): (strings, idx) -- row k's `features` column is
+        strings[idx[k]] (NO_FEATURE: ''); hits may carry ot_plus / ot_minus (--offtarget)."""
         l = guide_len
         self.chrom = name_token[1:]  # CROPSR.py:422 chromosome[1::]
+        self.features = features
+        self.ot = None
+        if hits.get("ot_plus") is not None:
+            self.ot = np.concatenate([hits["ot_plus"].reshape(-1, 4), hits["ot_minus"].reshape(-1, 4)]).astype(np.int64)
+            self.ot[self.ot == 0xFFFFFFFF] = -1
         ip = hits["pos_plus"].astype(np.int64)
         jm = hits["pos_minus"].astype(np.int64)
         self.n = int(ip.size + jm.size)
@@ -91,11 +100,15 @@ class ContigRows:
 
     def row(self, k, crispr_id):
         strand = "+" if k < self.n_plus else "-"
+        extra = () if self.ot is None else tuple(int(v) for v in self.ot[k])
         if len(self.long[k]) == 30:  # CROPSR.py:466
+            feat = ""
+            if self.features is not None and self.features[1][k] != NO_FEATURE:
+                feat = self.features[0][int(self.features[1][k])]
             return (crispr_id, "cas9", self.short[k], self.long[k], self.chrom, self.start[k],
-                    self.end[k], self.end[k] - 3, strand, self.score[k], "", "completed")
+                    self.end[k], self.end[k] - 3, strand, self.score[k], feat, "completed") + extra
         return (crispr_id, "cas9", self.short[k], self.long[k], self.chrom, self.start[k],
-                self.end[k], strand, -1, "", "completed")
+                self.end[k], strand, -1, "", "completed") + extra
 
 
 def flush_plan(size, chunk=None):
@@ -168,7 +181,7 @@ class Dataset:
             special, order = [4 * (n // 4), 4 * (n // 4) + 1], ORDER_TAIL2
         else:
             special, order = [], ORDER_BODY4
-        special = [k for k in special if len(out[k]) == 12]  # scored rows only
+        special = [k for k in special if len(out[k][3]) == 30]  # scored rows only
         if special:
             seqs = np.empty((len(special), 30), dtype=np.uint8)
             for r, k in enumerate(special):
@@ -182,10 +195,10 @@ class Dataset:
         return out
 
 
-def write_header(path):
-    """CROPSR.py:402-405."""
+def write_header(path, offtarget=False):
+    """CROPSR.py:402-405 (plus the four opt-in off-target column names)."""
     with open(path, "w", newline="") as f:
-        csv.writer(f).writerow(HEADER)
+        csv.writer(f).writerow(HEADER + (OFFTARGET_HEADER if offtarget else []))
 
 
 def write_pass(path, dataset, rescore):
@@ -207,9 +220,20 @@ def write_pass(path, dataset, rescore):
 class ContigTable:
     """Array form of ContigRows: same rows, same order, no per-row Python objects."""
 
-    def __init__(self, name_token, s, hits, guide_len):
-        """s: the contig string, as str or (one byte per character) bytes."""
+    def __init__(self, name_token, s, hits, guide_len, features=None):
+        """s: the contig string, as str or (one byte per character) bytes; features / ot_*: as in
+        ContigRows (the opt-in columns)."""
         self.guide_len = guide_len
+        self.feat_blob = self.feat_off = self.feat_idx = None
+        if features is not None:
+            enc = [t.encode("utf-8") for t in features[0]]
+            self.feat_blob = np.frombuffer(b"".join(enc) or b"\0", dtype=np.uint8)
+            self.feat_off = np.concatenate([[0], np.cumsum([len(e) for e in enc])]).astype(np.uint64)
+            self.feat_idx = np.ascontiguousarray(features[1], dtype=np.uint32)
+        self.ot = None
+        if hits.get("ot_plus") is not None:
+            self.ot = np.ascontiguousarray(np.concatenate([hits["ot_plus"].reshape(-1, 4), hits["ot_minus"].reshape(-1, 4)]),
+                                           dtype=np.uint32)
         self.chrom = name_token[1:].encode("utf-8")
         self.text = np.frombuffer(s.encode("ascii", "replace") if isinstance(s, str) else s, dtype=np.uint8)
         self.n_plus = int(hits["pos_plus"].size)
@@ -294,7 +318,8 @@ class NativeDataset:
                         t = blk.long_text(k0 + j).replace("U", "T").upper()  # CROPSR.py:458
                         seqs[r] = np.frombuffer(t.encode("ascii", "replace"), dtype=np.uint8)
                     score[fix] = rescore(seqs, order)
-                yield blk, blk.pos[k0:k1], blk.minus[k0:k1], score, np.ascontiguousarray(sel[g - lo:g - lo + m])
+                extras = (None if blk.feat_idx is None else blk.feat_idx[k0:k1], None if blk.ot is None else blk.ot[k0:k1])
+                yield blk, blk.pos[k0:k1], blk.minus[k0:k1], score, np.ascontiguousarray(sel[g - lo:g - lo + m]), extras
             g = base + blk.n
             b += 1
 
@@ -303,7 +328,9 @@ class NativeDataset:
         from . import _native as nat
         L = nat.lib()
         out = []
-        for blk, pos, minus, score, ids_part in self._segments(lo, count, ids_u8, index_range, rescore, ids_rev):
+        for blk, pos, minus, score, ids_part, extras in self._segments(lo, count, ids_u8, index_range, rescore, ids_rev):
+            if extras[0] is not None or extras[1] is not None:
+                raise ValueError("chunk_bytes formats the reference's columns only (use chunk_to_fd)")
             m = pos.size
             cap = m * (170 + 2 * len(blk.chrom)) + 64
             while True:
@@ -328,13 +355,21 @@ class NativeDataset:
         from . import _native as nat
         L = nat.lib()
         total = 0
-        for blk, pos, minus, score, ids_part in self._segments(lo, count, ids_u8, index_range, rescore, ids_rev):
+        for blk, pos, minus, score, ids_part, (feat_idx, ot) in self._segments(lo, count, ids_u8, index_range, rescore, ids_rev):
             written = ctypes.c_uint64()
-            st = L.crp_write_rows(
+            if feat_idx is not None:
+                feat_idx = np.ascontiguousarray(feat_idx)
+            if ot is not None:
+                ot = np.ascontiguousarray(ot)
+            st = L.crp_write_rows_ex(
                 fd, blk.text.ctypes.data_as(nat.u8p), blk.text.size,
                 ctypes.cast(ctypes.c_char_p(blk.chrom), nat.u8p), len(blk.chrom), blk.guide_len,
                 pos.ctypes.data_as(nat.u32p), minus.ctypes.data_as(nat.u8p),
                 score.ctypes.data_as(nat.f64p), ids_part.ctypes.data_as(nat.u8p), pos.size,
+                None if feat_idx is None else blk.feat_blob.ctypes.data_as(nat.u8p),
+                None if feat_idx is None else blk.feat_off.ctypes.data_as(nat.u64p),
+                None if feat_idx is None else feat_idx.ctypes.data_as(nat.u32p),
+                None if ot is None else ot.ctypes.data_as(nat.u32p),
                 ctypes.byref(written), self.n_threads)
             total += written.value
             if st == nat.CRP_ERR_IO:

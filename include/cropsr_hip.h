@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define CRP_ABI_VERSION 1
+#define CRP_ABI_VERSION 2
 
 typedef enum crp_status {
     CRP_OK = 0,
@@ -49,7 +49,8 @@ typedef enum crp_status {
     CRP_ERR_STATE = -5,       /* call out of order (e.g. scan before seal) */
     CRP_ERR_CAPACITY = -6,    /* arena capacity exceeded */
     CRP_ERR_UNSUPPORTED = -7, /* e.g. guide length outside [1, 50] */
-    CRP_ERR_IO = -8           /* write(2) on the caller's descriptor failed; errno is left set */
+    CRP_ERR_IO = -8,          /* write(2) on the caller's descriptor failed; errno is left set */
+    CRP_ERR_COMM = -9         /* an RCCL call failed or librccl.so could not be loaded; see crp_last_error */
 } crp_status;
 
 typedef struct crp_ctx crp_ctx;
@@ -197,6 +198,93 @@ int crp_legacy_ids(uint32_t *mt_key, int32_t *mt_pos, uint8_t *ids, uint64_t n_r
 int crp_fasta_table(const uint8_t *data, uint64_t n, uint8_t *out_text, uint64_t out_cap, uint64_t *records,
                     uint64_t records_cap, uint64_t *n_records, uint64_t *out_len, int *plain, int n_threads);
 
+/* The same rows with the two OPT-IN extensions of this engine (both absent from the reference, whose
+ * default output stays byte-identical when they are not asked for):
+ *   features    the `features` column (always '' in the reference, CROPSR.py:466-468): a table of
+ *               strings, entry t = feat_blob[feat_off[t] : feat_off[t+1]], and per row the entry it
+ *               gets, feat_idx[r] (0xFFFFFFFF: ''); csv-quoted as needed.  feat_idx NULL = ''.
+ *               Rows without a cutsite (the 11-field rows) keep ''.
+ *   offtarget   4 x uint32 per row appended as four more columns (crp_offtarget_counts);
+ *               0xFFFFFFFF prints as -1.  NULL = no extra columns.
+ * With both NULL this is crp_write_rows. */
+int crp_write_rows_ex(int fd, const uint8_t *contig_text, uint64_t contig_len, const uint8_t *chrom, uint64_t chrom_len,
+                      int guide_len, const uint32_t *pos, const uint8_t *minus, const double *score,
+                      const uint8_t *ids, uint64_t n_rows, const uint8_t *feat_blob, const uint64_t *feat_off,
+                      const uint32_t *feat_idx, const uint32_t *offtarget, uint64_t *bytes_written, int n_threads);
+
+/* ---- multi-GPU: one process per GPU, RCCL over xGMI ------------------------ */
+/* The reference has no parallelism (its only hint is the dead cropsr_functions.py:256-273).  The path
+ * shards by contig with no collective on the data path; the one exchange is the final gatherv of the
+ * per-rank hit tables to a root.  RCCL has no gatherv: crp_gather_hits does an all-gather of the two
+ * counts, then ncclGroupStart / ncclSend|ncclRecv per column / ncclGroupEnd -- every peer->root
+ * transfer on its own xGMI link.  librccl.so is loaded on the first crp_comm_* call, never before.
+ * The 128-byte id comes from crp_comm_unique_id on one rank and reaches the others through the
+ * launcher (cropsr_amd/rendezvous.py: a socket of its own, not torch). */
+#define CRP_COMM_ID_BYTES 128
+int crp_comm_unique_id(uint8_t id[CRP_COMM_ID_BYTES]);
+int crp_comm_init(crp_ctx *ctx, const uint8_t id[CRP_COMM_ID_BYTES], int rank, int world);
+int crp_comm_destroy(crp_ctx *ctx);
+/* All ranks: returns when every rank has called it and the library's stream has drained. */
+int crp_comm_barrier(crp_ctx *ctx);
+/* Element-wise reduction of n (<= 64) host doubles over all ranks, result on every rank. */
+#define CRP_REDUCE_SUM 0
+#define CRP_REDUCE_MAX 1
+int crp_comm_allreduce_f64(crp_ctx *ctx, double *values, int n, int op);
+/* All ranks, after crp_scan_score on `arena` (NULL: this rank contributes empty tables): gathers the
+ * '+' and '-' tables (pos u32, score f64) of every rank into root's HBM.  flags (the same on every
+ * rank): CRP_GATHER_OFFTARGET also gathers the per-hit off-target counts (crp_offtarget_counts must
+ * have run on `arena`).  counts_all (2 x world values, may be NULL) receives every rank's
+ * {n_plus, n_minus} on every rank. */
+#define CRP_GATHER_OFFTARGET 1
+/* CRP_GATHER_PRE: the f64 column that travels is the pre-sigmoid sum (crp_scan_score with want_pre)
+ * instead of the score -- for a root that applies its own host's exp (cli --score-finalize=host). */
+#define CRP_GATHER_PRE 2
+int crp_gather_hits(crp_ctx *ctx, crp_arena *arena, int root, int flags, uint64_t *counts_all);
+/* Root only: copy the tables rank `rank` contributed to the last crp_gather_hits to host arrays
+ * (sizes from counts_all; ot_*: 4 x uint32 per hit; any pointer may be NULL). */
+int crp_gathered_fetch(crp_ctx *ctx, int rank, uint32_t *pos_plus, double *score_plus, uint32_t *ot_plus,
+                       uint32_t *pos_minus, double *score_minus, uint32_t *ot_minus);
+
+/* ---- off-target seed scan (opt-in; absent from the reference) ------------- */
+/* BASELINE.json configs[4]: genome-wide off-target <=3-mismatch seed scan.  The reference has no such
+ * step (its only alignment code is the dead bowtie2 shell-out of prmrdsgn2.py:139-160), so the
+ * definition is this engine's own, stated on the reference's own strings:
+ *   site   every kept hit of the scan (either strand, CROPSR.py:419/:430) whose `sequence` column
+ *          (CROPSR.py:420/:431) has >= 12 characters of which the first 12 -- the PAM-proximal seed --
+ *          are bases after the scoring transform of CROPSR.py:458 (.replace('U','T').upper() in ACGT)
+ *   count  for a site g and k = 0..3: the number of OTHER sites whose seed differs from g's in
+ *          exactly k of the 12 positions
+ * Genome-wide means: over every arena added between crp_offtarget_reset and crp_offtarget_solve, on
+ * every rank of the communicator (crp_offtarget_reduce).  Method: a histogram of the 4^12 seeds, then
+ * the exact Hamming-ball sums of that histogram for all seeds at once by a position-wise recurrence
+ * (three passes of four positions through LDS), then one 16-byte look-up per hit -- no pairwise
+ * comparison anywhere. */
+#define CRP_OT_SEED_LEN 12
+#define CRP_OT_MAX_MM 3
+/* Allocates (first call) and zeroes the site histogram of this context. */
+int crp_offtarget_reset(crp_ctx *ctx);
+/* After crp_scan_score on `arena`: derives the seed of every kept hit and adds the sites to the
+ * histogram.  own_ranges (n_ranges pairs [begin, end) of arena positions, ascending, may be NULL =
+ * everything): only hits whose match position lies inside count as sites -- a contig cut into pieces
+ * with halos (multi-GPU) must not count its halo hits twice.  *n_sites (may be NULL): sites added. */
+int crp_offtarget_add(crp_arena *arena, int guide_len, const uint64_t *own_ranges, uint64_t n_ranges,
+                      uint64_t *n_sites);
+/* Multi-GPU: RCCL all-reduce (sum) of the histogram over the communicator -- the one bandwidth-heavy
+ * xGMI collective of this engine (64 MiB per rank).  Without a communicator: no-op. */
+int crp_offtarget_reduce(crp_ctx *ctx);
+/* The site histogram (4^12 uint32) to / from host memory: what a host-side exchange sums instead of
+ * crp_offtarget_reduce (ranks sharing one GPU, where RCCL cannot run), and what the tests check. */
+int crp_offtarget_hist_get(crp_ctx *ctx, uint32_t *hist);
+int crp_offtarget_hist_set(crp_ctx *ctx, const uint32_t *hist);
+/* Hamming-ball sums for all 4^12 seeds. */
+int crp_offtarget_solve(crp_ctx *ctx);
+/* Per-hit counts of `arena` (which must have been added): 4 x uint32 per hit, table order, k = 0..3;
+ * 0xFFFFFFFF x 4 for a hit that is not a site.  Host pointers may be NULL (counts stay in HBM). */
+int crp_offtarget_counts(crp_arena *arena, uint32_t *counts_plus, uint32_t *counts_minus);
+/* The seed codes of the same hits (uint32 per hit: sum of code_k << 2k, A=0 T=1 C=2 G=3, k = 0 next
+ * to the PAM; 0xFFFFFFFF not a site, 0xFFFFFFFE a site outside own_ranges), for tests. */
+int crp_offtarget_seeds(crp_arena *arena, uint32_t *seeds_plus, uint32_t *seeds_minus);
+
 /* ---- options -------------------------------------------------------------- */
 /* CRP_OPT_TWO_PASS (value 0/1, default 0): with 0 crp_scan_score is ONE kernel launch; the
  * table offsets come from a chained scan across workgroups inside it (decoupled look-back
@@ -206,7 +294,23 @@ int crp_fasta_table(const uint8_t *data, uint64_t n, uint8_t *out_text, uint64_t
  * look-back ever time out, the scan is repeated with the three-launch sequence and the
  * context stays in that mode. */
 #define CRP_OPT_TWO_PASS 1
+/* CRP_OPT_CHAIN_TIMEOUT_US (default 20000): how long a workgroup of the single-launch scan waits for
+ * a predecessor's counts before it gives up (wall time, read from the GPU's 100 MHz real-time
+ * counter).  A scan in which a wait ran out is repeated with the three-launch sequence; the next scan
+ * tries the single launch again.  Only after three such scans in a row does the context stay with
+ * three launches (crp_query reports both). */
+#define CRP_OPT_CHAIN_TIMEOUT_US 2
 int crp_configure(crp_ctx *ctx, int option, int64_t value);
+
+/* Read-only state, for logs and bench output. */
+#define CRP_Q_CHAIN_TIMEOUTS 1   /* single-launch scans that had to be repeated with three launches */
+#define CRP_Q_TWO_PASS_ACTIVE 2  /* 1 when scans currently run as three launches (configured or latched) */
+#define CRP_Q_COMM_WORLD 3       /* ranks of the RCCL communicator (0: none) */
+#define CRP_Q_COMM_RANK 4
+int crp_query(const crp_ctx *ctx, int what, int64_t *value);
+/* Identifies the build: a hash of the library's sources taken by the Makefile ("unknown" otherwise).
+ * profiles/traffic.json carries the id of the build it was measured on; bench.py refuses another. */
+const char *crp_build_id(void);
 
 /* ---- measurement --------------------------------------------------------- */
 /* on = 1: the emit+score kernel of every crp_scan_score is bracketed by HIP events
@@ -216,8 +320,22 @@ int crp_profile_enable(crp_ctx *ctx, int on);
  * index 0 = count pass, 1 = tile-offset scan (both only with CRP_OPT_TWO_PASS = 1),
  * 2 = emit+score pass (the whole scan with CRP_OPT_TWO_PASS = 0). */
 int crp_profile_read(crp_ctx *ctx, double ms[3], uint64_t launches[3], int reset);
+/* The same for any kernel kind (ms and launches since the last reset of that kind). */
+#define CRP_K_COUNT 0
+#define CRP_K_TILE_SCAN 1
+#define CRP_K_EMIT 2
+#define CRP_K_OT_SEED 3      /* off-target: seeds of the kept hits + site histogram */
+#define CRP_K_OT_BALL 4      /* off-target: the three Hamming-ball passes together */
+#define CRP_K_OT_LOOKUP 5    /* off-target: per-hit counts */
+#define CRP_K_GATHER 6       /* RCCL gatherv of the hit tables (count all-gather + grouped send/recv) */
+#define CRP_K_OT_REDUCE 7    /* RCCL all-reduce of the site histogram */
+#define CRP_K_KINDS 8
+int crp_profile_read_kind(crp_ctx *ctx, int kind, double *ms, uint64_t *launches, int reset);
 /* Blocks until everything queued on the library's stream has finished. */
 int crp_synchronize(crp_ctx *ctx);
+/* Number of rows of the last crp_scan_score that carry a real score (not -1), counted on the GPU:
+ * the unit of the "gRNAs scored" metric. */
+int crp_count_scored(crp_arena *arena, uint64_t *n_scored);
 
 #ifdef __cplusplus
 }

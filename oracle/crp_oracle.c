@@ -418,3 +418,105 @@ void orc_score_hits(const uint8_t *s, int64_t len, int l, const uint32_t *pos, i
         score_row(t, pre + k, score + k);
     }
 }
+
+/* ---------------------------------------------------------------- off-target
+ * The off-target seed scan has NO counterpart in the reference: parity
+ * is unpinned by construction.  What is pinned is the INPUT of the definition: it is stated on the
+ * reference's own `sequence` column (CROPSR.py:420 / :431), which this file restates literally
+ * (orc_short_sequence) and which tests/test_offtarget.py also takes from the reference's golden CSVs.
+ *
+ *   seed(g)  = the first 12 characters of sequence(g) after .replace('U','T').upper() (the scoring
+ *              transform of CROPSR.py:458), defined iff there are 12 and all are in ACGT
+ *   c_k(g)   = #{ sites s != g : hamming(seed(g), seed(s)) == k },  k = 0..3
+ *
+ * orc_seed_codes     seed -> 24-bit code, sum of code_k << 2k, alphabet order A,T,C,G of CROPSR.py:300
+ * orc_offtarget_pairs    the definition, all pairs: O(n^2)
+ * orc_offtarget_enum     an independent second method (histogram + enumeration of the 6 571 seeds
+ *                        within distance 3 of each distinct seed): for inputs too big for all pairs;
+ *                        tests/test_offtarget.py checks it against orc_offtarget_pairs first
+ */
+#define ORC_NOT_A_SITE 0xffffffffu
+
+void orc_seed_codes(const uint8_t *s, int64_t len, int l, const uint32_t *pos, int64_t n, int strand_minus,
+                    uint32_t *codes)
+{
+    uint8_t buf[512];
+    for (int64_t i = 0; i < n; ++i) {
+        const int64_t m = orc_short_sequence(s, len, pos[i], strand_minus, l, buf);
+        uint32_t code = 0;
+        int ok = m >= 12;
+        for (int k = 0; ok && k < 12; ++k) {
+            uint8_t c = buf[k];
+            if (c == 'U') c = 'T';                       /* .replace('U','T') */
+            if (c >= 'a' && c <= 'z') c = (uint8_t)(c - 32); /* .upper() */
+            const int b = base_index((char)c);
+            if (b < 0) ok = 0;
+            else code |= (uint32_t)b << (2 * k);
+        }
+        codes[i] = ok ? code : ORC_NOT_A_SITE;
+    }
+}
+
+static inline int seed_distance(uint32_t a, uint32_t b)
+{
+    const uint32_t x = a ^ b;
+    return __builtin_popcount((x | (x >> 1)) & 0x555555u);
+}
+
+/* counts: n x 4 */
+void orc_offtarget_pairs(const uint32_t *codes, int64_t n, uint32_t *counts)
+{
+    for (int64_t i = 0; i < n; ++i) {
+        uint32_t c[4] = {0, 0, 0, 0};
+        if (codes[i] == ORC_NOT_A_SITE) {
+            for (int k = 0; k < 4; ++k) counts[4 * i + k] = ORC_NOT_A_SITE;
+            continue;
+        }
+        for (int64_t j = 0; j < n; ++j) {
+            if (j == i || codes[j] == ORC_NOT_A_SITE) continue;
+            const int d = seed_distance(codes[i], codes[j]);
+            if (d <= 3) c[d]++;
+        }
+        for (int k = 0; k < 4; ++k) counts[4 * i + k] = c[k];
+    }
+}
+
+/* hist: 4^12 site counts (the caller may have summed several inputs into it).  counts of the codes
+ * given, minus the guide itself. */
+void orc_offtarget_hist_add(const uint32_t *codes, int64_t n, uint32_t *hist)
+{
+    for (int64_t i = 0; i < n; ++i)
+        if (codes[i] != ORC_NOT_A_SITE) hist[codes[i]]++;
+}
+
+static void ball_of(uint32_t seed, const uint32_t *hist, uint32_t c[4])
+{
+    c[0] = hist[seed];
+    c[1] = c[2] = c[3] = 0;
+    for (int p1 = 0; p1 < 12; ++p1)
+        for (uint32_t b1 = 1; b1 < 4; ++b1) {
+            const uint32_t s1 = seed ^ (b1 << (2 * p1));
+            c[1] += hist[s1];
+            for (int p2 = p1 + 1; p2 < 12; ++p2)
+                for (uint32_t b2 = 1; b2 < 4; ++b2) {
+                    const uint32_t s2 = s1 ^ (b2 << (2 * p2));
+                    c[2] += hist[s2];
+                    for (int p3 = p2 + 1; p3 < 12; ++p3)
+                        for (uint32_t b3 = 1; b3 < 4; ++b3) c[3] += hist[s2 ^ (b3 << (2 * p3))];
+                }
+        }
+}
+
+void orc_offtarget_enum(const uint32_t *codes, int64_t n, const uint32_t *hist, uint32_t *counts)
+{
+    for (int64_t i = 0; i < n; ++i) {
+        if (codes[i] == ORC_NOT_A_SITE) {
+            for (int k = 0; k < 4; ++k) counts[4 * i + k] = ORC_NOT_A_SITE;
+            continue;
+        }
+        uint32_t c[4];
+        ball_of(codes[i], hist, c);
+        c[0] -= 1;
+        for (int k = 0; k < 4; ++k) counts[4 * i + k] = c[k];
+    }
+}

@@ -162,3 +162,80 @@ def weights():
     c = np.empty(2)
     lib().orc_weights(_p(f, _f64p), _p(s, _f64p), _p(c, _f64p))
     return f, s, c
+
+
+# ---- off-target seed scan (no reference counterpart; see crp_oracle.c) -------------------------
+NOT_A_SITE = 0xFFFFFFFF
+N_SEEDS = 1 << 24
+
+
+def _ot_bind():
+    L = lib()
+    if not getattr(L, "_ot_bound", False):
+        L.orc_seed_codes.argtypes = [_u8p, ctypes.c_int64, ctypes.c_int, _u32p, ctypes.c_int64, ctypes.c_int, _u32p]
+        L.orc_offtarget_pairs.argtypes = [_u32p, ctypes.c_int64, _u32p]
+        L.orc_offtarget_hist_add.argtypes = [_u32p, ctypes.c_int64, _u32p]
+        L.orc_offtarget_enum.argtypes = [_u32p, ctypes.c_int64, _u32p, _u32p]
+        L._ot_bound = True
+    return L
+
+
+def seed_codes(s, pos, minus, l=20):
+    """24-bit seed code (or NOT_A_SITE) of every hit, from its literal `sequence` string."""
+    a = _as_u8(s)
+    pos = np.ascontiguousarray(pos, dtype=np.uint32)
+    out = np.empty(pos.size, dtype=np.uint32)
+    _ot_bind().orc_seed_codes(_p(a, _u8p), a.size, int(l), _p(pos, _u32p), pos.size, int(bool(minus)), _p(out, _u32p))
+    return out
+
+
+def seed_code_of_sequence(seq):
+    """The same code from a `sequence` string (e.g. a CSV cell of the reference): pure Python."""
+    t = seq.replace("U", "T").upper()
+    if len(t) < 12:
+        return NOT_A_SITE
+    code = 0
+    for k in range(12):
+        b = "ATCG".find(t[k])
+        if b < 0:
+            return NOT_A_SITE
+        code |= b << (2 * k)
+    return code
+
+
+def offtarget_pairs(codes):
+    """(n, 4) counts by the definition: all pairs."""
+    codes = np.ascontiguousarray(codes, dtype=np.uint32)
+    out = np.empty((codes.size, 4), dtype=np.uint32)
+    _ot_bind().orc_offtarget_pairs(_p(codes, _u32p), codes.size, _p(out, _u32p))
+    return out
+
+
+def offtarget_hist(code_arrays, hist=None):
+    """Histogram of the sites in the given code arrays (added to `hist` if given)."""
+    if hist is None:
+        hist = np.zeros(N_SEEDS, dtype=np.uint32)
+    for codes in code_arrays:
+        codes = np.ascontiguousarray(codes, dtype=np.uint32)
+        _ot_bind().orc_offtarget_hist_add(_p(codes, _u32p), codes.size, _p(hist, _u32p))
+    return hist
+
+
+def offtarget_enum(codes, hist):
+    """(n, 4) counts by histogram + neighbour enumeration (second, independent method)."""
+    codes = np.ascontiguousarray(codes, dtype=np.uint32)
+    out = np.empty((codes.size, 4), dtype=np.uint32)
+    _ot_bind().orc_offtarget_enum(_p(codes, _u32p), codes.size, _p(hist, _u32p), _p(out, _u32p))
+    return out
+
+
+def offtarget_genome(contigs, l=20):
+    """Genome-wide scan over contig strings: per contig dict(ot_plus, ot_minus, seed_plus, seed_minus)."""
+    per, hist = [], np.zeros(N_SEEDS, dtype=np.uint32)
+    for c in contigs:
+        plus, minus = scan(c, l)
+        sp, sm = seed_codes(c, plus, False, l), seed_codes(c, minus, True, l)
+        offtarget_hist([sp, sm], hist)
+        per.append((sp, sm))
+    return [dict(seed_plus=sp, seed_minus=sm, ot_plus=offtarget_enum(sp, hist), ot_minus=offtarget_enum(sm, hist))
+            for sp, sm in per]

@@ -81,39 +81,89 @@ def golden_fasta_path(name, tmp_path):
     return os.path.join(GOLDEN, "probe_%s.fa" % name)
 
 
-class OracleBackend:
-    """cli backend built on the CPU oracle, for pinning the host logic without a GPU."""
+class OracleResident:
+    """parallel.sharded_scan's Resident on the CPU oracle: one host "arena" with the texts at
+    64-aligned offsets separated like the device arena."""
 
-    def __init__(self, orc):
-        self.orc = orc
-
-    def scan(self, strings, l):
-        return [self.orc.scan_score(s.encode("ascii", "replace") if isinstance(s, str) else s, l) for s in strings]
-
-    def scan_tables(self, texts, l):
-        """What EngineBackend.scan_tables returns, from the oracle: CPU tensors with arena positions
-        (texts at 64-aligned offsets separated like the device arena), for parallel.sharded_scan."""
+    def __init__(self, orc, texts, l):
         import numpy as np
-        import torch
-        off, layout = 64, []
+        self.orc, self.l = orc, l
+        self.texts, self.layout, self.hits = [bytes(t) for t in texts], [], []
+        off = 64
         cols = {c: [] for c in ("pos_plus", "score_plus", "pos_minus", "score_minus")}
-        for t in texts:
-            h = self.orc.scan_score(bytes(t), l)
-            layout.append((off, len(t)))
+        for t in self.texts:
+            h = orc.scan_score(t, l)
+            self.hits.append(h)
+            self.layout.append((0, off, len(t)))
             cols["pos_plus"].append(h["pos_plus"] + np.uint32(off))
             cols["pos_minus"].append(h["pos_minus"] + np.uint32(off))
             cols["score_plus"].append(h["score_plus"])
             cols["score_minus"].append(h["score_minus"])
             off += ((len(t) + 63) // 64 + 1) * 64
         cat = lambda xs, dt: np.concatenate(xs).astype(dt) if xs else np.empty(0, dtype=dt)
-        tables = {"pos_plus": torch.from_numpy(cat(cols["pos_plus"], np.uint32).view(np.int32)),
-                  "score_plus": torch.from_numpy(cat(cols["score_plus"], np.float64)),
-                  "pos_minus": torch.from_numpy(cat(cols["pos_minus"], np.uint32).view(np.int32)),
-                  "score_minus": torch.from_numpy(cat(cols["score_minus"], np.float64))}
-        return tables, layout, lambda: None
+        self.cols = {"pos_plus": cat(cols["pos_plus"], np.uint32), "score_plus": cat(cols["score_plus"], np.float64),
+                     "pos_minus": cat(cols["pos_minus"], np.uint32), "score_minus": cat(cols["score_minus"], np.float64)}
+
+    def offtarget(self, group, own_by_arena):
+        """The seed scan by the oracle's histogram + enumeration method, sites of all ranks."""
+        import numpy as np
+        orc = self.orc
+        own = np.asarray(own_by_arena[0] if own_by_arena else [], dtype=np.int64).reshape(-1, 2)
+        seeds = {"plus": [], "minus": []}
+        for t, h, (_, off, _ln) in zip(self.texts, self.hits, self.layout):
+            for strand, minus in (("plus", False), ("minus", True)):
+                codes = orc.seed_codes(t, h["pos_" + strand], minus, self.l)
+                p = h["pos_" + strand].astype(np.int64) + off
+                mine = np.zeros(p.size, dtype=bool)
+                for b, e in own:
+                    mine |= (p >= b) & (p < e)
+                codes[~mine] = orc.NOT_A_SITE  # a neighbour's halo: not this rank's site
+                seeds[strand].append(codes)
+        cat = lambda xs: np.concatenate(xs) if xs else np.empty(0, np.uint32)
+        sp, sm = cat(seeds["plus"]), cat(seeds["minus"])
+        hist = orc.offtarget_hist([sp, sm])
+        idx = np.flatnonzero(hist)
+        total = np.zeros_like(hist)
+        for i, v in group.all_gather((idx, hist[idx])):
+            np.add.at(total, i, v)
+        self.cols["ot_plus"], self.cols["ot_minus"] = orc.offtarget_enum(sp, total), orc.offtarget_enum(sm, total)
+
+    def gather(self, group, dst, offtarget):
+        from cropsr_amd import parallel
+        return parallel.gather_host(group, [self.cols], dst, offtarget)
+
+    def release(self):
+        pass
+
+
+class OracleBackend:
+    """cli backend built on the CPU oracle, for pinning the host logic without a GPU."""
+
+    def __init__(self, orc, finalize="gpu"):
+        self.orc = orc
+        self.finalize = finalize
+
+    def _sigmoid(self, pre):
+        from cropsr_amd import cli
+        return cli.host_sigmoid(pre)
+
+    def scan(self, strings, l, offtarget=False):
+        texts = [s.encode("ascii", "replace") if isinstance(s, str) else bytes(s) for s in strings]
+        out = [self.orc.scan_score(t, l) for t in texts]
+        if self.finalize == "host":
+            for h in out:
+                h["score_plus"], h["score_minus"] = self._sigmoid(h["pre_plus"]), self._sigmoid(h["pre_minus"])
+        if offtarget:
+            for h, ot in zip(out, self.orc.offtarget_genome(texts, l)):
+                h["ot_plus"], h["ot_minus"] = ot["ot_plus"], ot["ot_minus"]
+        return out
+
+    def scan_resident(self, texts, l):
+        return OracleResident(self.orc, texts, l)
 
     def rescore(self, rows_u8, order):
-        return self.orc.score30_order(rows_u8, order)[1]
+        pre, score = self.orc.score30_order(rows_u8, order)
+        return self._sigmoid(pre) if self.finalize == "host" else score
 
 
 def oracle_scan_provider(orc):
