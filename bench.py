@@ -5,26 +5,31 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
+(torch.distributed.run is only the launcher: this program imports no PyTorch.  The ranks find
+each other through cropsr_amd.rendezvous and talk over RCCL inside libcropsr_hip.so.)
+
 A step = one pass of the hot path (crp_scan_score: ONE kernel launch that scans, compacts and
 scores, taking its table offsets from a chained scan across workgroups; --two-pass selects the
 count -> tile scan -> emit+score launch sequence instead) over the rank's arena, with the packed
-genome already resident in HBM.  Contigs are
-independent, so at N > 1 the steps run with NO collective on the data path; the
-path's one exchange -- the FINAL RCCL gatherv of the per-rank hit tables to rank 0 --
-runs once after the timed steps and is reported on its own (`gatherv`), together with
-the rate that includes it (`value_with_final_gatherv`).  --gather-every-step puts it
-inside every step instead.
+genome already resident in HBM.  Contigs are independent, so at N > 1 the steps run with NO
+collective on the data path; the path's one exchange -- the FINAL RCCL gatherv of the per-rank hit
+tables to rank 0 (crp_gather_hits) -- runs once after the timed steps and is reported on its own
+(`gatherv`), together with the rate that includes it (`value_with_final_gatherv`).
+--gather-every-step puts it inside every step instead.  A failed exchange still prints the line
+(`gatherv_ok: false`) and then exits non-zero.
 Workload at N = 1: the >= 1 Gb crop genome BASELINE.json's target is quoted on
 ("switchgrass-like", SURVEY.md 8d cfg 5, seeded synthetic).  Weak scaling: N ranks
 process N such genomes (seeds 0..N-1), contigs dealt to ranks by LPT.
 
-Rank 0 prints ONE JSON line (contract in the task statement) with `roofline`
-(HIP-event timing of the emit+score kernel on the library's stream) and, at N = 1,
-`cpu_baseline` (the reference-faithful numpy port on a bounded sample).
+Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` (HIP-event timing of
+the emit+score kernel on the library's stream), `offtarget` (the opt-in genome-wide seed scan of
+cfg 5 on the same resident genome, its own steps and roofline) and, at N = 1, `cpu_baseline` (the
+reference-faithful numpy port on a bounded sample: one core, and all cores for BLAS).
 """
 import argparse
 import json
 import os
+import resource
 import sys
 import time
 
@@ -32,6 +37,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+N_SIMD = 1024          # 256 CUs x 4
 
 
 def parse_args():
@@ -46,12 +52,14 @@ def parse_args():
     ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the final RCCL gatherv altogether")
     ap.add_argument("--gather-every-step", action="store_true",
                     help="N > 1: run the gatherv inside every timed step instead of once at the end")
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="torch.distributed backend; gloo (+ --share-gpu0) rehearses the N > 1 control flow on one GPU")
-    ap.add_argument("--share-gpu0", action="store_true", help="rehearsal only: every rank uses device 0")
+    ap.add_argument("--share-gpu0", action="store_true",
+                    help="rehearsal only: every rank uses device 0; fences and sums go over the control sockets and "
+                         "the gatherv over the host transport (RCCL cannot put two ranks on one GPU)")
+    ap.add_argument("--offtarget-steps", type=int, default=5,
+                    help="timed steps of the off-target seed scan (0 = skip that block)")
     ap.add_argument("--cpu-sample-bases", type=int, default=40000000,
                     help="upper bound on the bases of the same workload timed on the CPU port; the actual "
-                         "sample is sized for about 12 s of CPU work (0 = skip)")
+                         "sample is sized for about 12 s of CPU work per leg (0 = skip)")
     return ap.parse_args()
 
 
@@ -64,62 +72,93 @@ def make_workload(name, genome, scale):
     return bw.ecoli_like()
 
 
-def cpu_baseline(sample_string, n_bases):
-    """Reference-faithful numpy port (oracle/faithful_port.py) on one core."""
-    from oracle import faithful_port as fp
+def _cpu_leg(fp, sample_string, n_bases, threads, seconds):
+    """One timed run of the reference-faithful port with `threads` BLAS threads."""
     try:
         from threadpoolctl import threadpool_limits
-        ctx = threadpool_limits(limits=1)
+        ctx = threadpool_limits(limits=threads)
     except Exception:  # pragma: no cover
         import contextlib
         ctx = contextlib.nullcontext()
     with ctx:
-        # size the sample for about 12 s of CPU work: time a 200 kb probe first
+        # size the sample for about `seconds` of CPU work: time a 200 kb probe first
         probe = min(200000, n_bases)
         t0 = time.perf_counter()
         fp.scan_score(sample_string[:probe + 1])
         rate = probe / (time.perf_counter() - t0)
-        n_bases = int(min(n_bases, max(probe, 12.0 * rate)))
+        n_bases = int(min(n_bases, max(probe, seconds * rate)))
+        ru0 = resource.getrusage(resource.RUSAGE_SELF)
         t0 = time.perf_counter()
         rows, scores = fp.scan_score(sample_string[:n_bases + 1])
         dt = time.perf_counter() - t0
+        ru1 = resource.getrusage(resource.RUSAGE_SELF)
     scored = int((scores != -1.0).sum())
-    return {"value": scored / dt, "unit": "gRNAs/s", "cores": 1, "kind": "port",
-            "sample": "first %d bases of contig 0 of the same workload, scan+score only "
-                      "(%d gRNAs in %.1f s; %.1f kb/s)" % (n_bases, scored, dt, n_bases / dt / 1e3)}
+    return {"value": scored / dt, "cores": threads, "bases": n_bases, "gRNAs": scored, "wall_s": dt,
+            "user_s": ru1.ru_utime - ru0.ru_utime, "sys_s": ru1.ru_stime - ru0.ru_stime,
+            "minor_faults": ru1.ru_minflt - ru0.ru_minflt}
+
+
+def cpu_baseline(sample_string, n_bases):
+    """Reference-faithful numpy port (oracle/faithful_port.py) on one core, then with every host core
+    available to BLAS -- the reference's only multi-threaded calls are its two np.matmul
+    (CROPSR.py:305,311).  user/sys seconds and page faults are reported because the reference's
+    scorer is page-fault bound (12 KB of fresh temporaries per gRNA): its speed depends on the host's
+    memory system far more than on its cores."""
+    from oracle import faithful_port as fp
+    try:
+        n_cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n_cores = os.cpu_count() or 1
+    one = _cpu_leg(fp, sample_string, n_bases, 1, 12.0)
+    out = {"value": one["value"], "unit": "gRNAs/s", "cores": 1, "kind": "port",
+           "sample": "first %d bases of contig 0 of the same workload, scan+score only (%d gRNAs in %.1f s; %.1f kb/s; "
+                     "user %.1f s, sys %.1f s, %d minor page faults)"
+                     % (one["bases"], one["gRNAs"], one["wall_s"], one["bases"] / one["wall_s"] / 1e3,
+                        one["user_s"], one["sys_s"], one["minor_faults"]),
+           "calibration": "profiles/cpu_calibration.json (real reference vs this port, development container)"}
+    if n_cores > 1:
+        allc = _cpu_leg(fp, sample_string, n_bases, n_cores, 8.0)
+        out["all_cores"] = {"value": allc["value"], "unit": "gRNAs/s", "cores": n_cores,
+                            "sample": "first %d bases, %d gRNAs in %.1f s (user %.1f s, sys %.1f s)"
+                                      % (allc["bases"], allc["gRNAs"], allc["wall_s"], allc["user_s"], allc["sys_s"])}
+    return out
+
+
+def load_profile_facts(build_id, workload):
+    """HBM traffic and VALU instruction counts per launch of the emit kernel, from the committed
+    rocprofv3 summary -- used only if it was measured on THIS build of the library and this workload."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(path):
+        return None, "no profiles/traffic.json"
+    with open(path) as f:
+        tj = json.load(f)
+    if tj.get("workload") != workload or tj.get("kernel") != "emit_kernel":
+        return None, "profiles/traffic.json is for another workload"
+    if tj.get("build_id") != build_id:
+        return None, "profiles/traffic.json was measured on build %s, this is %s: stale, not used" % (tj.get("build_id"), build_id)
+    return tj, tj.get("source", "profiles/traffic.json")
 
 
 def main():
     args = parse_args()
     import numpy as np
-    import torch
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = 0 if args.share_gpu0 else int(os.environ.get("LOCAL_RANK", "0"))
+    from cropsr_amd import Engine, parallel, rendezvous
+    from cropsr_amd import _native as nat
+
+    group = rendezvous.Group.from_env()
+    rank = group.rank if group else 0
+    world = group.world if group else 1
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        if args.backend == "nccl":
-            # a collective that cannot complete must end in an exception, not in a hang or an abort:
-            # the bench line is printed either way (the final gatherv is wrapped in try/except)
-            import datetime
-            os.environ.setdefault("TORCH_NCCL_BLOCKING_WAIT", "1")
-            os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0")
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank),
-                                    timeout=datetime.timedelta(seconds=180))
-        else:
-            dist.init_process_group("gloo")
-
-    from cropsr_amd import Engine
-    from cropsr_amd import parallel
+    local_rank = 0 if args.share_gpu0 else (group.local_rank if group else 0)
+    use_rccl = world > 1 and not args.share_gpu0
 
     eng = Engine(local_rank)  # raises without libcropsr_hip.so / GPU: no fallback
     if args.two_pass:
         eng.configure(two_pass=True)
+    if use_rccl:
+        eng.comm_init(group)  # RCCL communicator inside the library; the id travels over the control sockets
 
     # ---- workload: `world` genomes, contigs dealt to ranks by LPT (weak scaling)
     genomes = [make_workload(args.workload, g, args.scale) for g in range(world)]
@@ -145,30 +184,37 @@ def main():
     arena = builder.seal()
     t_gen = time.perf_counter() - t_gen
 
-    gather = None
-    if world > 1 and not args.no_gather:
-        gather = parallel.TableGather(dst=0)
+    def gatherv(n_plus, n_minus):
+        if use_rccl:
+            return eng.gather_hits(arena, 0)
+        cols = arena.fetch(n_plus, n_minus)  # host transport (rehearsal): D2H, then the control sockets
+        return parallel.gather_host(group, [dict(zip(("pos_plus", "score_plus", "pos_minus", "score_minus"),
+                                                      (cols[0], cols[2], cols[3], cols[5])))], 0)
+
+    want_gather = world > 1 and not args.no_gather
 
     def step():
         n_plus, n_minus = arena.scan_score_device(20, want_pre=False)
-        if gather is not None and args.gather_every_step:
-            gather(parallel.device_tables_as_tensors(arena, n_plus, n_minus))
+        if want_gather and args.gather_every_step:
+            gatherv(n_plus, n_minus)
         return n_plus, n_minus
 
     def fence():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+        nat.check(nat.lib().crp_synchronize(eng._ctx), "crp_synchronize", eng._ctx)
+        if use_rccl:
+            eng.comm_barrier()  # all-reduce on the library's stream + stream sync
+        elif group:
+            group.barrier()
 
-    for _ in range(args.warmup):
+    def reduce(values, op):
+        if use_rccl:
+            return eng.comm_allreduce(values, op)
+        return group.allreduce(values, op) if group else [float(v) for v in values]
+
+    for _ in range(max(1, args.warmup)):
         n_plus, n_minus = step()
-    if args.warmup == 0:
-        n_plus, n_minus = arena.scan_score_device(20, want_pre=False)
-    # units: kept hits that got a real score (a complete 30-window)
-    t = parallel.device_tables_as_tensors(arena, n_plus, n_minus)
-    scored = int((t["score_plus"] != -1.0).sum().item() + (t["score_minus"] != -1.0).sum().item())
-    del t
+    # units: kept hits that got a real score (a complete 30-window), counted on the GPU
+    scored = arena.count_scored()
     t_fetch = time.perf_counter()
     if rank == 0:
         arena.fetch(n_plus, n_minus)  # D2H of the tables into pageable numpy arrays (outside the timed region)
@@ -191,49 +237,98 @@ def main():
     prof = eng.profile_read(reset=True)
     prof["count"], prof["tile_scan"] = side["count"], side["tile_scan"]
     eng.profile(0)
+    state = eng.query()
 
-    tot = torch.tensor([dt, float(scored), float(my_bases), float(n_plus + n_minus)], dtype=torch.float64,
-                       device="cuda")
-    if dist is not None:
-        mx = tot[:1].clone()
-        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-        sm = tot[1:].clone()
-        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
-        dt = float(mx.item())
-        scored_all, bases_all, hits_all = [float(x) for x in sm.tolist()]
-    else:
-        scored_all, bases_all, hits_all = float(scored), float(my_bases), float(n_plus + n_minus)
+    dt = reduce([dt], "max")[0]
+    scored_all, bases_all, hits_all = reduce([scored, my_bases, n_plus + n_minus], "sum")
 
     # the final exchange, once, timed on its own (barrier + sync on both sides, max over ranks)
     gather_info = None
-    if gather is not None and not args.gather_every_step:
+    if want_gather and not args.gather_every_step:
         try:
-            gather(parallel.device_tables_as_tensors(arena, n_plus, n_minus))  # warm-up: RCCL sets up its P2P channels
+            gatherv(n_plus, n_minus)  # warm-up: RCCL sets up its point-to-point channels
             fence()
             tg = time.perf_counter()
-            gather(parallel.device_tables_as_tensors(arena, n_plus, n_minus))
+            gatherv(n_plus, n_minus)
             fence()
             tg = time.perf_counter() - tg
             gather_info = {"s": tg}  # rank 0 finishes last: it waits for every receive
-        except Exception as e:  # keep the bench line even if the exchange fails on this node
+        except Exception as e:  # the bench line is printed even if the exchange fails on this node
             gather_info = {"error": repr(e)[:300]}
+
+    # ---- the opt-in off-target seed scan of cfg 5 on the same resident genome and hit tables
+    ot = None
+    if args.offtarget_steps > 0 and not (gather_info and "error" in gather_info):
+        try:
+            def ot_step():
+                eng.offtarget_reset()
+                sites = arena.offtarget_add(20)
+                if use_rccl:
+                    eng.offtarget_reduce()  # 64 MiB all-reduce of the site histogram over xGMI
+                eng.offtarget_solve()
+                arena.offtarget_counts(n_plus, n_minus, fetch=False)
+                return sites
+            sites = ot_step()
+            eng.profile(2)
+            eng.profile_read(reset=True)
+            fence()
+            t1 = time.perf_counter()
+            for _ in range(args.offtarget_steps):
+                ot_step()
+            fence()
+            dt_ot = reduce([time.perf_counter() - t1], "max")[0]
+            pot = eng.profile_read(reset=True)
+            eng.profile(0)
+            sites_all = reduce([sites], "sum")[0]
+            per = {k: pot[k]["ms"] / max(1, pot[k]["launches"]) for k in ("ot_seed", "ot_ball", "ot_lookup", "ot_reduce")}
+            hits = n_plus + n_minus
+            # algorithmic bytes of one step on this rank: seeds 4 B pos in + 4 B seed out
+            # per hit + the 12 characters next to the PAM out of 4 planes (counted as 4 x 8 B words) + one 4-byte
+            # atomic per site; ball passes 64 MiB in, 3 x 256 MiB out, 2 x 256 MiB back in; look-up 4 + 16 + 16 B per hit
+            seed_bytes = hits * (4 + 4 + 32) + sites * 4
+            ball_bytes = (1 << 24) * (4 + 16 * 5)
+            look_bytes = hits * (4 + 16 + 16)
+            ot = {"metric": "guides off-target-scanned/sec", "value": hits_all * args.offtarget_steps / dt_ot,
+                  "unit": "guides/s", "steps": args.offtarget_steps, "ms_per_step": dt_ot / args.offtarget_steps * 1e3,
+                  "sites_total": int(sites_all), "seed_len": 12, "max_mismatches": 3,
+                  "kernels_ms": per,
+                  "roofline": {"bound": "hbm", "kernel": "ot_ball_kernel x3 (Hamming-ball sums over all 4^12 seeds)",
+                               "achieved": ball_bytes / (per["ot_ball"] * 1e-3) / 1e9 if per["ot_ball"] else None,
+                               "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": ball_bytes / (per["ot_ball"] * 1e-3) / 1e9 / HBM_PEAK_GBS if per["ot_ball"] else None,
+                               "traffic": None, "algorithmic_bytes_per_launch": int(ball_bytes),
+                               "seed_kernel_GBps": seed_bytes / (per["ot_seed"] * 1e-3) / 1e9 if per["ot_seed"] else None,
+                               "lookup_kernel_GBps": look_bytes / (per["ot_lookup"] * 1e-3) / 1e9 if per["ot_lookup"] else None},
+                  "parity": "unpinned: the reference has no off-target step (oracle: oracle/crp_oracle.c all-pairs)"}
+        except Exception as e:
+            ot = {"error": repr(e)[:300]}
 
     if rank == 0:
         info = eng.device_info()
+        build_id = nat.lib().crp_build_id().decode()
         n_chars = arena.stats()["n_chars"]
         hits = n_plus + n_minus
         algo_bytes = (n_chars + 3) // 4 + 2 * ((n_chars + 7) // 8) + 12 * hits  # SURVEY.md 8d, rank 0's launch
         emit = prof["emit_score"]
         emit_ms = emit["ms"] / max(1, emit["launches"])
         achieved = algo_bytes / (emit_ms * 1e-3) / 1e9
-        path_ms = sum(p["ms"] / max(1, p["launches"]) for p in prof.values())
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            with open(tpath) as f:
-                tj = json.load(f)
-            if tj.get("workload") == genomes[0].name and tj.get("kernel") == "emit_kernel":
-                traffic = tj.get("hbm_bytes_per_launch")
+        path_ms = sum(prof[k]["ms"] / max(1, prof[k]["launches"]) for k in ("count", "tile_scan", "emit_score"))
+        facts, facts_src = load_profile_facts(build_id, genomes[0].name)
+        three_launches = bool(args.two_pass or state["two_pass_active"])
+        roof = {"bound": "hbm",
+                "kernel": "emit_kernel (scan+compact+score)" if three_launches else
+                          "emit_kernel, single launch (masks + chained tile offsets + compact + score)",
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": facts.get("hbm_bytes_per_launch") if facts else None, "traffic_source": facts_src,
+                "algorithmic_bytes_per_launch": int(algo_bytes),
+                "kernel_ms": emit_ms, "all_kernels_ms": path_ms,
+                "count_kernel_ms": prof["count"]["ms"] / max(1, prof["count"]["launches"]),
+                "tile_scan_ms": prof["tile_scan"]["ms"] / max(1, prof["tile_scan"]["launches"])}
+        if facts and facts.get("valu_insts_per_launch") and facts.get("kernel_cycles_per_launch"):
+            # the second, honest ceiling: the kernel is VALU-issue bound (one wave64 VALU instruction
+            # holds its SIMD for 4 cycles on average here): issue slots used / issue slots there were
+            roof["valu_issue_frac"] = facts["valu_insts_per_launch"] * 4.0 / N_SIMD / facts["kernel_cycles_per_launch"]
+            roof["valu_insts_per_launch"] = facts["valu_insts_per_launch"]
         line = {
             "metric": "gRNAs scored/sec", "value": scored_all * args.steps / dt, "unit": "gRNAs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -242,28 +337,24 @@ def main():
             "config": {"workload": genomes[0].name, "genomes": world, "contigs_per_genome": len(genomes[0].specs),
                        "bases_total": int(bases_all), "kept_hits_total": int(hits_all),
                        "guide_len": 20,
-                       # a look-back time-out would switch the context to the three-launch sequence for good
-                       "launches_per_step": 3 if (args.two_pass or side["count"]["launches"] > 0) else 1,
+                       "launches_per_step": 3 if three_launches else 1,
+                       # single-launch scans that timed out in a look-back and were repeated as three launches
+                       "chain_timeouts": state["chain_timeouts"],
                        "parallelism": ("contigs by LPT over %d ranks" % world) +
-                       ("" if gather is None else (" + %s gatherv to rank 0 " % ("RCCL" if args.backend == "nccl" else "gloo (host-staged)") +
-                                                   ("every step" if args.gather_every_step else "once, after the steps"))),
-                       "device": info["name"].strip()},
+                       ("" if not want_gather else (" + %s gatherv to rank 0 " % ("RCCL (in-library)" if use_rccl else "host-socket") +
+                                                    ("every step" if args.gather_every_step else "once, after the steps"))),
+                       "device": info["name"].strip(), "library_build": build_id},
             "bases_per_s": bases_all * args.steps / dt,
-            "roofline": {"bound": "hbm",
-                         "kernel": "emit_kernel (scan+compact+score)" if args.two_pass else
-                                   "emit_kernel, single launch (masks + chained tile offsets + compact + score)",
-                         "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "algorithmic_bytes_per_launch": int(algo_bytes),
-                         "kernel_ms": emit_ms, "all_kernels_ms": path_ms,
-                         "count_kernel_ms": prof["count"]["ms"] / max(1, prof["count"]["launches"]),
-                         "tile_scan_ms": prof["tile_scan"]["ms"] / max(1, prof["tile_scan"]["launches"])},
+            "roofline": roof,
             "setup_s": {"generate_pack_upload": t_gen},
             # host-buffer boundary: characters H2D + pack, one scan, tables D2H (never `value`)
             "pcie_inclusive": {"upload_pack_s": t_upload, "fetch_tables_s": t_fetch,
                                "gRNAs_per_s": scored / (t_upload + dt / args.steps + t_fetch)},
         }
+        if ot is not None:
+            line["offtarget"] = ot
         if gather_info is not None:
+            line["gatherv_ok"] = "s" in gather_info
             if "s" in gather_info:
                 moved = 12.0 * (hits_all - hits)  # bytes that crossed xGMI to rank 0
                 gather_info.update({"bytes_to_root": int(moved), "GB_per_s_into_root": moved / gather_info["s"] / 1e9})
@@ -276,13 +367,16 @@ def main():
             line["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
         print(json.dumps(line), flush=True)
 
+    failed = bool(gather_info and "error" in gather_info) or bool(ot and "error" in ot)
+    if failed:
+        # the communicator is in an unknown state after a failed exchange: no collective teardown,
+        # and the run must not be recorded as a clean success
+        sys.stdout.flush()
+        os._exit(1)
     arena.close()
     eng.close()
-    if dist is not None:
-        if gather_info is not None and "error" in gather_info:
-            sys.stdout.flush()
-            os._exit(0)  # the process group is in an unknown state after a failed exchange: no collective teardown
-        dist.destroy_process_group()
+    if group:
+        group.close()
 
 
 if __name__ == "__main__":

@@ -12,8 +12,6 @@ import os
 
 import numpy as np
 import pytest
-import torch  # noqa: F401  -- before libcropsr_hip.so: PyTorch-ROCm bundles its own HIP
-#                runtime, and the one that initialises first must be torch's (parallel.py)
 
 from conftest import (GOLDEN, LENGTH_CASES, PROBES, VERBOSE_CASES, golden_fasta_path, normalize_verbose,
                       read_golden_csv, run_cli)
@@ -567,75 +565,107 @@ def test_cut_contig_on_gpu_equals_whole(engine, oracle):
     assert_hits_equal(got, oracle.scan_score(c, 20), ctx="stitched")
 
 
-def test_device_table_views_are_zero_copy(engine):
-    """parallel.device_tables_as_tensors: torch views of the library's HBM tables."""
-    import torch
-    from cropsr_amd import parallel
+def test_device_tables_and_scored_count(engine, oracle):
+    """crp_hits_device hands out the addresses of the tables in HBM (for a device-side consumer) and
+    crp_count_scored counts, on the GPU, the rows that carry a real score."""
     rng = np.random.default_rng(8)
-    arena = engine.arena([rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), 200000).tobytes()])
+    c = b"'" + rng.choice(np.frombuffer(b"ACGTacgtNGG", dtype=np.uint8), 200000).tobytes() + b"')]"
+    arena = engine.arena([c])
     n_plus, n_minus = arena.scan_score_device(20)
-    t = parallel.device_tables_as_tensors(arena, n_plus, n_minus)
-    cols = arena.fetch(n_plus, n_minus)
-    assert t["pos_plus"].is_cuda and t["pos_plus"].data_ptr() == arena.device_tables()[0]
-    assert (t["pos_plus"].cpu().numpy().view(np.uint32) == cols[0]).all()
-    assert (bits(t["score_plus"].cpu().numpy()) == bits(cols[2])).all()
-    assert (t["pos_minus"].cpu().numpy().view(np.uint32) == cols[3]).all()
-    assert (bits(t["score_minus"].cpu().numpy()) == bits(cols[5])).all()
+    ptrs = arena.device_tables()
+    assert len(ptrs) == 4 and all(p for p in ptrs)
+    want = oracle.scan_score(c, 20)
+    assert arena.count_scored() == int((want["score_plus"] != -1).sum() + (want["score_minus"] != -1).sum())
     arena.close()
 
 
-def _nccl_world1(out_path):
-    import torch
-    import torch.distributed as dist
-    from cropsr_amd import Engine, parallel
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29533")
-    torch.cuda.set_device(0)
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+def _rccl_world1(out_path, port):
+    """One rank, the real transport: RCCL through the C ABI (crp_comm_init, crp_gather_hits,
+    crp_comm_allreduce_f64, crp_offtarget_reduce)."""
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, ROOT)
+    from cropsr_amd import Engine, rendezvous
+    group = rendezvous.Group(0, 1)
     eng = Engine(0)
-    arena = eng.arena([b"ACGGTCCAGGTTCCAAGG" * 500])
+    eng.comm_init(group)
+    ok = eng.query()["comm_world"] == 1
+    arena = eng.arena([b"ACGGTCCAGGTTCCAAGG" * 500, b"'" + b"GGACCTTGGCCAATTGGCCA" * 300 + b"')]"])
     n_plus, n_minus = arena.scan_score_device(20)
-    got = parallel.TableGather(dst=0)(parallel.device_tables_as_tensors(arena, n_plus, n_minus))
-    ok = len(got) == 1 and got[0]["pos_plus"].numel() == n_plus and got[0]["score_minus"].numel() == n_minus
-    dist.barrier()
-    dist.destroy_process_group()
+    eng.offtarget_reset()
+    arena.offtarget_add(20)
+    eng.offtarget_reduce()
+    eng.offtarget_solve()
+    ot = arena.offtarget_counts(n_plus, n_minus)
+    for _ in range(2):
+        counts = eng.gather_hits(arena, 0, offtarget=True)
+        got = eng.gathered_fetch(0, counts, offtarget=True)
+    cols = arena.fetch(n_plus, n_minus)
+    ok = ok and counts.tolist() == [[n_plus, n_minus]]
+    ok = ok and (got["pos_plus"] == cols[0]).all() and (got["pos_minus"] == cols[3]).all()
+    ok = ok and (got["score_plus"].view(np.uint64) == cols[2].view(np.uint64)).all()
+    ok = ok and (got["ot_plus"] == ot[0]).all() and (got["ot_minus"] == ot[1]).all()
+    ok = ok and eng.comm_allreduce([1.5, 2.0], "sum") == [1.5, 2.0] and eng.comm_allreduce([3.0], "max") == [3.0]
+    eng.comm_barrier()
+    ok = ok and eng.gather_hits(None, 0).tolist() == [[0, 0]]  # a rank with nothing to contribute
     arena.close()
     eng.close()
     with open(out_path, "w") as f:
         f.write("ok" if ok else "bad")
 
 
-def test_gather_runs_on_rccl_backend(tmp_path):
-    """The bench's N > 1 code path on the real backend (RCCL), as far as one GPU allows:
-    world_size 1, in a child process."""
-    import torch.multiprocessing as mp
+def test_gather_runs_on_rccl_in_library(tmp_path):
+    """The N > 1 code path on the real transport, as far as one GPU allows: a communicator of one
+    rank, in a child process (librccl.so is dlopen()ed by the library on the first crp_comm_* call)."""
+    import multiprocessing as mp
     out = str(tmp_path / "r.txt")
-    ctx = mp.get_context("spawn")
-    p = ctx.Process(target=_nccl_world1, args=(out,))
+    p = mp.get_context("spawn").Process(target=_rccl_world1, args=(out, 29533))
     p.start()
-    p.join(300)
+    p.join(600)
     assert p.exitcode == 0
     assert open(out).read() == "ok"
 
 
-def test_cli_multi_process_on_gpu(manifest, tmp_path):
+@pytest.mark.parametrize("extra", [(), ("--offtarget",)])
+def test_cli_multi_process_on_gpu(manifest, tmp_path, extra):
     """`python -m torch.distributed.run --nproc-per-node 2 -m cropsr_amd ...`: two processes, contigs
     cut into 100-character pieces and dealt to them, HIP tables gathered to rank 0, which writes the
-    reference's bytes.  One GPU here, so both ranks use device 0 and the exchange runs on gloo
-    (host-staged); on a multi-GPU node the same command without CROPSR_DIST_BACKEND uses RCCL."""
+    reference's bytes.  One GPU here, so both ranks use device 0 and the exchange runs over the control
+    sockets (CROPSR_GATHER=host; RCCL cannot put two ranks on one GPU); on a multi-GPU node the same
+    command without that variable moves the tables over RCCL.  With --offtarget the two ranks' site
+    histograms are summed and the output equals the one-process run."""
     import subprocess
     import sys
     from conftest import ROOT
     out_csv = tmp_path / "out.csv"
-    env = dict(os.environ, CROPSR_DIST_BACKEND="gloo", CROPSR_DIST_MAX_PIECE="100", PYTHONPATH=ROOT)
+    env = dict(os.environ, CROPSR_GATHER="host", CROPSR_DIST_MAX_PIECE="100", PYTHONPATH=ROOT)
+    common = ["-f", os.path.join(GOLDEN, "probe_mixed.fa"), "-g", os.path.join(GOLDEN, "sample_head.gff"), "--cas9",
+              "--seed", str(manifest["seed"]), "--device", "0"] + list(extra)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29541", "-m", "cropsr_amd", "-f", os.path.join(GOLDEN, "probe_mixed.fa"),
-           "-g", os.path.join(GOLDEN, "sample_head.gff"), "-o", str(out_csv), "--cas9", "--seed", str(manifest["seed"]),
-           "--device", "0"]
+           "--master-port", "29541", "-m", "cropsr_amd", "-o", str(out_csv)] + common
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=str(tmp_path), env=env)
     assert p.returncode == 0, p.stderr[-2000:]
-    assert out_csv.read_bytes() == read_golden_csv("mixed")
     assert manifest["cases"]["mixed"]["stdout"] in p.stdout
+    if not extra:
+        assert out_csv.read_bytes() == read_golden_csv("mixed")
+    else:
+        one = tmp_path / "one.csv"
+        q = subprocess.run([sys.executable, "-m", "cropsr_amd", "-o", str(one)] + common, capture_output=True, text=True,
+                           timeout=600, cwd=str(tmp_path), env=dict(os.environ, PYTHONPATH=ROOT))
+        assert q.returncode == 0, q.stderr[-2000:]
+        assert out_csv.read_bytes() == one.read_bytes()
+
+
+def test_no_pytorch_in_the_product_process():
+    """north_star: "no PyTorch" -- importing the package, opening the GPU and scanning pulls in no torch."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = ("import sys; sys.path.insert(0, %r); import cropsr_amd, cropsr_amd.cli, cropsr_amd.parallel, cropsr_amd.rendezvous;"
+            "e = cropsr_amd.Engine(0); a = e.arena([b'ACGGTCCAGGTTCCAAGG' * 50]); a.scan_score(20); e.close();"
+            "assert 'torch' not in sys.modules; print('clean')") % ROOT
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "clean" in p.stdout, p.stderr[-2000:]
 
 
 def test_bench_line_contract():
@@ -656,9 +686,13 @@ def test_bench_line_contract():
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["vs_baseline"] is None and d["value"] > 0
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert "traffic_source" in r and d["config"]["chain_timeouts"] == 0 and d["config"]["launches_per_step"] == 1
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and "sample" in c
+    assert c["all_cores"]["cores"] >= 1 and c["all_cores"]["value"] > 0
     assert "workload" in d["config"] and "model" not in d["config"]
+    o = d["offtarget"]
+    assert o["value"] > 0 and o["roofline"]["bound"] == "hbm" and o["sites_total"] > 0 and "error" not in o
 
 
 def test_randomised_arenas_vs_oracle(engine, oracle):
@@ -686,27 +720,39 @@ def test_randomised_arenas_vs_oracle(engine, oracle):
 
 def test_chain_timeout_falls_back_to_three_launches(oracle, monkeypatch):
     """The safety net of the single-launch mode: a tile that never publishes its counts (test hook
-    CRP_TEST_MUTE_TILE) makes every later look-back time out; the scan must come back with the
-    RIGHT tables all the same (repeated with count / scan / emit), say so in crp_last_error, and
-    the context must stay in three-launch mode."""
+    CRP_TEST_MUTE_TILE) makes every later look-back run out of its TIME allowance; the scan must come
+    back with the RIGHT tables all the same (repeated with count / scan / emit) and say so -- in
+    crp_last_error and in crp_query's counter.  The fallback is per scan: the next scan tries the
+    single launch again, and only three failures in a row latch the three-launch mode
+    (crp_configure(CRP_OPT_TWO_PASS, 0) clears the latch)."""
     from cropsr_amd import Engine
     from cropsr_amd import _native as nat
     monkeypatch.setenv("CRP_TEST_MUTE_TILE", "3")
     eng = Engine(0)
     monkeypatch.delenv("CRP_TEST_MUTE_TILE")
+    eng.configure(chain_timeout_us=2000)  # 2 ms instead of the default 20: the test times out four times
     rng = np.random.default_rng(101)
     contigs = [rng.choice(np.frombuffer(b"ACGTacgtN", dtype=np.uint8), n).tobytes() for n in (400000, 1234, 250000)]
     arena = eng.arena(contigs)
     assert arena.stats()["n_words"] > 8 * 512  # more tiles than the muted one
+    assert eng.query()["chain_timeouts"] == 0
     got = arena.scan_score(20, want_pre=True)
     for k, c in enumerate(contigs):
         assert_hits_equal(got.contig(k), oracle.scan_score(c, 20), ctx=("fallback", k))
     assert b"timed out" in nat.lib().crp_last_error(eng._ctx)
+    assert eng.query() == dict(chain_timeouts=1, two_pass_active=0, comm_world=0, comm_rank=0)
     eng.profile(2)
     eng.profile_read(reset=True)
-    again = arena.scan_score(20, want_pre=True)
+    again = arena.scan_score(20, want_pre=True)  # tries the single launch again, times out again
     prof = eng.profile_read(reset=True)
-    assert prof["count"]["launches"] == 1 and prof["tile_scan"]["launches"] == 1  # three launches now
+    assert prof["count"]["launches"] == 1 and prof["tile_scan"]["launches"] == 1
     assert (bits(again.score_plus) == bits(got.score_plus)).all()
+    assert eng.query()["chain_timeouts"] == 2 and eng.query()["two_pass_active"] == 0
+    arena.scan_score(20)
+    assert eng.query()["chain_timeouts"] == 3 and eng.query()["two_pass_active"] == 1  # latched
+    arena.scan_score(20)
+    assert eng.query()["chain_timeouts"] == 3  # three launches from the start now
+    eng.configure(two_pass=False)
+    assert eng.query()["two_pass_active"] == 0
     arena.close()
     eng.close()

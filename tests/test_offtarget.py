@@ -1,0 +1,368 @@
+"""The opt-in off-target seed scan (BASELINE.json configs[4]; include/cropsr_hip.h crp_offtarget_*).
+
+The reference has NO off-target step, so parity is unpinned by
+construction.  What these tests pin instead:
+  * the INPUT of the definition to the reference's own output: the seed of a hit is a function of
+    its `sequence` column, and the seeds the oracle (and, on the GPU, the HIP kernel) derives equal
+    the seeds of the `sequence` cells in the CSV the real reference wrote (tests/golden);
+  * the oracle's two independent methods to each other (all pairs = the definition; histogram +
+    neighbour enumeration) and to hand-made known answers;
+  * on the GPU (-m gpu): the HIP path (bit-plane windows, histogram, three Hamming-ball passes,
+    look-up) == the oracle, on inputs from a few bases to >= 1 Mb mixed-case / N / IUPAC, several
+    arenas, halo ownership; at BASELINE.json's cfg-5 size: exact c0 and c1 of every one of the 52 M hits
+    against a numpy histogram, and the symmetry / bound properties of the counts.
+All integer: compared bit-exact.
+"""
+import csv
+import gzip
+import io
+import os
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, OracleBackend, golden_fasta_path, read_golden_csv, run_cli
+
+NOT = 0xFFFFFFFF
+
+
+def pairs_threaded(orc, codes, threads=8):
+    """The definition once more, in numpy (XOR + popcount of every guide against all sites), threaded
+    over guides: a third statement next to the oracle's two C ones, and fast enough for 10^5 hits."""
+    codes = np.ascontiguousarray(codes, dtype=np.uint32)
+    n = codes.size
+    out = np.empty((n, 4), dtype=np.uint32)
+    valid = codes != NOT
+    sites = np.ascontiguousarray(codes[valid])
+
+    def chunk(lo, hi):
+        for i in range(lo, hi):
+            if codes[i] == NOT:
+                out[i] = NOT
+                continue
+            x = sites ^ codes[i]
+            d = np.bitwise_count((x | (x >> 1)) & np.uint32(0x555555))
+            c = np.bincount(d[d <= 3], minlength=4)[:4]
+            c[0] -= 1  # the guide itself
+            out[i] = c
+    step = max(1, (n + threads - 1) // threads)
+    with ThreadPoolExecutor(threads) as ex:
+        list(ex.map(lambda lo: chunk(lo, min(n, lo + step)), range(0, n, step)))
+    return out
+
+
+# ------------------------------------------------------------------ CPU: oracle and host logic
+def test_seed_definition_on_the_references_own_sequence_column(oracle, sample_fasta_text):
+    """Seeds from the oracle's restated `sequence` strings == seeds of the `sequence` cells of the CSV
+    the REAL reference wrote for the sample genome (17 314 rows, 12.9 % lower case)."""
+    from cropsr_amd import fasta
+    (name, s), = fasta.contig_table(sample_fasta_text).items()
+    rows = list(csv.reader(io.StringIO(read_golden_csv("sample").decode("ascii"), newline="")))[1:]
+    assert len(rows) == 17314
+    want = np.array([oracle.seed_code_of_sequence(r[2]) for r in rows], dtype=np.uint32)
+    plus, minus = oracle.scan(s, 20)
+    got = np.concatenate([oracle.seed_codes(s, plus, False, 20), oracle.seed_codes(s, minus, True, 20)])
+    assert got.shape == want.shape and (got == want).all()
+    assert (want != NOT).all()  # yeast chr I has no N: every row is a site
+    # and the `sequence` cells themselves are what the oracle restates
+    assert rows[0][2] == oracle.short_sequence(s, int(plus[0]), False, 20)
+    assert rows[-1][2] == oracle.short_sequence(s, int(minus[-1]), True, 20)
+
+
+def test_known_answers(oracle):
+    """A hand-made contig: the same protospacer three times on '+' and once on '-' (the reference prints
+    the same `sequence` for all four), one copy with a mismatch inside the 12-base seed, one with a
+    mismatch outside it.  Expected counts are recomputed here from the `sequence` STRINGS in plain
+    Python (character comparison), independently of every code path under test."""
+    proto = "ACGTTGCAAGCTTGACCTGA"          # 5'->3', the PAM follows: the seed is its last 12 bases
+    site = lambda p: "TTTTT" + p + "AGGTTTTT"
+    mm_seed = proto[:15] + "A" + proto[16:]   # proto[15] = 'C': inside the last 12
+    mm_far = "C" + proto[1:]                  # outside the seed
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    rc = lambda x: "".join(comp[c] for c in reversed(x))
+    minus_site = "TTTTT" + rc(proto + "AGG") + "TTTTTTTT"  # CCT + rc(proto) on the forward strand
+    text = "'" + site(proto) + site(proto) + site(mm_seed) + site(mm_far) + site(proto) + minus_site + "')]"
+    plus, minus = oracle.scan(text, 20)
+    codes = np.concatenate([oracle.seed_codes(text, plus, False, 20), oracle.seed_codes(text, minus, True, 20)])
+    seqs = [oracle.short_sequence(text, int(p), False, 20) for p in plus] + [oracle.short_sequence(text, int(p), True, 20) for p in minus]
+    guide = "".join({"A": "U", "C": "G", "G": "C", "T": "A"}[c] for c in reversed(proto))  # as CROPSR.py:128 prints it
+    same = [k for k, q in enumerate(seqs) if q == guide]
+    assert len(same) == 4 and sum(k >= plus.size for k in same) == 1  # three '+' copies and the '-' one
+
+    def seed_of(q):
+        t = q.replace("U", "T").upper()
+        return t[:12] if len(t) >= 12 and all(c in "ACGT" for c in t[:12]) else None
+    seeds = [seed_of(q) for q in seqs]
+    want = np.full((len(seqs), 4), NOT, dtype=np.uint32)
+    for i, a in enumerate(seeds):
+        if a is None:
+            continue
+        c = [0, 0, 0, 0]
+        for j, b in enumerate(seeds):
+            if j != i and b is not None:
+                d = sum(x != y for x, y in zip(a, b))
+                if d <= 3:
+                    c[d] += 1
+        want[i] = c
+    counts = oracle.offtarget_pairs(codes)
+    assert (counts == want).all()
+    assert (counts == oracle.offtarget_enum(codes, oracle.offtarget_hist([codes]))).all()
+    for k in same:
+        assert counts[k][0] >= 4 and counts[k][1] >= 1  # 3 identical + the far-mismatch copy; the seed-mismatch copy
+
+
+@pytest.mark.parametrize("alphabet,n", [(b"ACGT", 40000), (b"ACGTacgtNGGCC", 60000), (b"GGCC", 3000), (b"ACGTUZuzRY", 30000)])
+def test_oracle_methods_agree(oracle, alphabet, n):
+    rng = np.random.default_rng(len(alphabet) * 1000 + n)
+    c = b"'" + rng.choice(np.frombuffer(alphabet, dtype=np.uint8), n).tobytes() + b"'),"
+    plus, minus = oracle.scan(c, 20)
+    codes = np.concatenate([oracle.seed_codes(c, plus, False, 20), oracle.seed_codes(c, minus, True, 20)])
+    a = oracle.offtarget_pairs(codes)
+    b = oracle.offtarget_enum(codes, oracle.offtarget_hist([codes]))
+    assert (a == b).all()
+    assert (pairs_threaded(oracle, codes) == a).all()  # and a third, numpy, statement of the definition
+    # seeds from the C restatement of `sequence` == seeds from Python string operations
+    for k in range(0, plus.size, 53):
+        assert oracle.seed_code_of_sequence(oracle.short_sequence(c, int(plus[k]), False, 20)) == codes[k]
+    for k in range(0, minus.size, 53):
+        assert oracle.seed_code_of_sequence(oracle.short_sequence(c, int(minus[k]), True, 20)) == codes[plus.size + k]
+
+
+@pytest.mark.parametrize("l", [11, 12, 17, 25])
+def test_guide_lengths(oracle, l):
+    """`sequence` has l characters: no seed below 12, the same 12 PAM-proximal ones above."""
+    rng = np.random.default_rng(l)
+    c = b"'" + rng.choice(np.frombuffer(b"ACGTacgt", dtype=np.uint8), 8000).tobytes() + b"')]"
+    plus, minus = oracle.scan(c, l)
+    sp = oracle.seed_codes(c, plus, False, l)
+    if l < 12:
+        assert (sp == NOT).all()
+    else:
+        p20, _ = oracle.scan(c, 20)
+        s20 = dict(zip(p20.tolist(), oracle.seed_codes(c, p20, False, 20).tolist()))
+        for p, code in zip(plus.tolist(), sp.tolist()):
+            if p in s20:
+                assert s20[p] == code
+
+
+def test_default_csv_is_untouched_and_offtarget_columns_match_the_oracle(oracle, manifest, tmp_path, monkeypatch):
+    """Without --offtarget the CSV is the reference's (bytes); with it, four columns are appended by both
+    writers (Python csv and the native formatter) with the oracle's counts, -1 where there is no seed."""
+    fa = golden_fasta_path("mixed", tmp_path)
+    plain, _ = run_cli(tmp_path, monkeypatch, fa, OracleBackend(oracle), manifest["seed"])
+    assert plain == read_golden_csv("mixed")
+    outs = []
+    for writer in ("native", "python"):
+        d = tmp_path / writer
+        d.mkdir()
+        got, _ = run_cli(d, monkeypatch, fa, OracleBackend(oracle), manifest["seed"], extra=("--offtarget", "--csv-writer", writer))
+        outs.append(got)
+    assert outs[0] == outs[1]
+    ref_rows = list(csv.reader(io.StringIO(plain.decode("latin-1"), newline="")))
+    rows = list(csv.reader(io.StringIO(outs[0].decode("latin-1"), newline="")))
+    assert rows[0] == ref_rows[0] + ["offtarget_seed_mm0", "offtarget_seed_mm1", "offtarget_seed_mm2", "offtarget_seed_mm3"]
+    assert [r[:-4] for r in rows[1:]] == ref_rows[1:]  # everything the reference writes is unchanged
+    # the counts: genome-wide over both contigs of the probe
+    from cropsr_amd import fasta
+    with open(fa, "rb") as f:
+        table = fasta.table_from_bytes(fasta.read_text_bytes(fa))
+    want = oracle.offtarget_genome([bytes(v) for _, v in table], 20)
+    # first pass of the file = contig 1's rows in order
+    n1 = want[0]["ot_plus"].shape[0] + want[0]["ot_minus"].shape[0]
+    exp = np.concatenate([want[0]["ot_plus"], want[0]["ot_minus"]]).astype(np.int64)
+    exp[exp == NOT] = -1
+    got = np.array([[int(x) for x in r[-4:]] for r in rows[1:1 + n1]])
+    assert (got == exp).all()
+    assert (exp == -1).any() and (exp >= 0).any()
+
+
+# ------------------------------------------------------------------------------- GPU
+gpu = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def engine():
+    from cropsr_amd import Engine
+    eng = Engine(0)
+    yield eng
+    eng.close()
+
+
+def gpu_offtarget(engine, contigs, l=20, max_words=None):
+    genome = engine.genome(contigs, max_words=max_words)
+    hits = genome.scan_score(l, offtarget=True)
+    seeds = []
+    for a, h in zip(genome.arenas, hits.per_arena):
+        seeds.append(a.offtarget_seeds(h.n_plus, h.n_minus))
+    out = [hits.contig(k) for k in range(len(contigs))]
+    genome.close()
+    return out, seeds, hits
+
+
+@gpu
+def test_gpu_seeds_equal_reference_sequence_column(engine, oracle, sample_fasta_text):
+    """The HIP seed kernel (12 characters next to the PAM out of the bit-planes) == the seeds of the
+    `sequence` cells the real reference printed for the sample genome."""
+    from cropsr_amd import fasta
+    (name, s), = fasta.contig_table(sample_fasta_text).items()
+    rows = list(csv.reader(io.StringIO(read_golden_csv("sample").decode("ascii"), newline="")))[1:]
+    want = np.array([oracle.seed_code_of_sequence(r[2]) for r in rows], dtype=np.uint32)
+    out, seeds, hits = gpu_offtarget(engine, [s.encode("ascii")])
+    got = np.concatenate(seeds[0])
+    assert got.shape == want.shape and (got == want).all()
+    counts = np.concatenate([out[0]["ot_plus"], out[0]["ot_minus"]])
+    assert (counts == pairs_threaded(oracle, want)).all()
+
+
+@gpu
+@pytest.mark.parametrize("alphabet", [b"ACGT", b"ACGTacgtNGGCC", b"GGCC", b"ACGTUZuzRY')],", b"ACGTacgtN"])
+def test_gpu_counts_vs_oracle_small(engine, oracle, alphabet):
+    rng = np.random.default_rng(len(alphabet))
+    contigs = [b"'" + rng.choice(np.frombuffer(alphabet, dtype=np.uint8), n).tobytes() + tail
+               for n, tail in ((30000, b"'),"), (0, b"'),"), (17, b"'),"), (5000, b"'),"), (64 * 7, b"')]"))]
+    out, seeds, _ = gpu_offtarget(engine, contigs)
+    want = oracle.offtarget_genome(contigs, 20)
+    for k in range(len(contigs)):
+        for key in ("ot_plus", "ot_minus"):
+            assert out[k][key].shape == want[k][key].shape and (out[k][key] == want[k][key]).all(), (k, key)
+    allc = np.concatenate([np.concatenate([w["seed_plus"], w["seed_minus"]]) for w in want])
+    brute = oracle.offtarget_pairs(allc)
+    assert (np.concatenate([np.concatenate([o["ot_plus"], o["ot_minus"]]) for o in out]) == brute).all()
+
+
+@gpu
+def test_gpu_counts_vs_all_pairs_on_a_megabase(engine, oracle):
+    """>= 1 Mb of mixed case / N / IUPAC in three contigs: every hit's four counts against the
+    DEFINITION (all pairs), the histogram against the oracle's."""
+    rng = np.random.default_rng(77)
+    a = np.frombuffer(b"ACGTACGTACGTacgtacgtNNRYGGCC", dtype=np.uint8)
+    contigs = [b"'" + rng.choice(a, n).tobytes() + b"')," for n in (700000, 350000, 90000)]
+    genome = engine.genome(contigs)
+    hits = genome.scan_score(20, offtarget=True)
+    hist = engine.offtarget_hist()
+    want = oracle.offtarget_genome(contigs, 20)
+    codes = np.concatenate([np.concatenate([w["seed_plus"], w["seed_minus"]]) for w in want])
+    assert (hist == oracle.offtarget_hist([codes])).all()
+    got = np.concatenate([np.concatenate([hits.contig(k)["ot_plus"], hits.contig(k)["ot_minus"]]) for k in range(3)])
+    genome.close()
+    assert codes.size > 60000
+    assert (got == pairs_threaded(oracle, codes, threads=16)).all()
+
+
+@gpu
+@pytest.mark.parametrize("l", [11, 12, 19, 21, 50])
+def test_gpu_guide_lengths(engine, oracle, l):
+    rng = np.random.default_rng(l)
+    contigs = [b"'" + rng.choice(np.frombuffer(b"ACGTacgtN", dtype=np.uint8), n).tobytes() + b"')," for n in (20000, 3000)]
+    out, _, _ = gpu_offtarget(engine, contigs, l)
+    want = oracle.offtarget_genome(contigs, l)
+    for k in range(2):
+        for key in ("ot_plus", "ot_minus"):
+            assert (out[k][key] == want[k][key]).all(), (l, k, key)
+
+
+@gpu
+def test_gpu_genome_wide_over_several_arenas_and_ownership(engine, oracle):
+    """Counts are genome-wide: the same contigs spread over three arenas give the same counts as in one;
+    own_ranges keeps halo hits out of the histogram (they come back as 0xFFFFFFFF rows)."""
+    rng = np.random.default_rng(5)
+    a = np.frombuffer(b"ACGTacgtNGGCC", dtype=np.uint8)
+    contigs = [b"'" + rng.choice(a, n).tobytes() + b"')," for n in (60000, 45000, 70000, 300)]
+    one, _, _ = gpu_offtarget(engine, contigs)
+    many, _, _ = gpu_offtarget(engine, contigs, max_words=2200)
+    for k in range(len(contigs)):
+        for key in ("ot_plus", "ot_minus", "pos_plus", "pos_minus"):
+            assert (one[k][key] == many[k][key]).all()
+    # ownership: only the first half of contig 0 counts
+    arena = engine.arena(contigs[:1])
+    n = arena.scan_score_device(20)
+    off = int(arena.offsets[0])
+    engine.offtarget_reset()
+    sites = arena.offtarget_add(20, [(off, off + 30000)])
+    engine.offtarget_solve()
+    cp, cm = arena.offtarget_counts(*n)
+    sp, sm = arena.offtarget_seeds(*n)
+    cols = arena.fetch(*n)
+    arena.close()
+    h = oracle.scan_score(contigs[0], 20)
+    codes_p = oracle.seed_codes(contigs[0], h["pos_plus"], False, 20)
+    codes_m = oracle.seed_codes(contigs[0], h["pos_minus"], True, 20)
+    own_p, own_m = h["pos_plus"] < 30000, h["pos_minus"] < 30000
+    assert sites == int((codes_p[own_p] != NOT).sum() + (codes_m[own_m] != NOT).sum())
+    assert (cols[0] - off == h["pos_plus"]).all()
+    assert (sp[~own_p & (codes_p != NOT)] == 0xFFFFFFFE).all() and (sp[own_p] == codes_p[own_p]).all()
+    owned = np.concatenate([np.where(own_p, codes_p, NOT), np.where(own_m, codes_m, NOT)]).astype(np.uint32)
+    want = oracle.offtarget_enum(owned, oracle.offtarget_hist([owned]))
+    assert (np.concatenate([cp, cm]) == want).all()
+
+
+@gpu
+def test_gpu_call_order_errors(engine):
+    from cropsr_amd import CropsrHipError
+    arena = engine.arena([b"ACGGTCCAGGTTCCAAGG" * 40])
+    n = arena.scan_score_device(20)
+    engine.offtarget_reset()
+    with pytest.raises(CropsrHipError):
+        arena.offtarget_counts(*n)        # not solved yet
+    arena.offtarget_add(20)
+    with pytest.raises(CropsrHipError):
+        arena.offtarget_add(20)           # twice since the reset
+    engine.offtarget_solve()
+    arena.offtarget_counts(*n)
+    engine.offtarget_reset()
+    with pytest.raises(CropsrHipError):
+        arena.offtarget_counts(*n)        # the reset made this arena's seeds stale
+    with pytest.raises(CropsrHipError):
+        arena.offtarget_add(20, [(10, 5)])  # a range that ends before it begins
+    arena.close()
+
+
+@gpu
+def test_gpu_full_size_properties():
+    """BASELINE.json cfg 5 at full size (switchgrass-like, 1.13 Gb, ~52 M kept hits): the oracle cannot
+    run here, so: EXACT c0 and c1 of every hit against a numpy histogram of the device's own seed codes
+    (c0 = hist[seed] - 1; c1 = sum over the 36 one-substitution neighbours), and for all four counts the
+    properties the definition implies -- sum over guides of c_k is even (every unordered pair is counted
+    from both ends), c0 + .. + c3 <= sites - 1, equal seeds have equal counts, non-sites are all-ones."""
+    import bench_workload as bw
+    from cropsr_amd import Engine
+    eng = Engine(0)
+    wl = bw.switchgrass_like()
+    lengths = [s.length + 4 for s in wl.specs]
+    builder = eng.arena_builder(lengths)
+    for k in range(len(wl.specs)):
+        builder.add(wl.contig_string(k))
+    arena = builder.seal()
+    n_plus, n_minus = arena.scan_score_device(20)
+    eng.offtarget_reset()
+    sites = arena.offtarget_add(20)
+    eng.offtarget_solve()
+    cp, cm = arena.offtarget_counts(n_plus, n_minus)
+    sp, sm = arena.offtarget_seeds(n_plus, n_minus)
+    hist_dev = eng.offtarget_hist()
+    arena.close()
+    eng.close()
+    seeds = np.concatenate([sp, sm])
+    counts = np.concatenate([cp, cm])
+    del sp, sm, cp, cm
+    valid = seeds != NOT
+    assert n_plus + n_minus > 50_000_000 and int(valid.sum()) == sites and sites > 40_000_000
+    hist = np.bincount(seeds[valid], minlength=1 << 24).astype(np.uint32)
+    assert (hist == hist_dev).all()
+    assert (counts[~valid] == NOT).all()
+    v = seeds[valid]
+    c = counts[valid].astype(np.int64)
+    del seeds, counts
+    assert (c[:, 0] == hist[v].astype(np.int64) - 1).all()
+    c1 = np.zeros(v.size, dtype=np.int64)
+    for p in range(12):
+        for b in (1, 2, 3):
+            c1 += hist[v ^ np.uint32(b << (2 * p))]
+    assert (c1 == c[:, 1]).all()
+    assert all(int(c[:, k].sum()) % 2 == 0 for k in range(4))
+    assert int(c.sum(axis=1).max()) <= sites - 1
+    order = np.argsort(v, kind="stable")[:2_000_000]
+    vs, cs = v[order], c[order]
+    same = vs[1:] == vs[:-1]
+    assert (cs[1:][same] == cs[:-1][same]).all()
