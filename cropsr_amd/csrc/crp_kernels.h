@@ -13,6 +13,34 @@ constexpr int BLOCK = 256;     // threads per workgroup (4 wavefronts of 64)
 // wait is bounded and a timed-out scan is repeated with the three-launch sequence (crp_api.cpp).
 #define CRP_CHAIN_TICKET 0
 #endif
+#ifndef CRP_DYN_CHUNKS
+// single-launch mode: 1 = the four waves of a workgroup draw chunks of 64 hits from a counter in LDS (the
+// look-back of wave 0 is absorbed by the other three), 0 = every wave owns every fourth chunk
+#define CRP_DYN_CHUNKS 0
+#endif
+#ifndef CRP_LB_FIRST
+// with CRP_DYN_CHUNKS: 1 = wave 0 looks back before it scores anything, 0 = after its first chunk
+#define CRP_LB_FIRST 0
+#endif
+#ifndef CRP_STREAM_MASKS
+// emit pass: 1 = hit masks from the registers the planes were loaded into + wave shuffles (needs two words
+// per thread), 0 = from the LDS copy after a barrier
+#define CRP_STREAM_MASKS (CRP_TILE_WPT == 2)
+#endif
+#ifndef CRP_PRIO_UNTIL_PUBLISH
+// single-launch mode: 1 = raised wave priority until the tile's counts are published, 2 = and, for the wave
+// that resolves the tile's prefix, until it has; 0 = off
+#define CRP_PRIO_UNTIL_PUBLISH 1
+#endif
+#ifndef CRP_PRIO_LEVEL
+#define CRP_PRIO_LEVEL 3
+#endif
+#ifndef CRP_TABLES_AFTER_PUBLISH
+#define CRP_TABLES_AFTER_PUBLISH 1  // stage the scorer's LDS tables after the block scan instead of before it
+#endif
+#ifndef CRP_LIST_FASTPATH
+#define CRP_LIST_FASTPATH 1  // hit-list build without the capacity test when the tile's hits all fit
+#endif
 #ifndef CRP_TILE_WPT
 #define CRP_TILE_WPT 2
 #endif

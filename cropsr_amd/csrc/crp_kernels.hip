@@ -25,6 +25,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "crp_kernels.h"
 #include "crp_score.h"
 #include "crp_score_generic.h"
@@ -219,6 +221,16 @@ __device__ __forceinline__ uint64_t counts_of(uint64_t g_c, uint64_t g_n, uint64
     uint64_t m = c_c & ahead(c_c, c_n, 1) & ~ahead(v_c, v_n, 2) & ~behind(v_p, v_c, 2);
     if (l > 8) m &= ~ahead(v_c, v_n, l - 8);
     return (uint64_t)__popcll(mplus) | ((uint64_t)__popcll(m) << 32);
+}
+
+// the same two masks for one word, from the derived G / C / void masks of the word and its neighbours
+__device__ __forceinline__ void masks_of(uint64_t g_c, uint64_t g_n, uint64_t c_c, uint64_t c_n, uint64_t v_p,
+                                         uint64_t v_c, uint64_t v_n, int l, uint64_t &mplus, uint64_t &mminus)
+{
+    mplus = ahead(g_c, g_n, 1) & ahead(g_c, g_n, 2) & ~behind(v_p, v_c, l + 5);
+    uint64_t m = c_c & ahead(c_c, c_n, 1) & ~ahead(v_c, v_n, 2) & ~behind(v_p, v_c, 2);
+    if (l > 8) m &= ~ahead(v_c, v_n, l - 8);
+    mminus = m;
 }
 
 // LFIX > 0: guide length known at compile time (20, the reference's default), so
@@ -445,6 +457,7 @@ __device__ __forceinline__ uint64_t lookback_resolve(uint64_t *desc, uint32_t ti
     int64_t base = (int64_t)tile - 1;
     uint32_t spins = 0;
     uint64_t t_first_stall = 0;  // 100 MHz real-time counter at the first stalled look of this tile
+    bool stalled_before = false;
     while (true) {
         uint64_t contrib = 0;
         bool found = false, stall = false;
@@ -477,7 +490,10 @@ __device__ __forceinline__ uint64_t lookback_resolve(uint64_t *desc, uint32_t ti
                 bool give_up = false;
                 if ((spins++ & 15u) == 0) {
                     const uint64_t now = __builtin_amdgcn_s_memrealtime();
-                    if (t_first_stall == 0) t_first_stall = now | 1;
+                    if (!stalled_before) {
+                        t_first_stall = now;
+                        stalled_before = true;
+                    }
                     give_up = now - t_first_stall > timeout_ticks;
                     // someone else already timed out: drain
                     give_up |= __hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
@@ -509,6 +525,7 @@ struct ChainArgs {
     uint64_t *totals;   // written by the last tile
     uint64_t *s_excl;   // LDS hand-over from the resolving wave to the workgroup
     uint32_t *s_flag;   // LDS: s_excl is valid
+    uint32_t *s_next;   // LDS: next chunk of 64 list entries to hand out (CRP_DYN_CHUNKS)
     uint32_t tile, n_tiles;
     uint64_t total;     // this tile's (plus | minus << 32)
     bool muted;         // test hook: this tile publishes nothing
@@ -562,6 +579,7 @@ __global__ __launch_bounds__(EMIT_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8
     __shared__ uint64_t wave_tot[EMIT_BLOCK / 64];
     __shared__ uint64_t s_excl;
     __shared__ uint32_t s_flag;
+    __shared__ uint32_t s_next;
 #if CRP_CHAIN_TICKET
     __shared__ uint32_t s_tile;
 #endif
@@ -583,14 +601,74 @@ __global__ __launch_bounds__(EMIT_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8
 #endif
     }
     const uint64_t t0 = (uint64_t)tile * TW;
+#if CRP_PRIO_UNTIL_PUBLISH
+    // single-launch mode: later tiles wait for this tile's counts, so the short phase that produces
+    // them (stage, masks, block scan) runs ahead of the scoring of the other workgroups on this CU
+    if (CHAINED) __builtin_amdgcn_s_setprio(CRP_PRIO_LEVEL);
+#endif
+#if CRP_STREAM_MASKS
+    // Every thread loads the two words it owns of each plane (one 16-byte load per plane) and derives
+    // its hit masks from those REGISTERS, taking the neighbouring words' G / C / void masks from the
+    // adjacent lanes by wave shuffles (lanes 0 and 63 read the word just outside the wave from
+    // memory) -- the count pass's scheme.  The words also go to LDS, but only the window extraction
+    // after the block scan reads them there: no barrier and no LDS round trip stand between the loads
+    // and the tile's counts, which in single-launch mode is what later tiles wait for.
+    static_assert(WPT == 2 && EMIT_BLOCK % 64 == 0, "streamed masks: two words per thread");
+    uint64_t mp[WPT], mm[WPT];
+    {
+        const int lane = tid & 63;
+        const uint64_t wa = t0 + 2 * (uint64_t)tid;          // this thread owns words wa, wa + 1
+        const uint64_t w0 = t0 + 128 * (uint64_t)(tid >> 6);  // first word of this wave
+        ulonglong2 q[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) q[p] = *reinterpret_cast<const ulonglong2 *>(pl.plane[p] + wa);
+        uint64_t e[4] = {ALL, ALL, 0, 0};  // void beyond the arena
+        if (lane == 0 && w0 > 0) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) e[p] = pl.plane[p][w0 - 1];
+        } else if (lane == 63 && w0 + 128 < n_words_padded) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) e[p] = pl.plane[p][w0 + 128];
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            sh[p][1 + 2 * tid] = q[p].x;
+            sh[p][2 + 2 * tid] = q[p].y;
+        }
+        if (tid < 8) {  // the tile's own halo words, for windows that reach across its ends
+            const int p = tid >> 1;
+            const uint64_t voidw = (p < 2) ? ALL : 0ull;
+            if (tid & 1) sh[p][TW + 1] = t0 + TW < n_words_padded ? pl.plane[p][t0 + TW] : voidw;
+            else sh[p][0] = t0 > 0 ? pl.plane[p][t0 - 1] : voidw;
+        }
+        uint64_t ga, ca, va, gb, cb, vb, ge, ce, ve;
+        derive(q[0].x, q[1].x, q[2].x, q[3].x, ga, ca, va);
+        derive(q[0].y, q[1].y, q[2].y, q[3].y, gb, cb, vb);
+        derive(e[0], e[1], e[2], e[3], ge, ce, ve);
+        uint64_t v_left = __shfl_up(vb, 1, 64);
+        uint64_t g_right = __shfl_down(ga, 1, 64), c_right = __shfl_down(ca, 1, 64), v_right = __shfl_down(va, 1, 64);
+        if (lane == 0) v_left = ve;
+        if (lane == 63) { g_right = ge; c_right = ce; v_right = ve; }
+        masks_of(ga, gb, ca, cb, v_left, va, vb, l, mp[0], mm[0]);
+        masks_of(gb, g_right, cb, c_right, va, vb, v_right, l, mp[1], mm[1]);
+    }
+#else
     stage_tile<TW>(pl, t0, n_words_padded, sh);
-    for (int k = tid; k < 256; k += EMIT_BLOCK) exp_tab[k] = CRP_EXP_TAB[k];
-    if (LFIX == 20)
-        for (int k = tid; k < CRP_SCORE_TAB_N; k += EMIT_BLOCK) score_tab[k] = CRP_SCORE_TAB[k];
+#endif
+    auto stage_tables = [&]() {
+        for (int k = tid; k < 256; k += EMIT_BLOCK) exp_tab[k] = CRP_EXP_TAB[k];
+        if (LFIX == 20)
+            for (int k = tid; k < CRP_SCORE_TAB_N; k += EMIT_BLOCK) score_tab[k] = CRP_SCORE_TAB[k];
+    };
+#if !CRP_TABLES_AFTER_PUBLISH
+    stage_tables();
+#endif
+#if !CRP_STREAM_MASKS
     __syncthreads();
 
     uint64_t mp[WPT], mm[WPT];
     thread_masks<WPT, TW>(sh, l, mp, mm);
+#endif
     uint64_t c = 0;
 #pragma unroll
     for (int k = 0; k < WPT; ++k) c += (uint64_t)__popcll(mp[k]) | ((uint64_t)__popcll(mm[k]) << 32);
@@ -601,7 +679,7 @@ __global__ __launch_bounds__(EMIT_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8
     uint64_t off_plus = 0, off_minus = 0;
     ChainArgs ch{};
     if (CHAINED) {
-        ch = ChainArgs{chain + CHAIN_HEADER_WORDS, reinterpret_cast<uint32_t *>(chain) + 1, chain + 1, &s_excl, &s_flag,
+        ch = ChainArgs{chain + CHAIN_HEADER_WORDS, reinterpret_cast<uint32_t *>(chain) + 1, chain + 1, &s_excl, &s_flag, &s_next,
                        tile, gridDim.x, total, tile == mute_tile, timeout_ticks};
         if (tid == 0) {
             // mute_tile (normally none): a tile that never publishes, to exercise the time-out path
@@ -610,6 +688,11 @@ __global__ __launch_bounds__(EMIT_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8
             chain_next[CHAIN_HEADER_WORDS + tile] = 0;
             if (tile == 0) chain_next[0] = chain_next[1] = chain_next[2] = chain_next[3] = 0;
         }
+#if CRP_PRIO_UNTIL_PUBLISH == 1
+        __builtin_amdgcn_s_setprio(0);
+#elif CRP_PRIO_UNTIL_PUBLISH == 2  // the wave that will resolve the tile's prefix keeps its priority until it has
+        if (tid >= 64) __builtin_amdgcn_s_setprio(0);
+#endif
         if (n_all == 0) {
             // nothing to store: the aggregate (0) is all later tiles need; only the last tile
             // must still learn its prefix, to publish the totals
@@ -626,6 +709,10 @@ __global__ __launch_bounds__(EMIT_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8
         off_minus = off.y;
         if (n_all == 0) return;
     }
+#if CRP_TABLES_AFTER_PUBLISH
+    // the scorer's tables are first read after the barrier that follows the hit-list build
+    stage_tables();
+#endif
     emit_rounds<WPT, TW, CAP, LFIX == 20, CHAINED>(sh, list, exp_tab, score_tab, mp, mm, ex, n_plus, n_minus, l, (uint32_t)(t0 * 64),
                                                    off_plus, off_minus, out, ch);
 }
@@ -644,7 +731,10 @@ __device__ __forceinline__ void emit_rounds(uint64_t (*sh)[TW + 2], uint16_t *li
     for (uint32_t lo_rank = 0; lo_rank < n_all; lo_rank += CAP) {
         if (lo_rank) __syncthreads();  // previous round's readers are done
         // ---- compact: rank -> tile-local position, '+' hits first, then '-'
-        {
+        // A tile whose hits all fit the list (the normal case; uniform over the workgroup) writes
+        // without the per-entry capacity test.
+        auto compact = [&](auto check) {
+            constexpr bool CHECK = decltype(check)::value;
             uint32_t rp = (uint32_t)ex - lo_rank;                    // rank of next '+' hit, window-relative
             uint32_t rm = n_plus + (uint32_t)(ex >> 32) - lo_rank;  // same for '-'
 #pragma unroll
@@ -658,7 +748,7 @@ __device__ __forceinline__ void emit_rounds(uint64_t (*sh)[TW + 2], uint16_t *li
                     while (m) {
                         const uint32_t b = __builtin_ctz(m);
                         m &= m - 1;
-                        if (rp < (uint32_t)CAP) list[rp] = (uint16_t)(wbase + 32 * half + b);
+                        if (!CHECK || rp < (uint32_t)CAP) list[rp] = (uint16_t)(wbase + 32 * half + b);
                         ++rp;
                     }
                 }
@@ -668,12 +758,19 @@ __device__ __forceinline__ void emit_rounds(uint64_t (*sh)[TW + 2], uint16_t *li
                     while (m) {
                         const uint32_t b = __builtin_ctz(m);
                         m &= m - 1;
-                        if (rm < (uint32_t)CAP) list[rm] = (uint16_t)(wbase + 32 * half + b);
+                        if (!CHECK || rm < (uint32_t)CAP) list[rm] = (uint16_t)(wbase + 32 * half + b);
                         ++rm;
                     }
                 }
             }
-        }
+        };
+#if CRP_LIST_FASTPATH
+        if (n_all <= (uint32_t)CAP) compact(std::false_type{});
+        else compact(std::true_type{});
+#else
+        compact(std::true_type{});
+#endif
+        if (CHAINED && tid == 0) *ch.s_next = 0;  // chunk counter of this round (read after the barrier below)
         __syncthreads();
         // ---- one hit per lane: extract the 30-window, score, store
         const uint32_t n_round = min((uint32_t)CAP, n_all - lo_rank);
@@ -755,6 +852,54 @@ __device__ __forceinline__ void emit_rounds(uint64_t (*sh)[TW + 2], uint16_t *li
                 off_minus = e >> 32;
                 resolved = true;
             };
+#if CRP_DYN_CHUNKS
+            // The waves draw chunks of 64 list entries from a counter in LDS instead of owning every
+            // fourth one: whatever time wave 0 spends in the look-back (round trip + waiting for
+            // predecessors), the other three take over its share of the hits, so the look-back
+            // lengthens no wave's critical path; the tail of the list is balanced the same way.
+            const int lane = tid & 63;
+            auto grab = [&]() -> uint32_t {
+                uint32_t c = 0;
+                if (lane == 0) c = atomicAdd(ch.s_next, 1u);
+                return (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+            };
+            auto look_back = [&]() {
+                uint64_t lb[LB_DEPTH];
+                lookback_load(ch.desc, (int64_t)ch.tile - 1, lb);
+                chain_resolve(ch, lb);
+                __hip_atomic_store(ch.s_flag, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            };
+            const bool scanner = lo_rank == 0 && tid < 64;  // wave-uniform: once per tile
+#if CRP_LB_FIRST
+            if (scanner) look_back();
+#endif
+            uint32_t c = grab();
+            bool have_cur = false, first = true;
+            Hit cur{};
+            while (c * 64u < n_round) {
+                const uint32_t k = c * 64u + (uint32_t)lane;
+                Hit nxt{0xffffffffu, 0, -1.0, -1.0};
+                if (k < n_round) nxt = compute(k);
+                c = grab();  // (the atomic's round trip hides under the stores below)
+#if !CRP_LB_FIRST
+                if (scanner && first) look_back();
+#endif
+                first = false;
+                if (have_cur) {
+                    settle();
+                    if (cur.e != 0xffffffffu) store(cur);
+                }
+                cur = nxt;
+                have_cur = true;
+            }
+#if !CRP_LB_FIRST
+            if (scanner && first) look_back();  // wave 0 drew no chunk at all
+#endif
+            if (have_cur) {
+                settle();
+                if (cur.e != 0xffffffffu) store(cur);
+            }
+#else
             uint32_t k = tid;
             const bool any = k < n_round;
             Hit cur{};
@@ -764,6 +909,9 @@ __device__ __forceinline__ void emit_rounds(uint64_t (*sh)[TW + 2], uint16_t *li
                 lookback_load(ch.desc, (int64_t)ch.tile - 1, lb);
                 chain_resolve(ch, lb);
                 __hip_atomic_store(ch.s_flag, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+#if CRP_PRIO_UNTIL_PUBLISH == 2
+                __builtin_amdgcn_s_setprio(0);
+#endif
             }
             if (any) {
                 for (k += EMIT_BLOCK; k < n_round; k += EMIT_BLOCK) {
@@ -775,6 +923,7 @@ __device__ __forceinline__ void emit_rounds(uint64_t (*sh)[TW + 2], uint16_t *li
                 settle();
                 store(cur);
             }
+#endif
         }
     }
 }

@@ -88,11 +88,44 @@ def scan_score(s, l=20, chunk=1000000):
     scores = np.full(len(rows), -1.0)
     for lo in range(0, len(rows), chunk):
         part = rows[lo:lo + chunk]
+        # like the reference (CROPSR.py:458-459): a row whose long string is not 30 characters becomes an
+        # np.empty(30,) of float64 -- and ONE such row makes np.array() below promote the whole batch to
+        # float64, which multiplies the size of the np.repeat temporaries by eight.  That is what the
+        # reference pays on almost every real contig (a '-' hit near the end of the string suffices),
+        # so the timed port must pay it too (profiles/cpu_calibration.json).
         seqs = [np.frombuffer(bytes(r[3].replace("U", "T").upper(), "ascii"), "uint8") if len(r[3]) == 30
-                else np.zeros(30, dtype="uint8") for r in part]
+                else np.empty(30,) for r in part]
         if not seqs:
             continue
         sc = dense_score(np.array(seqs))
         ok = np.array([len(r[3]) == 30 for r in part])
         scores[lo:lo + len(part)][ok] = sc[ok]
     return rows, scores
+
+
+def full_run(s, out_csv, l=20, chunk=1000000):
+    """The reference's whole per-contig pass for ONE contig string -- hot path PLUS what surrounds it
+    (CROPSR.py:442-474: the 7-element row lists, the id draws, the 12-tuples, csv.writer) -- used only
+    by tools/calibrate_cpu_baseline.py, so that the port can be timed against the real reference's own
+    whole-run timer like for like.  Returns the number of rows written."""
+    import csv
+    rows = [[r[0], r[1], "chr", r[2], r[3], "cas9", r[4]] for r in scan(s, l)]
+    size = len(rows)
+    alphanum = np.array(list("ABCDEFGHIJKLMNOPQRSTUVWXYZ0123456789"), dtype="|U1")
+    written = 0
+    with open(out_csv, "a") as f:
+        w = csv.writer(f)
+        ids = np.random.choice(alphanum, [size, 7])
+        ids = ["".join(z) for z in ids.tolist()]
+        for lo in range(0, size, chunk):
+            part = rows[lo:lo + chunk]
+            seqs = [np.frombuffer(bytes(r[4].replace("U", "T").upper(), "ascii"), "uint8") if len(r[4]) == 30
+                    else np.empty(30,) for r in part]
+            score = dense_score(np.array(seqs))
+            out = [(ids[lo - i - 1], r[5], r[3], r[4], r[2], r[0], r[1], r[1] - 3, r[6], score[i], "", "completed")
+                   if len(r[4]) == 30 else
+                   (ids[lo - i - 1], r[5], r[3], r[4], r[2], r[0], r[1], r[6], -1, "", "completed")
+                   for i, r in enumerate(part)]
+            w.writerows(out)
+            written += len(out)
+    return written

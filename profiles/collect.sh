@@ -1,6 +1,6 @@
 #!/bin/bash
 # Collect the rocprofv3 evidence bench.py's roofline numbers are judged against.
-# Run on the GPU box from the repo root:   bash profiles/collect.sh r01
+# Run on the GPU box from the repo root:   bash profiles/collect.sh r02
 # Writes raw rocprof output under gpurun_out/prof_<tag>/ (scratch) and the
 # summaries under gpurun_out/profiles_<tag>/ -- copy those into profiles/.
 #   1. --kernel-trace --stats      : per-kernel average durations of the bench command
@@ -8,14 +8,14 @@
 #   3. --pmc WRITE_SIZE            : HBM write traffic  (separate pass)
 #   4. --pmc SQ_* (two passes)     : where the emit kernel's wave time goes
 set -e
-TAG=${1:-r01}
+TAG=${1:-r02}
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 RAW=gpurun_out/prof_$TAG
 OUT=gpurun_out/profiles_$TAG
 rm -rf "$RAW" "$OUT"
 mkdir -p "$RAW" "$OUT"
-BENCH="python3 bench.py --steps 10 --warmup 2 --cpu-sample-bases 0"
+BENCH="python3 bench.py --steps 10 --warmup 2 --cpu-sample-bases 0 --offtarget-steps 3"
 
 rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/trace -- $BENCH > $OUT/bench_under_trace.json 2> $RAW/trace.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $RAW/fetch -- $BENCH > /dev/null 2> $RAW/fetch.err
@@ -27,5 +27,5 @@ rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VALU_FMA_F64 S
 python3 bench.py --steps 20 --warmup 3 > $OUT/bench_unprofiled.json 2> $RAW/bench.err
 
 cp $RAW/trace/*/*_kernel_stats.csv $OUT/kernel_stats.csv
-python3 profiles/summarize.py $RAW $OUT
+python3 profiles/summarize.py $RAW $OUT $TAG
 ls -la $OUT

@@ -34,6 +34,7 @@ def load(raw, tag):
 
 def main():
     raw, out = sys.argv[1], sys.argv[2]
+    tag = sys.argv[3] if len(sys.argv) > 3 else "r02"
     rows = []
     merged = collections.defaultdict(dict)
     for tag in ("fetch", "write", "sq1", "sq2"):
@@ -61,6 +62,13 @@ def main():
              "read_bytes_corrected": fetch_kib * 1024 * 2, "write_bytes": write_kib * 1024,
              "hbm_bytes_per_launch": fetch_kib * 1024 * 2 + write_kib * 1024,
              "algorithmic_bytes_per_launch": bench.get("roofline", {}).get("algorithmic_bytes_per_launch"),
+             # ties the numbers to the library they were measured on: bench.py refuses another build
+             "build_id": bench.get("config", {}).get("library_build"),
+             "source": "profiles/%s (rocprofv3 --pmc passes of profiles/collect.sh)" % tag,
+             # the second ceiling: VALU instructions issued per launch and the kernel's length in shader
+             # cycles (GRBM_GUI_ACTIVE is summed over the 8 XCDs)
+             "valu_insts_per_launch": merged[k].get("SQ_INSTS_VALU", (None, 0))[0],
+             "kernel_cycles_per_launch": (merged[k].get("GRBM_GUI_ACTIVE", (0, 0))[0] / 8.0) or None,
              "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 64 B per 128-B request)"}
         with open(os.path.join(out, "traffic.json"), "w") as f:
             json.dump(t, f, indent=1)

@@ -13,6 +13,7 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: whole-genome checks that take minutes (still part of -m gpu)")
     # a fresh checkout has no binaries: build them once (hipcc cross-compiles without a GPU)
     so = os.path.join(ROOT, "cropsr_amd", "libcropsr_hip.so")
     orc = os.path.join(ROOT, "oracle", "liborc.so")

@@ -1,0 +1,128 @@
+"""--annotate: the opt-in GFF / Phytozome join.  No reference oracle exists (the
+reference drops the parsed GFF, CROPSR.py:375, and writes '' into `features`, :466-468): the product's
+sweep + binary search is checked against the brute-force restatement in oracle/annotate_oracle.py, and
+the default CSV is asserted untouched.  CPU only (the join is host code)."""
+import csv
+import gzip
+import io
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, OracleBackend, golden_fasta_path, read_golden_csv, run_cli
+
+
+@pytest.fixture()
+def sample_gff(tmp_path):
+    p = tmp_path / "sample_genome.gff"
+    with gzip.open(os.path.join(GOLDEN, "sample_genome.gff.gz"), "rb") as f:
+        p.write_bytes(f.read())
+    return str(p)
+
+
+def _run(tmp_path, monkeypatch, oracle, manifest, fasta, gff, extra):
+    import io as _io
+    from cropsr_amd import cli
+    monkeypatch.chdir(tmp_path)
+    out_csv = str(tmp_path / "out.csv")
+    args = cli.build_parser().parse_args(["-f", fasta, "-g", gff, "-o", out_csv, "--cas9", "--seed", str(manifest["seed"])] + list(extra))
+    cli.run(args, backend=OracleBackend(oracle), out=_io.StringIO())
+    with open(out_csv, "rb") as f:
+        return f.read()
+
+
+def test_contig_names():
+    from cropsr_amd import annotate
+    assert annotate.contig_name("[('Chr01',") == "Chr01"
+    assert annotate.contig_name("('c2',") == "c2"
+    assert annotate.contig_name(">chrX") == "chrX"
+
+
+@pytest.mark.parametrize("writer", ["native", "python"])
+def test_sample_genome_features_equal_brute_force(writer, oracle, manifest, tmp_path, monkeypatch, sample_gff):
+    """The reference's own sample pair (yeast chr I + its GFF, 100 genes / 97 CDS): every one of the 17 314
+    rows gets the labels the brute-force join gives it; every other byte of the CSV is the reference's."""
+    from oracle import annotate_oracle
+    fa = golden_fasta_path("sample", tmp_path)
+    got = _run(tmp_path, monkeypatch, oracle, manifest, fa, sample_gff, ("--annotate", "--csv-writer", writer))
+    ref = read_golden_csv("sample")
+    a = list(csv.reader(io.StringIO(got.decode("latin-1"), newline="")))
+    b = list(csv.reader(io.StringIO(ref.decode("latin-1"), newline="")))
+    assert len(a) == len(b) and a[0] == b[0]
+    want = annotate_oracle.features_of_rows(b[1:], lambda chrom: chrom.strip("(',"), 1, sample_gff)
+    n_annotated = 0
+    for ra, rb, w in zip(a[1:], b[1:], want):
+        assert ra[:10] == rb[:10] and ra[11:] == rb[11:]
+        assert ra[10] == w
+        n_annotated += bool(w)
+    assert 8000 < n_annotated < 17314  # ~70 % of yeast chr I is genic
+    assert any(";" in w for w in want) and any(w.startswith("gene:gene-YAL068C;CDS:cds-NP_009332.1") for w in want)
+    # without the flag: the reference's bytes
+    d = tmp_path / "plain"
+    d.mkdir()
+    assert _run(d, monkeypatch, oracle, manifest, fa, sample_gff, ()) == ref
+
+
+def test_overlapping_features_phytozome_names_and_odd_gff(oracle, manifest, tmp_path, monkeypatch):
+    """Nested and overlapping genes, CDS without ID, a seqid that is not in the FASTA, a contig without
+    features, unformatted FASTA (dec = 0), Phytozome names (-p), and labels that need csv quoting."""
+    from oracle import annotate_oracle
+    from cropsr_amd import annotate
+    rng = np.random.default_rng(12)
+    seqs = {"c1": rng.choice(list("ACGT"), 3000), "c2": rng.choice(list("ACGTacgtN"), 1200), "c3": rng.choice(list("ACGT"), 500)}
+    fa = tmp_path / "g.fa"
+    with open(fa, "w") as f:
+        for k, v in seqs.items():
+            body = "".join(v)
+            f.write(">%s\n" % k + "\n".join(body[i:i + 60] for i in range(0, len(body), 60)) + "\n")
+    gff = tmp_path / "g.gff"
+    lines = ["##gff-version 3",
+             "c1\tphytozome\tgene\t100\t900\t.\t+\t.\tID=G1.v1;Name=G1",
+             "c1\tphytozome\tmRNA\t100\t900\t.\t+\t.\tID=G1.1;Parent=G1.v1",
+             "c1\tphytozome\tCDS\t150\t400\t.\t+\t0\tID=G1.1.CDS.1;Parent=G1.1",
+             "c1\tphytozome\tCDS\t600\t880\t.\t+\t0\tParent=G1.1",
+             "c1\tphytozome\tgene\t850\t1500\t.\t-\t.\tID=G2.v1;Name=G2",
+             "c1\tphytozome\tgene\t300\t350\t.\t-\t.\tName=nested,with \"quote\"",
+             "c1\tphytozome\tCDS\t2990\t3000\t.\t-\t0\tID=edge",
+             "c2\tphytozome\tgene\t1\t1200\t.\t+\t.\tID=whole",
+             "nowhere\tphytozome\tgene\t1\t100\t.\t+\t.\tID=ghost",
+             "c1\tphytozome\tgene\tx\t10\t.\t+\t.\tID=badcoords"]
+    gff.write_text("\n".join(lines) + "\n")
+    info = tmp_path / "annotation_info.txt"
+    info.write_text("#pacId\tlocusName\ttranscriptName\tpeptideName\tPfam\tPanther\tKOG\tKEGG/ec\tKO\tGO\tBest-hit-arabi-name\tarabi-symbol\tarabi-defline\n"
+                    "1\tG1\tG1.1\tG1.1.p\t\t\t\t\t\t\tAT1G01010.1\tNAC001\tNAC domain containing protein 1\n"
+                    "2\tG2\tG2.1\tG2.1.p\t\t\t\t\t\t\t\t\t\n")
+    got = _run(tmp_path, monkeypatch, oracle, manifest, str(fa), str(gff), ("--annotate", "-p", str(info), "--each-contig-once"))
+    plain_dir = tmp_path / "plain"
+    plain_dir.mkdir()
+    plain = _run(plain_dir, monkeypatch, oracle, manifest, str(fa), str(gff), ("--each-contig-once",))
+    a = list(csv.reader(io.StringIO(got.decode("latin-1"), newline="")))
+    b = list(csv.reader(io.StringIO(plain.decode("latin-1"), newline="")))
+    pinfo = annotate.parse_annotation_info(str(info))
+    assert pinfo == {"G1": ("AT1G01010.1", "NAC domain containing protein 1"), "G2": ("", "")}
+    want = annotate_oracle.features_of_rows(b[1:], lambda chrom: chrom.strip("(',"), 1, str(gff), pinfo)
+    assert len(a) == len(b)
+    for ra, rb, w in zip(a[1:], b[1:], want):
+        assert [x for i, x in enumerate(ra) if i != 10 or len(ra) != 12] == [x for i, x in enumerate(rb) if i != 10 or len(rb) != 12]
+        if len(ra) == 12:
+            assert ra[10] == w
+    labels = set(w for w in want if w)
+    assert "gene:G1.v1|AT1G01010.1|NAC domain containing protein 1;CDS:G1.1.CDS.1" in labels
+    assert any("gene:nested,with \"quote\"" in w for w in labels)      # needs quoting in the CSV: round-trips
+    assert any(w.startswith("gene:G1.v1|") and "gene:G2.v1" in w for w in labels)  # overlap 850..900
+    assert "CDS:G1.1" in " ".join(labels)                                  # CDS without ID: its Parent
+    assert all("ghost" not in w and "badcoords" not in w for w in labels)
+    c3_rows = [ra for ra in a[1:] if "c3" in ra[4]]
+    assert c3_rows and all(r[10] == "" for r in c3_rows if len(r) == 12)
+    # two-line FASTA without a final newline is scanned unformatted: coordinates are 0-based there (dec = 0)
+    fa2 = tmp_path / "two.fa"
+    fa2.write_text(">c1\n" + "".join(seqs["c1"]))
+    d2 = tmp_path / "two"
+    d2.mkdir()
+    got2 = _run(d2, monkeypatch, oracle, manifest, str(fa2), str(gff), ("--annotate",))
+    rows2 = list(csv.reader(io.StringIO(got2.decode("latin-1"), newline="")))[1:]
+    want2 = annotate_oracle.features_of_rows([[c if i != 10 else "" for i, c in enumerate(r)] for r in rows2],
+                                             lambda chrom: chrom, 0, str(gff))
+    assert [r[10] for r in rows2 if len(r) == 12] == [w for r, w in zip(rows2, want2) if len(r) == 12]
+    assert any(w for w in want2)

@@ -37,8 +37,8 @@ def main():
     ap.add_argument("--reference-behaviour", action="store_true", help="re-emit earlier contigs like the reference")
     ap.add_argument("--profile", action="store_true")
     ap.add_argument("--procs", type=int, default=1,
-                    help="run the CLI as that many torch.distributed processes (all on device 0, exchange on gloo: a "
-                         "rehearsal of the multi-GPU mode on a one-GPU box)")
+                    help="run the CLI as that many processes under torch.distributed.run (the launcher only; all on "
+                         "device 0, tables over the host transport: a rehearsal of the multi-GPU mode on a one-GPU box)")
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
     import bench_workload as bw
@@ -59,7 +59,7 @@ def main():
         argv.append("--each-contig-once")
     if a.procs > 1:
         import subprocess
-        env = dict(os.environ, CROPSR_DIST_BACKEND="gloo", PYTHONPATH=ROOT)
+        env = dict(os.environ, CROPSR_GATHER="host", PYTHONPATH=ROOT)  # all ranks on device 0: RCCL cannot run
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.procs),
                "--master-addr", "127.0.0.1", "--master-port", "29551", "-m", "cropsr_amd"] + argv + ["--device", "0"]
         t0 = time.time()
@@ -72,7 +72,6 @@ def main():
         os.remove(out_csv)
         os.remove(fa)
         return
-    import torch  # noqa: F401  (the bundled HIP runtime must come up before the engine's)
     from cropsr_amd import cli
     args = cli.build_parser().parse_args(argv)
     os.chdir(tmp)
