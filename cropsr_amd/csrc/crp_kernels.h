@@ -22,6 +22,12 @@ constexpr int BLOCK = 256;     // threads per workgroup (4 wavefronts of 64)
 // with CRP_DYN_CHUNKS: 1 = wave 0 looks back before it scores anything, 0 = after its first chunk
 #define CRP_LB_FIRST 0
 #endif
+#ifndef CRP_LB_EARLY
+#define CRP_LB_EARLY 0  // single-launch mode: request the look-back's descriptors before the first hits are scored
+#endif
+#ifndef CRP_EXPERIMENT_NO_LB
+#define CRP_EXPERIMENT_NO_LB 0  // timing-only ablations of the look-back (results are wrong when set)
+#endif
 #ifndef CRP_STREAM_MASKS
 // emit pass: 1 = hit masks from the registers the planes were loaded into + wave shuffles (needs two words
 // per thread), 0 = from the LDS copy after a barrier

@@ -453,6 +453,9 @@ __device__ __forceinline__ uint64_t lookback_resolve(uint64_t *desc, uint32_t ti
 {
     const int lane = threadIdx.x & 63;
     if (tile == 0) return 0;
+#if CRP_EXPERIMENT_NO_LB == 1  // TIMING ONLY (wrong tables): what the look-back costs altogether
+    return 0;
+#endif
     uint64_t excl = 0;
     int64_t base = (int64_t)tile - 1;
     uint32_t spins = 0;
@@ -480,6 +483,9 @@ __device__ __forceinline__ uint64_t lookback_resolve(uint64_t *desc, uint32_t ti
                 }
             }
         }
+#if CRP_EXPERIMENT_NO_LB == 2  // TIMING ONLY (wrong tables): the look-back's loads and analysis, but no waiting
+        if (stall) break;
+#endif
         if (stall) {
             // Wait on that ONE descriptor (a single 8-byte load per look instead of the whole
             // window and its analysis), then read the window again.
@@ -903,10 +909,18 @@ __device__ __forceinline__ void emit_rounds(uint64_t (*sh)[TW + 2], uint16_t *li
             uint32_t k = tid;
             const bool any = k < n_round;
             Hit cur{};
+#if CRP_LB_EARLY
+            // the descriptors are requested BEFORE the wave scores its first hits and looked at after:
+            // their round trip hides under that work (a snapshot that turns out too old costs a second one)
+            uint64_t lb[LB_DEPTH];
+            if (lo_rank == 0 && tid < 64) lookback_load(ch.desc, (int64_t)ch.tile - 1, lb);
+#endif
             if (any) cur = compute(k);
             if (lo_rank == 0 && tid < 64) {  // wave-uniform: once per tile
+#if !CRP_LB_EARLY
                 uint64_t lb[LB_DEPTH];
                 lookback_load(ch.desc, (int64_t)ch.tile - 1, lb);
+#endif
                 chain_resolve(ch, lb);
                 __hip_atomic_store(ch.s_flag, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 #if CRP_PRIO_UNTIL_PUBLISH == 2

@@ -103,6 +103,12 @@ def scan_score(s, l=20, chunk=1000000):
     return rows, scores
 
 
+def _cutsite(start_pos, end_pos, crispr_sys):
+    """CROPSR.py:155-158 (a function call per row there too)."""
+    if crispr_sys == "cas9":
+        return end_pos - 3
+
+
 def full_run(s, out_csv, l=20, chunk=1000000):
     """The reference's whole per-contig pass for ONE contig string -- hot path PLUS what surrounds it
     (CROPSR.py:442-474: the 7-element row lists, the id draws, the 12-tuples, csv.writer) -- used only
@@ -116,13 +122,16 @@ def full_run(s, out_csv, l=20, chunk=1000000):
     with open(out_csv, "a") as f:
         w = csv.writer(f)
         ids = np.random.choice(alphanum, [size, 7])
-        ids = ["".join(z) for z in ids.tolist()]
+        # the reference's own conversion of every id row to a str (CROPSR.py:449): characters -> code points
+        # -> bytes -> str, one Python-level pass per row
+        import array
+        ids = [array.array("B", map(ord, z)).tobytes().decode("utf-8") for z in ids.tolist()]
         for lo in range(0, size, chunk):
             part = rows[lo:lo + chunk]
             seqs = [np.frombuffer(bytes(r[4].replace("U", "T").upper(), "ascii"), "uint8") if len(r[4]) == 30
                     else np.empty(30,) for r in part]
             score = dense_score(np.array(seqs))
-            out = [(ids[lo - i - 1], r[5], r[3], r[4], r[2], r[0], r[1], r[1] - 3, r[6], score[i], "", "completed")
+            out = [(ids[lo - i - 1], r[5], r[3], r[4], r[2], r[0], r[1], _cutsite(r[0], r[1], r[5]), r[6], score[i], "", "completed")
                    if len(r[4]) == 30 else
                    (ids[lo - i - 1], r[5], r[3], r[4], r[2], r[0], r[1], r[6], -1, "", "completed")
                    for i, r in enumerate(part)]

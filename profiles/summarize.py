@@ -34,7 +34,7 @@ def load(raw, tag):
 
 def main():
     raw, out = sys.argv[1], sys.argv[2]
-    tag = sys.argv[3] if len(sys.argv) > 3 else "r02"
+    round_tag = sys.argv[3] if len(sys.argv) > 3 else "r02"
     rows = []
     merged = collections.defaultdict(dict)
     for tag in ("fetch", "write", "sq1", "sq2"):
@@ -64,7 +64,7 @@ def main():
              "algorithmic_bytes_per_launch": bench.get("roofline", {}).get("algorithmic_bytes_per_launch"),
              # ties the numbers to the library they were measured on: bench.py refuses another build
              "build_id": bench.get("config", {}).get("library_build"),
-             "source": "profiles/%s (rocprofv3 --pmc passes of profiles/collect.sh)" % tag,
+             "source": "profiles/%s (rocprofv3 --pmc passes of profiles/collect.sh)" % round_tag,
              # the second ceiling: VALU instructions issued per launch and the kernel's length in shader
              # cycles (GRBM_GUI_ACTIVE is summed over the 8 XCDs)
              "valu_insts_per_launch": merged[k].get("SQ_INSTS_VALU", (None, 0))[0],
