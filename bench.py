@@ -380,4 +380,13 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except Exception as e:  # a rank that fails alone must not leave its peers in a collective
+        import traceback
+        traceback.print_exc()
+        from cropsr_amd import rendezvous
+        g = getattr(rendezvous, "LAST_GROUP", None)
+        if g is not None and g.world > 1:
+            g.abort("%s: %s" % (type(e).__name__, e))
+        sys.exit(1)

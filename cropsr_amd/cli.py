@@ -246,8 +246,13 @@ def _distributed():
     """The rendezvous.Group of a multi-process launch (python -m torch.distributed.run ... -m cropsr_amd
     or any launcher that exports RANK / WORLD_SIZE / LOCAL_RANK / MASTER_PORT), else None.  One process
     per GPU; no PyTorch: the control plane is rendezvous.py, the data plane RCCL inside the library."""
+    global _ACTIVE_GROUP
     from . import rendezvous
-    return rendezvous.Group.from_env()
+    _ACTIVE_GROUP = rendezvous.Group.from_env()
+    return _ACTIVE_GROUP
+
+
+_ACTIVE_GROUP = None  # the group main() aborts when this rank fails outside an agreed error (Group.check)
 
 
 def check_guide_length(l):
@@ -444,7 +449,19 @@ def run(args, backend=None, out=sys.stdout, group=None):
 
 def main(argv=None):
     args = build_parser().parse_args(argv)
-    run(args)
+    try:
+        run(args)
+    except Exception as e:
+        from . import rendezvous
+        if isinstance(e, rendezvous.RankError):  # agreed on by every rank: all exit the same way
+            sys.exit("cropsr_amd: " + str(e))
+        if _ACTIVE_GROUP is not None and _ACTIVE_GROUP.world > 1:
+            # this rank alone failed (a HIP or RCCL error in the middle of the exchange, ...): its peers may sit in
+            # a collective that will never complete -- take the whole run down with the reason
+            import traceback
+            traceback.print_exc()
+            _ACTIVE_GROUP.abort("%s: %s" % (type(e).__name__, e))
+        raise
 
 
 if __name__ == "__main__":

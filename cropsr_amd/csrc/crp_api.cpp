@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "crp_internal.h"
+#include "crp_roctx.h"
 
 namespace {
 
@@ -252,6 +253,7 @@ static int arena_reserve(crp_arena *a, uint64_t len, uint64_t *first_word)
 
 int crp_arena_add_contig_ascii(crp_arena *a, const uint8_t *text, uint64_t len, uint64_t *arena_offset)
 {
+    crp::Range roctx_range("crp: H2D + pack");
     if (!a || (len && !text)) return CRP_ERR_INVALID;
     crp_ctx *ctx = a->ctx;
     uint64_t w_first = 0;
@@ -292,6 +294,7 @@ int crp_arena_add_contig_ascii(crp_arena *a, const uint8_t *text, uint64_t len, 
 int crp_arena_add_contig_packed(crp_arena *a, const uint64_t *hi, const uint64_t *lo, const uint64_t *up,
                                 const uint64_t *ac, uint64_t len, uint64_t *arena_offset)
 {
+    crp::Range roctx_range("crp: H2D planes");
     if (!a) return CRP_ERR_INVALID;
     if (len && (!hi || !lo || !up || !ac)) return CRP_ERR_INVALID;
     crp_ctx *ctx = a->ctx;
@@ -465,6 +468,7 @@ static int scan_single_pass(crp_arena *a, const crp::Planes &pl, uint64_t eff_wo
 
 int crp_scan_score(crp_arena *a, int guide_len, int want_pre, uint64_t *n_plus, uint64_t *n_minus)
 {
+    crp::Range roctx_range("crp: scan + score");
     if (!a) return CRP_ERR_INVALID;
     if (!a->sealed) return CRP_ERR_STATE;
     if (guide_len < 1 || guide_len > 50) return CRP_ERR_UNSUPPORTED;
@@ -507,6 +511,7 @@ int crp_scan_score(crp_arena *a, int guide_len, int want_pre, uint64_t *n_plus, 
 int crp_fetch_hits(crp_arena *a, uint32_t *pos_plus, double *pre_plus, double *score_plus, uint32_t *pos_minus,
                    double *pre_minus, double *score_minus)
 {
+    crp::Range roctx_range("crp: D2H tables");
     if (!a) return CRP_ERR_INVALID;
     if (!a->have_hits) return CRP_ERR_STATE;
     if ((pre_plus || pre_minus) && !a->have_pre) return CRP_ERR_STATE;
@@ -540,6 +545,7 @@ int crp_hits_device(crp_arena *a, void **pos_plus, void **score_plus, void **pos
 // ------------------------------------------------------------------- seam 2
 int crp_score_30mers(crp_ctx *ctx, const uint8_t *rows, uint64_t n, int order, double *pre, double *score)
 {
+    crp::Range roctx_range("crp: score 30-mers");
     if (!ctx || (n && (!rows || !score))) return CRP_ERR_INVALID;
     if (order < CRP_ORDER_BODY4 || order > CRP_ORDER_DOT1) return CRP_ERR_INVALID;
     if (n == 0) return CRP_OK;

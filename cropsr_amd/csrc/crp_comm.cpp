@@ -22,6 +22,7 @@
 #include <rccl/rccl.h>
 
 #include "crp_internal.h"
+#include "crp_roctx.h"
 
 namespace {
 
@@ -228,6 +229,7 @@ int crp_comm_barrier(crp_ctx *ctx)
 
 int crp_gather_hits(crp_ctx *ctx, crp_arena *a, int root, int flags, uint64_t *counts_all)
 {
+    crp::Range roctx_range("crp: gatherv (RCCL)");
     if (!ctx) return CRP_ERR_INVALID;
     crp_comm *c = ctx->comm;
     if (!c) return CRP_ERR_STATE;

@@ -16,6 +16,7 @@
 // private buffers and commit them with write(2) in row order, so nothing the size of the
 // whole CSV is ever held in memory).
 #include "cropsr_hip.h"
+#include "crp_roctx.h"
 
 #include <algorithm>
 #include <atomic>
@@ -329,6 +330,7 @@ extern "C" int crp_write_rows_ex(int fd, const uint8_t *contig_text, uint64_t co
                                  const uint64_t *feat_off, const uint32_t *feat_idx, const uint32_t *offtarget,
                                  uint64_t *bytes_written, int n_threads)
 {
+    crp::Range roctx_range("crp: format + write rows");
     if (fd < 0 || bad_args(contig_text, chrom, chrom_len, guide_len, pos, minus, score, ids, n_rows))
         return CRP_ERR_INVALID;
     if (feat_idx && (!feat_off || !feat_blob)) return CRP_ERR_INVALID;

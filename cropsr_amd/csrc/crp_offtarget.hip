@@ -32,6 +32,7 @@
 #include <algorithm>
 
 #include "crp_internal.h"
+#include "crp_roctx.h"
 
 namespace crp {
 
@@ -220,6 +221,7 @@ int crp_offtarget_reset(crp_ctx *ctx)
 
 int crp_offtarget_add(crp_arena *a, int guide_len, const uint64_t *own_ranges, uint64_t n_ranges, uint64_t *n_sites)
 {
+    crp::Range roctx_range("crp: off-target seeds + histogram");
     if (!a || (n_ranges && !own_ranges) || n_ranges > 0x7fffffffu) return CRP_ERR_INVALID;
     if (guide_len < 1 || guide_len > 50) return CRP_ERR_UNSUPPORTED;
     crp_ctx *ctx = a->ctx;
@@ -273,6 +275,7 @@ int crp_offtarget_add(crp_arena *a, int guide_len, const uint64_t *own_ranges, u
 
 int crp_offtarget_reduce(crp_ctx *ctx)
 {
+    crp::Range roctx_range("crp: off-target all-reduce (RCCL)");
     if (!ctx) return CRP_ERR_INVALID;
     if (!ctx->d_ot_hist || ctx->ot_solved) return CRP_ERR_STATE;
     CRP_HIP(ctx, hipSetDevice(ctx->device));
@@ -307,6 +310,7 @@ int crp_offtarget_hist_set(crp_ctx *ctx, const uint32_t *hist)
 
 int crp_offtarget_solve(crp_ctx *ctx)
 {
+    crp::Range roctx_range("crp: off-target ball sums");
     if (!ctx) return CRP_ERR_INVALID;
     if (!ctx->d_ot_hist) return CRP_ERR_STATE;
     if (ctx->ot_solved) return CRP_OK;
@@ -326,6 +330,7 @@ int crp_offtarget_solve(crp_ctx *ctx)
 
 int crp_offtarget_counts(crp_arena *a, uint32_t *counts_plus, uint32_t *counts_minus)
 {
+    crp::Range roctx_range("crp: off-target look-up");
     if (!a) return CRP_ERR_INVALID;
     crp_ctx *ctx = a->ctx;
     if (!ctx->ot_solved || !a->have_hits || a->ot_epoch != ctx->ot_epoch) return CRP_ERR_STATE;

@@ -20,13 +20,23 @@ crp_offtarget_reduce).  This module is the small CONTROL plane around it:
 
 Star topology through rank 0; every operation is a collective that all ranks
 call in the same order.  Messages: 8-byte length + pickle (arrays: raw bytes).
+
+A second connection per rank is the ABORT channel, watched by a daemon thread: a
+rank that dies (its sockets close) or calls Group.abort(msg) makes every other
+rank print the reason and exit with status 3 -- also out of a blocking RCCL
+call, which has no time-out of its own.  A collective that cannot complete ends
+in a non-zero exit, never in a hang.  Group.close() is itself a barrier, so a
+rank that merely finishes first does not look like one that died.
 """
 import json
 import os
 import pickle
+import select
 import socket
 import struct
+import sys
 import tempfile
+import threading
 import time
 
 import numpy as np
@@ -56,6 +66,9 @@ def _recv_msg(sock):
     return _recv_exact(sock, n)
 
 
+LAST_GROUP = None  # the most recent multi-rank Group of this process (for top-level abort handlers)
+
+
 class RankError(RuntimeError):
     """Raised on EVERY rank by Group.check when any rank reported an error."""
 
@@ -67,6 +80,9 @@ class Group:
         self.rank, self.world, self.local_rank = int(rank), int(world), int(local_rank)
         self._peers = {}     # hub: rank -> socket
         self._hub = None     # others: socket to rank 0
+        self._abort_peers = {}  # hub: rank -> abort-channel socket
+        self._abort_hub = None  # others: abort-channel socket to rank 0
+        self._closing = False
         self._listener = None
         self._file = None
         if self.world == 1:
@@ -88,17 +104,20 @@ class Group:
                     json.dump({"host": host, "port": port, "world": self.world, "pid": os.getpid()}, f)
                 os.replace(tmp, rdzv_file)  # atomic: a reader never sees half a file
                 self._file = rdzv_file
-            while len(self._peers) < self.world - 1:
+            while len(self._peers) < self.world - 1 or len(self._abort_peers) < self.world - 1:
                 conn, _ = self._listener.accept()
                 conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
                 conn.settimeout(_TIMEOUT_S)
                 hello = pickle.loads(_recv_msg(conn))
-                if hello.get("world") != self.world or hello.get("rank") in self._peers or not 0 < hello.get("rank", 0) < self.world:
+                table = self._abort_peers if hello.get("abort") else self._peers
+                if hello.get("world") != self.world or hello.get("rank") in table or not 0 < hello.get("rank", 0) < self.world:
                     conn.close()  # a stray client of another run
                     continue
-                self._peers[hello["rank"]] = conn
+                table[hello["rank"]] = conn
             for r in sorted(self._peers):
                 _send_msg(self._peers[r], pickle.dumps("welcome"))
+            for sock in self._abort_peers.values():
+                sock.settimeout(None)
         else:
             deadline = time.time() + _TIMEOUT_S
             while True:
@@ -115,14 +134,73 @@ class Group:
                     s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
                     s.settimeout(_TIMEOUT_S)
                     _send_msg(s, pickle.dumps({"rank": self.rank, "world": self.world}))
+                    a = socket.create_connection((host, int(port)), timeout=5)
+                    a.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                    a.settimeout(_TIMEOUT_S)
+                    _send_msg(a, pickle.dumps({"rank": self.rank, "world": self.world, "abort": True}))
                     if pickle.loads(_recv_msg(s)) != "welcome":
                         raise OSError("unexpected greeting")
-                    self._hub = s
+                    a.settimeout(None)
+                    self._hub, self._abort_hub = s, a
                     break
                 except (OSError, ValueError, ConnectionError):
                     if time.time() > deadline:
                         raise TimeoutError("rank %d: no rendezvous with rank 0 within %.0f s" % (self.rank, _TIMEOUT_S))
                     time.sleep(0.05)
+        threading.Thread(target=self._watch, name="cropsr-abort-watch", daemon=True).start()
+        global LAST_GROUP
+        LAST_GROUP = self
+
+    # ------------------------------------------------------------- abort channel
+    def _die(self, why):
+        sys.stderr.write("[cropsr_amd rank %d] aborting: %s\n" % (self.rank, why))
+        sys.stderr.flush()
+        os._exit(3)
+
+    def _watch(self):
+        """Daemon thread: leave the process as soon as any rank has died or asked for an abort."""
+        try:
+            if self.rank == 0:
+                socks = dict((s, r) for r, s in self._abort_peers.items())
+                while socks and not self._closing:
+                    ready, _, _ = select.select(list(socks), [], [], 0.5)
+                    for s in ready:
+                        try:
+                            msg = _recv_msg(s)
+                            why = "rank %d: %s" % (socks[s], pickle.loads(msg))
+                        except Exception:
+                            why = "rank %d died (its connection closed)" % socks[s]
+                        if self._closing:
+                            return
+                        for o in socks:
+                            if o is not s:
+                                try:
+                                    _send_msg(o, pickle.dumps(why))
+                                except OSError:
+                                    pass
+                        self._die(why)
+            else:
+                try:
+                    why = pickle.loads(_recv_msg(self._abort_hub))
+                except Exception:
+                    why = "rank 0 died (its connection closed)"
+                if not self._closing:
+                    self._die(why)
+        except Exception:  # the sockets went away under a closing group
+            return
+
+    def abort(self, why):
+        """Make every rank exit (status 3) with this reason; does not return."""
+        why = str(why)
+        try:
+            if self.rank == 0:
+                for s in self._abort_peers.values():
+                    _send_msg(s, pickle.dumps("rank 0: " + why))
+            elif self._abort_hub is not None:
+                _send_msg(self._abort_hub, pickle.dumps(why))
+        except OSError:
+            pass
+        self._die(why)
 
     # ------------------------------------------------------------------ set-up
     @classmethod
@@ -144,13 +222,21 @@ class Group:
         return cls(rank, world, local, endpoint, path)
 
     def close(self):
-        for s in list(self._peers.values()) + [self._hub, self._listener]:
+        """Collective: returns once every rank is closing (a rank that finishes first must not look dead)."""
+        if self.world > 1 and not self._closing and (self._hub is not None or self._peers):
+            self._closing = True
+            try:
+                self.barrier()
+            except Exception:
+                pass
+        self._closing = True
+        for s in list(self._peers.values()) + list(self._abort_peers.values()) + [self._hub, self._abort_hub, self._listener]:
             if s is not None:
                 try:
                     s.close()
                 except OSError:
                     pass
-        self._peers, self._hub, self._listener = {}, None, None
+        self._peers, self._abort_peers, self._hub, self._abort_hub, self._listener = {}, {}, None, None, None
         if self._file:
             try:
                 os.unlink(self._file)

@@ -258,3 +258,43 @@ def test_cli_multi_process_offtarget_equals_single_process(tmp_path, monkeypatch
     with open(tmp_path / "rank0" / "out.csv", "rb") as f:
         assert f.read() == want
     assert b"offtarget_seed_mm3\r\n" in want.split(b"\r\n", 1)[0] + b"\r\n"
+
+
+def _dying_worker(rank, world, port, out_dir):
+    group = _group(rank, world, port)
+    if rank == 1:
+        os._exit(7)  # dies without a word, its peers sitting in a collective
+    try:
+        group.all_gather("waiting for rank 1 forever")
+        msg = "returned"
+    except Exception as e:
+        msg = "raised %s" % type(e).__name__
+    with open(os.path.join(out_dir, "rank%d.txt" % rank), "w") as f:
+        f.write(msg)
+
+
+def _aborting_worker(rank, world, port, out_dir):
+    group = _group(rank, world, port)
+    if rank == 2:
+        group.abort("out of memory on this GPU")
+    import time
+    time.sleep(30)  # stands for a blocking RCCL call: only the watchdog thread can end it
+    with open(os.path.join(out_dir, "rank%d.txt" % rank), "w") as f:
+        f.write("survived")
+
+
+def test_a_dead_or_aborting_rank_takes_every_rank_down_quickly(tmp_path):
+    """No hang: when a rank dies, or calls Group.abort, every other rank exits non-zero within seconds --
+    also out of a call that never returns (a blocked collective)."""
+    import time
+    t0 = time.time()
+    codes = _spawn(_dying_worker, 3, str(tmp_path))
+    assert codes[1] == 7, codes
+    for r in (0, 2):  # either the watchdog ended the process (3) or the collective raised; never a normal return
+        f = tmp_path / ("rank%d.txt" % r)
+        assert codes[r] == 3 or (codes[r] == 0 and f.read_text().startswith("raised")), (r, codes)
+    t1 = time.time()
+    codes = _spawn(_aborting_worker, 3, str(tmp_path))
+    assert codes == [3, 3, 3], codes
+    assert time.time() - t0 < 25 and time.time() - t1 < 15
+    assert not any(f.startswith("rank") and open(tmp_path / f).read() == "survived" for f in os.listdir(tmp_path))
