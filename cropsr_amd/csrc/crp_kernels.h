@@ -22,6 +22,9 @@ constexpr int BLOCK = 256;     // threads per workgroup (4 wavefronts of 64)
 // with CRP_DYN_CHUNKS: 1 = wave 0 looks back before it scores anything, 0 = after its first chunk
 #define CRP_LB_FIRST 0
 #endif
+#ifndef CRP_PIPE_UNROLL
+#define CRP_PIPE_UNROLL 0  // single-launch mode: the store-one-behind loop unrolled by two (no copies of the parked hit)
+#endif
 #ifndef CRP_LB_EARLY
 #define CRP_LB_EARLY 0  // single-launch mode: request the look-back's descriptors before the first hits are scored
 #endif

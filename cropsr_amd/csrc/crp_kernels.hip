@@ -928,6 +928,21 @@ __device__ __forceinline__ void emit_rounds(uint64_t (*sh)[TW + 2], uint16_t *li
 #endif
             }
             if (any) {
+#if CRP_PIPE_UNROLL
+                // two iterations per trip with the roles of the two parked hits swapped: no register copies
+                Hit alt{};
+                while (true) {
+                    k += EMIT_BLOCK;
+                    if (k >= n_round) { settle(); store(cur); break; }
+                    alt = compute(k);
+                    settle();
+                    store(cur);
+                    k += EMIT_BLOCK;
+                    if (k >= n_round) { store(alt); break; }
+                    cur = compute(k);
+                    store(alt);
+                }
+#else
                 for (k += EMIT_BLOCK; k < n_round; k += EMIT_BLOCK) {
                     const Hit nxt = compute(k);
                     settle();
@@ -936,6 +951,7 @@ __device__ __forceinline__ void emit_rounds(uint64_t (*sh)[TW + 2], uint16_t *li
                 }
                 settle();
                 store(cur);
+#endif
             }
 #endif
         }

@@ -6,6 +6,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <random>
 #include <string>
@@ -56,6 +57,51 @@ int main(int argc, char **argv)
         const size_t got = used ? std::fread(back.data(), 1, used, f) : 0;
         std::fclose(f);
         if (got != used || !std::equal(back.begin(), back.end(), out.begin())) { std::printf("bytes differ\n"); ++failures; }
+        // the opt-in columns (crp_write_rows_ex): a string table for `features` (entries that need quoting
+        // included) with one index per row, and four off-target counts per row (0xFFFFFFFF prints as -1)
+        const std::vector<std::string> table = {"gene:G1", "gene:G1;CDS:c,1", "x\"y", ""};
+        std::string blob;
+        std::vector<uint64_t> off(1, 0);
+        for (const auto &t : table) { blob += t; off.push_back(blob.size()); }
+        std::vector<uint32_t> fidx(n), ot(4 * n);
+        for (uint64_t r = 0; r < n; ++r) {
+            fidx[r] = rng() % 3 == 0 ? 0xffffffffu : (uint32_t)(rng() % table.size());
+            for (int k = 0; k < 4; ++k) ot[4 * r + k] = rng() % 5 == 0 ? 0xffffffffu : (uint32_t)(rng() % 100000);
+        }
+        f = std::fopen(path, "wb");
+        uint64_t written_ex = 0;
+        st = crp_write_rows_ex(fileno(f), text.data(), len, (const uint8_t *)chrom.data(), chrom.size(), l, pos.data(),
+                               minus.data(), score.data(), ids.data(), n, (const uint8_t *)blob.data(), off.data(), fidx.data(),
+                               ot.data(), &written_ex, 5);
+        std::fclose(f);
+        if (st != CRP_OK || written_ex < used + 8 * n) { std::printf("write_rows_ex status %d\n", st); ++failures; continue; }
+        std::vector<char> ex(written_ex + 1, 0);
+        f = std::fopen(path, "rb");
+        const size_t got_ex = written_ex ? std::fread(ex.data(), 1, written_ex, f) : 0;
+        std::fclose(f);
+        // every row ends in its four counts
+        const char *p = ex.data(), *end = ex.data() + got_ex;
+        for (uint64_t r = 0; r < n && failures == 0; ++r) {
+            const char *eol = p;
+            // rows may contain quoted \r\n inside fields: the row's own end is the \r\n after its last count
+            char want[64];
+            const int m = std::snprintf(want, sizeof want, ",%lld,%lld,%lld,%lld\r\n",
+                                        ot[4 * r] == 0xffffffffu ? -1ll : (long long)ot[4 * r],
+                                        ot[4 * r + 1] == 0xffffffffu ? -1ll : (long long)ot[4 * r + 1],
+                                        ot[4 * r + 2] == 0xffffffffu ? -1ll : (long long)ot[4 * r + 2],
+                                        ot[4 * r + 3] == 0xffffffffu ? -1ll : (long long)ot[4 * r + 3]);
+            eol = std::search(p, end, want, want + m);
+            if (eol == end) { std::printf("row %llu: counts not found\n", (unsigned long long)r); ++failures; break; }
+            p = eol + m;
+        }
+        if (failures == 0 && p != end) { std::printf("trailing bytes after the last row\n"); ++failures; }
+        // and without the extras the _ex entry point is crp_write_rows
+        f = std::fopen(path, "wb");
+        uint64_t written_plain = 0;
+        st = crp_write_rows_ex(fileno(f), text.data(), len, (const uint8_t *)chrom.data(), chrom.size(), l, pos.data(),
+                               minus.data(), score.data(), ids.data(), n, nullptr, nullptr, nullptr, nullptr, &written_plain, 3);
+        std::fclose(f);
+        if (st != CRP_OK || written_plain != used) { std::printf("write_rows_ex (plain) status %d\n", st); ++failures; }
     }
     {  // crp_legacy_ids: forward and last-first draws from the same MT19937 state agree row for row
         std::vector<uint32_t> key(624), key2;
