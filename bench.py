@@ -152,7 +152,9 @@ def main():
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     local_rank = 0 if args.share_gpu0 else (group.local_rank if group else 0)
-    use_rccl = world > 1 and not args.share_gpu0
+    # (CROPSR_BENCH_FORCE_RCCL=1 with --share-gpu0 asks RCCL for a communicator of ranks that share a GPU, which it
+    # refuses: a way to see the failure path -- every rank exits non-zero with the same message -- on a one-GPU box)
+    use_rccl = world > 1 and (not args.share_gpu0 or os.environ.get("CROPSR_BENCH_FORCE_RCCL") == "1")
 
     eng = Engine(local_rank)  # raises without libcropsr_hip.so / GPU: no fallback
     if args.two_pass:
@@ -283,9 +285,10 @@ def main():
             per = {k: pot[k]["ms"] / max(1, pot[k]["launches"]) for k in ("ot_seed", "ot_ball", "ot_lookup", "ot_reduce")}
             hits = n_plus + n_minus
             # algorithmic bytes of one step on this rank: seeds 4 B pos in + 4 B seed out
-            # per hit + the 12 characters next to the PAM out of 4 planes (counted as 4 x 8 B words) + one 4-byte
-            # atomic per site; ball passes 64 MiB in, 3 x 256 MiB out, 2 x 256 MiB back in; look-up 4 + 16 + 16 B per hit
-            seed_bytes = hits * (4 + 4 + 32) + sites * 4
+            # per hit + the 12 characters next to the PAM out of 4 planes (counted as 4 x 8 B words); partition 4 B seed
+            # in + 2 B out per site, bucket histograms 2 B in per site + 64 MiB in and out; ball passes 64 MiB in,
+            # 3 x 256 MiB out, 2 x 256 MiB back in; look-up 4 + 16 + 16 B per hit
+            seed_bytes = hits * (4 + 4 + 32) + hits * 4 + sites * 4 + 2 * (1 << 26)
             ball_bytes = (1 << 24) * (4 + 16 * 5)
             look_bytes = hits * (4 + 16 + 16)
             ot = {"metric": "guides off-target-scanned/sec", "value": hits_all * args.offtarget_steps / dt_ot,

@@ -61,6 +61,7 @@ const char *crp_strerror(int status)
         case CRP_ERR_CAPACITY: return "arena capacity exceeded";
         case CRP_ERR_UNSUPPORTED: return "unsupported parameter";
         case CRP_ERR_IO: return "write to the output descriptor failed";
+        case CRP_ERR_COMM: return "RCCL error";
         default: return "unknown status";
     }
 }
@@ -119,6 +120,8 @@ int crp_destroy(crp_ctx *ctx)
     if (ctx->h_scalar) (void)hipHostFree(ctx->h_scalar);
     (void)hipFree(ctx->d_ot_hist);
     (void)hipFree(ctx->d_ot_ball);
+    (void)hipFree(ctx->d_ot_part);
+    (void)hipFree(ctx->d_ot_bucket);
     crp::comm_release(ctx);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;

@@ -255,7 +255,8 @@ int crp_gathered_fetch(crp_ctx *ctx, int rank, uint32_t *pos_plus, double *score
  *   count  for a site g and k = 0..3: the number of OTHER sites whose seed differs from g's in
  *          exactly k of the 12 positions
  * Genome-wide means: over every arena added between crp_offtarget_reset and crp_offtarget_solve, on
- * every rank of the communicator (crp_offtarget_reduce).  Method: a histogram of the 4^12 seeds, then
+ * every rank of the communicator (crp_offtarget_reduce).  Method: a histogram of the 4^12 seeds (built
+ * by partitioning the sites by seed prefix, no atomic per site), then
  * the exact Hamming-ball sums of that histogram for all seeds at once by a position-wise recurrence
  * (three passes of four positions through LDS), then one 16-byte look-up per hit -- no pairwise
  * comparison anywhere. */
