@@ -381,6 +381,12 @@ def run(args, backend=None, out=sys.stdout, group=None):
         all_hits = parallel.sharded_scan(backend, strings, args.l, group, max_piece=max_piece, offtarget=offtarget)
         if hasattr(backend, "finalize_gathered"):
             all_hits = backend.finalize_gathered(all_hits)
+    world = 1 if group is None else group.world
+    if own_group and group is not None:
+        # the exchange is over: the other ranks leave now (Group.close is a barrier) instead of waiting, watched by
+        # each other's abort channels, for however long this rank formats and writes the CSV
+        group.close()
+        group = None
     stages["upload_scan_fetch_s"] = time.perf_counter() - t_stage
 
     annot = None
@@ -432,15 +438,13 @@ def run(args, backend=None, out=sys.stdout, group=None):
         ids.close()
     if own_backend:
         backend.close()
-    if own_group and group is not None:
-        group.close()
     if verbose:
         print(f"The output file has been generated at {args.o}", file=out)
     if getattr(args, "bench_json", None):
         import json
         kept = int(sum(h["pos_plus"].size + h["pos_minus"].size for h in all_hits))
         stages.update(total_s=time.time() - begin, contigs=len(strings), characters=int(sum(len(v) for v in strings)),
-                      kept_hits=kept, rows_written=int(n_rows_written), world=1 if group is None else group.world,
+                      kept_hits=kept, rows_written=int(n_rows_written), world=world,
                       gRNAs_per_s_end_to_end=kept / max(1e-9, time.time() - begin))
         with open(args.bench_json, "w") as f:
             json.dump(stages, f)

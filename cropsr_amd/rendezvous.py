@@ -41,7 +41,7 @@ import time
 
 import numpy as np
 
-_TIMEOUT_S = float(os.environ.get("CROPSR_RDZV_TIMEOUT", "300"))
+_TIMEOUT_S = float(os.environ.get("CROPSR_RDZV_TIMEOUT", "1800"))  # a live rank may be slow; a dead one is caught by the abort channel
 
 
 def _send_msg(sock, payload):
