@@ -41,6 +41,7 @@ import time
 
 import numpy as np
 
+_CONNECT_TIMEOUT_S = float(os.environ.get("CROPSR_RDZV_CONNECT_TIMEOUT", "300"))  # finding the other ranks
 _TIMEOUT_S = float(os.environ.get("CROPSR_RDZV_TIMEOUT", "1800"))  # a live rank may be slow; a dead one is caught by the abort channel
 
 
@@ -96,7 +97,7 @@ class Group:
             else:
                 self._listener.bind(("127.0.0.1", 0))
             self._listener.listen(self.world)
-            self._listener.settimeout(_TIMEOUT_S)
+            self._listener.settimeout(_CONNECT_TIMEOUT_S)
             if not endpoint:
                 host, port = self._listener.getsockname()
                 tmp = rdzv_file + ".%d.tmp" % os.getpid()
@@ -119,7 +120,7 @@ class Group:
             for sock in self._abort_peers.values():
                 sock.settimeout(None)
         else:
-            deadline = time.time() + _TIMEOUT_S
+            deadline = time.time() + _CONNECT_TIMEOUT_S
             while True:
                 try:
                     if endpoint:
@@ -145,7 +146,7 @@ class Group:
                     break
                 except (OSError, ValueError, ConnectionError):
                     if time.time() > deadline:
-                        raise TimeoutError("rank %d: no rendezvous with rank 0 within %.0f s" % (self.rank, _TIMEOUT_S))
+                        raise TimeoutError("rank %d: no rendezvous with rank 0 within %.0f s" % (self.rank, _CONNECT_TIMEOUT_S))
                     time.sleep(0.05)
         threading.Thread(target=self._watch, name="cropsr-abort-watch", daemon=True).start()
         global LAST_GROUP
