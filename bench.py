@@ -355,6 +355,9 @@ def main():
                                "gRNAs_per_s": scored / (t_upload + dt / args.steps + t_fetch)},
         }
         if ot is not None:
+            if facts and "roofline" in ot:
+                ot["roofline"]["traffic"] = facts.get("offtarget_ball_hbm_bytes_per_step")
+                ot["roofline"]["traffic_source"] = facts_src
             line["offtarget"] = ot
         if gather_info is not None:
             line["gatherv_ok"] = "s" in gather_info
