@@ -22,6 +22,12 @@ constexpr int BLOCK = 256;     // threads per workgroup (4 wavefronts of 64)
 // with CRP_DYN_CHUNKS: 1 = wave 0 looks back before it scores anything, 0 = after its first chunk
 #define CRP_LB_FIRST 0
 #endif
+#ifndef CRP_LB_FIRST_STATIC
+#define CRP_LB_FIRST_STATIC 0  // single-launch mode: wave 0 resolves the prefix before it scores its first hits
+#endif
+#ifndef CRP_LB_NOINLINE
+#define CRP_LB_NOINLINE 0  // single-launch mode: the look-back as a real function call (keeps its registers out of the scorer's loop)
+#endif
 #ifndef CRP_PIPE_UNROLL
 #define CRP_PIPE_UNROLL 0  // single-launch mode: the store-one-behind loop unrolled by two (no copies of the parked hit)
 #endif

@@ -447,7 +447,11 @@ __device__ __forceinline__ void lookback_load(const uint64_t *desc, int64_t base
 // base = tile - 1 (the loads were issued before the wave scored its first hits, so they
 // cost no wait here).  Returns the exclusive prefix in every lane and publishes the
 // inclusive one.
+#if CRP_LB_NOINLINE
+__device__ __attribute__((noinline)) uint64_t lookback_resolve(uint64_t *desc, uint32_t tile, uint64_t total,
+#else
 __device__ __forceinline__ uint64_t lookback_resolve(uint64_t *desc, uint32_t tile, uint64_t total,
+#endif
                                                      uint64_t (&v)[LB_DEPTH], uint32_t *fail, bool muted,
                                                      uint32_t timeout_ticks)
 {
@@ -909,6 +913,18 @@ __device__ __forceinline__ void emit_rounds(uint64_t (*sh)[TW + 2], uint16_t *li
             uint32_t k = tid;
             const bool any = k < n_round;
             Hit cur{};
+#if CRP_LB_FIRST_STATIC
+            // the whole look-back BEFORE the wave scores anything (nothing of the scorer is live then)
+            if (lo_rank == 0 && tid < 64) {
+                uint64_t lb0[LB_DEPTH];
+                lookback_load(ch.desc, (int64_t)ch.tile - 1, lb0);
+                chain_resolve(ch, lb0);
+                __hip_atomic_store(ch.s_flag, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+#if CRP_PRIO_UNTIL_PUBLISH == 2
+                __builtin_amdgcn_s_setprio(0);
+#endif
+            }
+#endif
 #if CRP_LB_EARLY
             // the descriptors are requested BEFORE the wave scores its first hits and looked at after:
             // their round trip hides under that work (a snapshot that turns out too old costs a second one)
@@ -916,7 +932,7 @@ __device__ __forceinline__ void emit_rounds(uint64_t (*sh)[TW + 2], uint16_t *li
             if (lo_rank == 0 && tid < 64) lookback_load(ch.desc, (int64_t)ch.tile - 1, lb);
 #endif
             if (any) cur = compute(k);
-            if (lo_rank == 0 && tid < 64) {  // wave-uniform: once per tile
+            if (!CRP_LB_FIRST_STATIC && lo_rank == 0 && tid < 64) {  // wave-uniform: once per tile
 #if !CRP_LB_EARLY
                 uint64_t lb[LB_DEPTH];
                 lookback_load(ch.desc, (int64_t)ch.tile - 1, lb);

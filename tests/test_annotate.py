@@ -126,3 +126,46 @@ def test_overlapping_features_phytozome_names_and_odd_gff(oracle, manifest, tmp_
                                              lambda chrom: chrom, 0, str(gff))
     assert [r[10] for r in rows2 if len(r) == 12] == [w for r, w in zip(rows2, want2) if len(r) == 12]
     assert any(w for w in want2)
+
+
+def test_random_interval_sets_against_brute_force():
+    """Seeded fuzz of the sweep + binary search: random gene / CDS intervals (nested, abutting, duplicated, single-base,
+    out of range), random hit positions on both strands, guide lengths 17..25, dec 0 and 1 -- against a direct loop."""
+    from cropsr_amd import annotate
+    import tempfile
+    rng = np.random.default_rng(99)
+    for trial in range(40):
+        n = int(rng.integers(200, 5000))
+        feats = []
+        for k in range(int(rng.integers(0, 40))):
+            a = int(rng.integers(1, n + 50))
+            b = a + int(rng.choice([0, 1, 5, 50, 500, n]))
+            t = "gene" if rng.random() < 0.5 else "CDS"
+            feats.append(("c", t, a, b, "ID=f%d" % (k if rng.random() < 0.8 else 0)))
+        with tempfile.NamedTemporaryFile("w", suffix=".gff", delete=False) as f:
+            f.write("##gff-version 3\n")
+            for sid, t, a, b, attrs in feats:
+                f.write("%s\tsrc\t%s\t%d\t%d\t.\t+\t.\t%s\n" % (sid, t, a, b, attrs))
+            f.write("other\tsrc\tgene\t1\t100000\t.\t+\t.\tID=elsewhere\n")
+            path = f.name
+        try:
+            ann = annotate.Annotation(path)
+            l = int(rng.integers(17, 26))
+            dec = int(rng.integers(0, 2))
+            ip = np.sort(rng.choice(np.arange(l + 5, n), size=min(60, n - l - 5), replace=False)).astype(np.uint32)
+            jm = np.sort(rng.choice(np.arange(2, n), size=min(60, n - 2), replace=False)).astype(np.uint32)
+            strings, idx = ann.for_contig("('c'," if dec else ">c", dict(pos_plus=ip, pos_minus=jm), l, dec, n)
+            cuts = [int(i) - 3 for i in ip] + [int(j) for j in jm]
+            full = [min(int(i) + 5, n) - (int(i) - l - 5) == 30 for i in ip] + [min(int(j) + 3 + l + 5, n) - (int(j) - 2) == 30 for j in jm]
+            for k, (cut, ok) in enumerate(zip(cuts, full)):
+                want = []
+                if ok:
+                    x = cut - dec + 1
+                    for sid, t, a, b, attrs in feats:
+                        lab = "%s:%s" % (t, attrs[3:])
+                        if a <= x <= b and lab not in want:
+                            want.append(lab)
+                got = "" if idx[k] == annotate.NO_FEATURE else strings[int(idx[k])]
+                assert got == ";".join(want), (trial, k, cut, got, want)
+        finally:
+            os.unlink(path)
