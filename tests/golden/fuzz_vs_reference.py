@@ -5,7 +5,7 @@ reference (child process, `libm` environment of make_golden.py) and through crop
 the CPU oracle as hit provider; CSV bytes and stdout must be identical.  Failing inputs are kept
 under --keep for promotion to golden probes.
 
-usage: python tests/golden/fuzz_vs_reference.py [-n 200] [--seed 1] [--keep DIR]
+usage: python tests/golden/fuzz_vs_reference.py [-n 200] [--seed 1] [--keep DIR] [--finalize-host]
 """
 import argparse
 import io
@@ -50,7 +50,7 @@ def random_fasta(rnd):
     return text
 
 
-def ours(fa_text, extra, scratch):
+def ours(fa_text, extra, scratch, finalize="gpu"):
     from conftest import OracleBackend
     from cropsr_amd import cli
     from oracle import oracle as orc
@@ -61,12 +61,13 @@ def ours(fa_text, extra, scratch):
         f.write(fa_text)
     with open(gff, "w") as f:
         f.write(mg.MINI_GFF)
-    args = cli.build_parser().parse_args(["-f", fa, "-g", gff, "-o", out, "--cas9", "--seed", str(mg.SEED)] + list(extra))
+    args = cli.build_parser().parse_args(["-f", fa, "-g", gff, "-o", out, "--cas9", "--seed", str(mg.SEED)] + list(extra)
+                                         + (["--score-finalize", "host"] if finalize == "host" else []))
     cwd = os.getcwd()
     os.chdir(d)
     buf = io.StringIO()
     try:
-        cli.run(args, backend=OracleBackend(orc), out=buf)
+        cli.run(args, backend=OracleBackend(orc, finalize=finalize), out=buf)
         with open(out, "rb") as f:
             res = f.read(), buf.getvalue()
     except BaseException as e:  # the reference's failure modes count too
@@ -81,7 +82,11 @@ def main():
     ap.add_argument("-n", type=int, default=200)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--keep", default=None)
+    ap.add_argument("--finalize-host", action="store_true",
+                    help="compare `--score-finalize host` with the reference in THIS host's default numpy environment "
+                         "(AVX-512 exp where the CPU has it) instead of the pinned libm one")
     a = ap.parse_args()
+    env_kind, finalize = ("avx512", "host") if a.finalize_host else ("libm", "gpu")
     rnd = random.Random(a.seed)
     scratch = tempfile.mkdtemp(prefix="fuzz_")
     bad = 0
@@ -90,10 +95,10 @@ def main():
         fa = degenerate[it] if it < len(degenerate) else random_fasta(rnd)
         extra = rnd.choice([(), (), (), ("-l", "17"), ("-l", "23"), ("-l", "30"), ("-v",), ("-v", "-l", "21")])
         try:
-            want = mg.run_reference(fa, mg.MINI_GFF, "libm", scratch, extra=extra)
+            want = mg.run_reference(fa, mg.MINI_GFF, env_kind, scratch, extra=extra)
         except RuntimeError as e:
             want = ("EXC", str(e).strip().splitlines()[-1].split(":")[0]), ""
-        got = ours(fa, extra, scratch)
+        got = ours(fa, extra, scratch, finalize)
         if "-v" in extra and not isinstance(want[0], tuple) and not isinstance(got[0], tuple):
             from conftest import normalize_verbose  # paths and the CPU count differ by construction
             want = (want[0], normalize_verbose(want[1]))
