@@ -22,8 +22,14 @@ constexpr int BLOCK = 256;     // threads per workgroup (4 wavefronts of 64)
 // with CRP_DYN_CHUNKS: 1 = wave 0 looks back before it scores anything, 0 = after its first chunk
 #define CRP_LB_FIRST 0
 #endif
+#ifndef CRP_NT_STORES
+#define CRP_NT_STORES 0  // hit-table stores with the non-temporal hint
+#endif
+#ifndef CRP_ROTATE_WAVES
+#define CRP_ROTATE_WAVES 1  // single-launch mode: wave 0 (which also resolves the prefix) owns the last chunk of every four
+#endif
 #ifndef CRP_LB_FIRST_STATIC
-#define CRP_LB_FIRST_STATIC 0  // single-launch mode: wave 0 resolves the prefix before it scores its first hits
+#define CRP_LB_FIRST_STATIC 1  // single-launch mode: wave 0 resolves the prefix before it scores its first hits
 #endif
 #ifndef CRP_LB_NOINLINE
 #define CRP_LB_NOINLINE 0  // single-launch mode: the look-back as a real function call (keeps its registers out of the scorer's loop)
@@ -33,6 +39,15 @@ constexpr int BLOCK = 256;     // threads per workgroup (4 wavefronts of 64)
 #endif
 #ifndef CRP_LB_EARLY
 #define CRP_LB_EARLY 0  // single-launch mode: request the look-back's descriptors before the first hits are scored
+#endif
+#ifndef CRP_EXPERIMENT_LDS_PAD
+#define CRP_EXPERIMENT_LDS_PAD 0  // timing-only: unused LDS per workgroup, to measure the sensitivity to occupancy
+#endif
+#ifndef CRP_EXPERIMENT_NO_STORE
+#define CRP_EXPERIMENT_NO_STORE 0  // timing-only: the table stores are skipped
+#endif
+#ifndef CRP_EXPERIMENT_STOP
+#define CRP_EXPERIMENT_STOP 0  // timing-only: 1 = tiles stop after publishing their counts, 2 = after the hit list
 #endif
 #ifndef CRP_EXPERIMENT_NO_LB
 #define CRP_EXPERIMENT_NO_LB 0  // timing-only ablations of the look-back (results are wrong when set)

@@ -31,6 +31,12 @@
 #include "crp_score.h"
 #include "crp_score_generic.h"
 
+#if CRP_NT_STORES  // the tables are written once and not read again by this kernel
+#define CRP_TABLE_STORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#else
+#define CRP_TABLE_STORE(ptr, val) (*(ptr) = (val))
+#endif
+
 namespace crp {
 
 static constexpr uint64_t ALL = ~0ull;
@@ -594,6 +600,10 @@ __global__ __launch_bounds__(EMIT_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8
     __shared__ uint32_t s_tile;
 #endif
     __shared__ uint16_t list[CAP];
+#if CRP_EXPERIMENT_LDS_PAD  // TIMING ONLY: occupancy sensitivity (bytes of unused LDS per workgroup)
+    __shared__ uint8_t lds_pad[CRP_EXPERIMENT_LDS_PAD];
+    if (n_words_padded == 12345) lds_pad[threadIdx.x] = 1;
+#endif
 
     const int tid = threadIdx.x;
     uint32_t tile = blockIdx.x;
@@ -719,6 +729,9 @@ __global__ __launch_bounds__(EMIT_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8
         off_minus = off.y;
         if (n_all == 0) return;
     }
+#if CRP_EXPERIMENT_STOP == 1  // TIMING ONLY: load + masks + block scan + publish, nothing else
+    if (CHAINED) return;
+#endif
 #if CRP_TABLES_AFTER_PUBLISH
     // the scorer's tables are first read after the barrier that follows the hit-list build
     stage_tables();
@@ -781,6 +794,9 @@ __device__ __forceinline__ void emit_rounds(uint64_t (*sh)[TW + 2], uint16_t *li
         compact(std::true_type{});
 #endif
         if (CHAINED && tid == 0) *ch.s_next = 0;  // chunk counter of this round (read after the barrier below)
+#if CRP_EXPERIMENT_STOP == 2  // TIMING ONLY: ... + the hit list
+        if (CHAINED) return;
+#endif
         __syncthreads();
         // ---- one hit per lane: extract the 30-window, score, store
         const uint32_t n_round = min((uint32_t)CAP, n_all - lo_rank);
@@ -828,20 +844,23 @@ __device__ __forceinline__ void emit_rounds(uint64_t (*sh)[TW + 2], uint16_t *li
             return hit;
         };
         auto store = [&](const Hit &hit) {
+#if CRP_EXPERIMENT_NO_STORE  // TIMING ONLY: nothing is written unless an impossible score turns up
+            if (hit.score != 12345.0) return;
+#endif
             const uint32_t pos = tile_pos + hit.e;
             if (hit.r >= n_plus) {
                 const uint64_t o = off_minus + (hit.r - n_plus);
                 if (o < out.cap_minus) {
-                    out.pos_minus[o] = pos;
-                    out.score_minus[o] = hit.score;
-                    if (out.pre_minus) out.pre_minus[o] = hit.pre;
+                    CRP_TABLE_STORE(&out.pos_minus[o], pos);
+                    CRP_TABLE_STORE(&out.score_minus[o], hit.score);
+                    if (out.pre_minus) CRP_TABLE_STORE(&out.pre_minus[o], hit.pre);
                 }
             } else {
                 const uint64_t o = off_plus + hit.r;
                 if (o < out.cap_plus) {
-                    out.pos_plus[o] = pos;
-                    out.score_plus[o] = hit.score;
-                    if (out.pre_plus) out.pre_plus[o] = hit.pre;
+                    CRP_TABLE_STORE(&out.pos_plus[o], pos);
+                    CRP_TABLE_STORE(&out.score_plus[o], hit.score);
+                    if (out.pre_plus) CRP_TABLE_STORE(&out.pre_plus[o], hit.pre);
                 }
             }
         };
@@ -910,7 +929,15 @@ __device__ __forceinline__ void emit_rounds(uint64_t (*sh)[TW + 2], uint16_t *li
                 if (cur.e != 0xffffffffu) store(cur);
             }
 #else
+#if CRP_ROTATE_WAVES
+            // The workgroup's slot (LDS, wave slots) is held until its LAST wave is done, and wave 0 also
+            // resolves the tile's prefix.  So wave 0 takes the chunks of 64 rows nobody would miss: waves
+            // 1, 2, 3 own chunks 0, 1, 2 (mod 4) and wave 0 chunk 3 -- when the row count is not a multiple
+            // of 256 it is wave 0 that has one chunk less, not one more.
+            uint32_t k = (uint32_t)(tid & 63) | ((((uint32_t)tid >> 6) + (EMIT_BLOCK / 64 - 1)) % (EMIT_BLOCK / 64)) << 6;
+#else
             uint32_t k = tid;
+#endif
             const bool any = k < n_round;
             Hit cur{};
 #if CRP_LB_FIRST_STATIC
