@@ -68,6 +68,11 @@ constexpr int BLOCK = 256;     // threads per workgroup (4 wavefronts of 64)
 #ifndef CRP_TABLES_AFTER_PUBLISH
 #define CRP_TABLES_AFTER_PUBLISH 1  // stage the scorer's LDS tables after the block scan instead of before it
 #endif
+#ifndef CRP_LIST_COMPACT
+// hit-list build: 1 = the non-empty 32-bit mask halves of a wave are compacted into a work list first and the
+// bit peeling runs over items (no lane idles on an empty half); 0 = every lane peels its own halves
+#define CRP_LIST_COMPACT 0
+#endif
 #ifndef CRP_LIST_FASTPATH
 #define CRP_LIST_FASTPATH 1  // hit-list build without the capacity test when the tile's hits all fit
 #endif

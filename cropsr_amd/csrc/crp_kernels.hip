@@ -562,7 +562,7 @@ __device__ __forceinline__ void chain_resolve(const ChainArgs &ch, uint64_t (&lb
 }
 
 template <int WPT, int TW, int CAP, bool PAM, bool CHAINED>
-__device__ __forceinline__ void emit_rounds(uint64_t (*sh)[TW + 2], uint16_t *list, const uint64_t *exp_tab, const double *score_tab,
+__device__ __forceinline__ void emit_rounds(uint64_t (*sh)[TW + 2], uint16_t *list, uint64_t *exp_tab, double *score_tab,
                                             const uint64_t (&mp)[WPT], const uint64_t (&mm)[WPT], uint64_t ex,
                                             uint32_t n_plus, uint32_t n_minus, int l, uint32_t tile_pos,
                                             uint64_t off_plus, uint64_t off_minus, const HitTables &out,
@@ -590,8 +590,11 @@ __global__ __launch_bounds__(EMIT_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8
     constexpr int TW = EMIT_BLOCK * WPT;
     constexpr int CAP = CRP_LIST_CAP_PER_WPT * WPT;  // list entries per round; typical tiles need one round
     __shared__ uint64_t sh[4][TW + 2];
-    __shared__ uint64_t exp_tab[256];
-    __shared__ double score_tab[CRP_SCORE_TAB_N];
+    // exp table (256 words) + chain-prefix tables of the scorer, one block: until the hit list is built the
+    // same bytes are the list build's work-list scratch (CRP_LIST_COMPACT)
+    __shared__ uint64_t tabs[256 + CRP_SCORE_TAB_N];
+    uint64_t *const exp_tab = tabs;
+    double *const score_tab = reinterpret_cast<double *>(tabs + 256);
     __shared__ uint64_t wave_tot[EMIT_BLOCK / 64];
     __shared__ uint64_t s_excl;
     __shared__ uint32_t s_flag;
@@ -675,12 +678,14 @@ __global__ __launch_bounds__(EMIT_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8
 #else
     stage_tile<TW>(pl, t0, n_words_padded, sh);
 #endif
+#if !CRP_LIST_COMPACT
     auto stage_tables = [&]() {
         for (int k = tid; k < 256; k += EMIT_BLOCK) exp_tab[k] = CRP_EXP_TAB[k];
         if (LFIX == 20)
             for (int k = tid; k < CRP_SCORE_TAB_N; k += EMIT_BLOCK) score_tab[k] = CRP_SCORE_TAB[k];
     };
-#if !CRP_TABLES_AFTER_PUBLISH
+#endif
+#if !CRP_TABLES_AFTER_PUBLISH && !CRP_LIST_COMPACT
     stage_tables();
 #endif
 #if !CRP_STREAM_MASKS
@@ -732,7 +737,7 @@ __global__ __launch_bounds__(EMIT_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8
 #if CRP_EXPERIMENT_STOP == 1  // TIMING ONLY: load + masks + block scan + publish, nothing else
     if (CHAINED) return;
 #endif
-#if CRP_TABLES_AFTER_PUBLISH
+#if CRP_TABLES_AFTER_PUBLISH && !CRP_LIST_COMPACT
     // the scorer's tables are first read after the barrier that follows the hit-list build
     stage_tables();
 #endif
@@ -742,7 +747,7 @@ __global__ __launch_bounds__(EMIT_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8
 
 // Compact the kept hits of one staged tile and score them, CAP list entries per round.
 template <int WPT, int TW, int CAP, bool PAM, bool CHAINED>
-__device__ __forceinline__ void emit_rounds(uint64_t (*sh)[TW + 2], uint16_t *list, const uint64_t *exp_tab, const double *score_tab,
+__device__ __forceinline__ void emit_rounds(uint64_t (*sh)[TW + 2], uint16_t *list, uint64_t *exp_tab, double *score_tab,
                                             const uint64_t (&mp)[WPT], const uint64_t (&mm)[WPT], uint64_t ex,
                                             uint32_t n_plus, uint32_t n_minus, int l, uint32_t tile_pos,
                                             uint64_t off_plus, uint64_t off_minus, const HitTables &out,
@@ -787,7 +792,59 @@ __device__ __forceinline__ void emit_rounds(uint64_t (*sh)[TW + 2], uint16_t *li
                 }
             }
         };
-#if CRP_LIST_FASTPATH
+#if CRP_LIST_COMPACT
+        // Balanced build (a tile whose hits all fit the list).  The peeling loops above run to the wave's
+        // MAXIMUM popcount while most lanes have nothing left -- soft-masking clusters the hits, half the lanes
+        // of a wave own no hit at all.  So the non-empty 32-bit halves are first compacted into a work list
+        // (one 8-byte item each: mask, position base, rank base; slots from the compare's own lane mask +
+        // v_mbcnt, no loop), and the peeling then runs over ITEMS, 64 at a time: no lane idles on an empty
+        // half.  Scratch = the scorer's table block of LDS, which is staged only after the list is complete;
+        // one word of every thread per pass, so a wave never has more than 256 items (its share holds 304).
+        auto compact_balanced = [&]() {
+            const int lane = tid & 63;
+            constexpr uint32_t PER_WAVE = (256 + CRP_SCORE_TAB_N) / (EMIT_BLOCK / 64);
+            static_assert(PER_WAVE >= 256, "work-list scratch: 4 halves x 64 lanes per pass");
+            uint2 *const scr = reinterpret_cast<uint2 *>(exp_tab) + (tid >> 6) * PER_WAVE;
+            uint32_t rp = (uint32_t)ex;                    // rank of this thread's next '+' hit
+            uint32_t rm = n_plus + (uint32_t)(ex >> 32);  // same for '-'
+#pragma unroll
+            for (int k = 0; k < WPT; ++k) {
+                const uint32_t wbase = (uint32_t)(tid * WPT + k) * 64u;
+                uint32_t n_items = 0;  // wave-uniform
+                auto push = [&](uint32_t m, uint32_t pbase, uint32_t r) {
+                    const uint64_t nz = __ballot(m != 0);
+                    const uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(nz >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nz, n_items));
+                    if (m) scr[slot] = make_uint2(m, pbase | (r << 16));
+                    n_items += (uint32_t)__popcll(nz);
+                };
+                const uint32_t p0 = (uint32_t)mp[k], p1 = (uint32_t)(mp[k] >> 32);
+                const uint32_t m0 = (uint32_t)mm[k], m1 = (uint32_t)(mm[k] >> 32);
+                push(p0, wbase, rp);
+                rp += __popc(p0);
+                push(p1, wbase + 32, rp);
+                rp += __popc(p1);
+                push(m0, wbase, rm);
+                rm += __popc(m0);
+                push(m1, wbase + 32, rm);
+                rm += __popc(m1);
+                // (LDS serves a wave's accesses in order: the items are there when they are read back)
+                for (uint32_t b = 0; b < n_items; b += 64) {
+                    uint2 it = make_uint2(0, 0);
+                    if (b + lane < n_items) it = scr[b + lane];
+                    uint32_t m = it.x;
+                    const uint32_t pbase = it.y & 0xffffu;
+                    uint16_t *dst = list + (it.y >> 16);
+                    while (m) {
+                        const uint32_t bit = __builtin_ctz(m);
+                        m &= m - 1;
+                        *dst++ = (uint16_t)(pbase + bit);
+                    }
+                }
+            }
+        };
+        if (n_all <= (uint32_t)CAP) compact_balanced();
+        else compact(std::true_type{});
+#elif CRP_LIST_FASTPATH
         if (n_all <= (uint32_t)CAP) compact(std::false_type{});
         else compact(std::true_type{});
 #else
@@ -798,6 +855,14 @@ __device__ __forceinline__ void emit_rounds(uint64_t (*sh)[TW + 2], uint16_t *li
         if (CHAINED) return;
 #endif
         __syncthreads();
+#if CRP_LIST_COMPACT
+        if (lo_rank == 0) {  // the list is complete, its scratch is free: now the scorer's tables move in
+            for (int k = tid; k < 256; k += EMIT_BLOCK) exp_tab[k] = CRP_EXP_TAB[k];
+            if (PAM)
+                for (int k = tid; k < CRP_SCORE_TAB_N; k += EMIT_BLOCK) score_tab[k] = CRP_SCORE_TAB[k];
+            __syncthreads();
+        }
+#endif
         // ---- one hit per lane: extract the 30-window, score, store
         const uint32_t n_round = min((uint32_t)CAP, n_all - lo_rank);
         struct Hit {
