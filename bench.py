@@ -394,5 +394,8 @@ if __name__ == "__main__":
         from cropsr_amd import rendezvous
         g = getattr(rendezvous, "LAST_GROUP", None)
         if g is not None and g.world > 1:
+            if isinstance(e, rendezvous.RankError):  # every rank has this error: leave together
+                g.close()
+                sys.exit(1)
             g.abort("%s: %s" % (type(e).__name__, e))
         sys.exit(1)

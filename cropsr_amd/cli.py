@@ -457,7 +457,9 @@ def main(argv=None):
         run(args)
     except Exception as e:
         from . import rendezvous
-        if isinstance(e, rendezvous.RankError):  # agreed on by every rank: all exit the same way
+        if isinstance(e, rendezvous.RankError):  # agreed on by every rank: all leave the same way, together
+            if _ACTIVE_GROUP is not None:
+                _ACTIVE_GROUP.close()
             sys.exit("cropsr_amd: " + str(e))
         if _ACTIVE_GROUP is not None and _ACTIVE_GROUP.world > 1:
             # this rank alone failed (a HIP or RCCL error in the middle of the exchange, ...): its peers may sit in
