@@ -84,6 +84,10 @@ def scaled(w, bit):
 # bits of (bits * MAGIC) are different for every one of the 2^k patterns (any one-to-one mapping
 # will do, the table is laid out to match).  Terms past the first k of a chain stay gated FMAs.
 TABLE_BITS = {"fA": 8, "fT": 8, "fG": 7, "fC": 7, "sG": 7, "sC": 7, "sA": 6, "sT": 0}  # sT: 4 terms, 25 positions apart
+# experiments: CRP_TABLE_BITS="fA=7,fT=7" trades table size (LDS) against gated FMAs
+for _kv in os.environ.get("CRP_TABLE_BITS", "").split(","):
+    if "=" in _kv:
+        TABLE_BITS[_kv.split("=")[0].strip()] = int(_kv.split("=")[1])
 
 
 def find_gather(qs, rng_seed):
