@@ -78,7 +78,7 @@ def _worker(rank, world, port, out_path, offtarget, max_piece):
     group.close()
 
 
-@pytest.mark.parametrize("world,offtarget,max_piece", [(2, False, None), (3, False, 7000), (2, True, 7000), (3, True, None)])
+@pytest.mark.parametrize("world,offtarget,max_piece", [(2, False, None), (3, False, 7000), (2, True, 7000), (3, True, None), (8, True, 7000)])
 def test_sharded_scan_over_control_sockets(world, offtarget, max_piece, tmp_path, oracle):
     """Every contig's tables (and, with the seed scan, every hit's genome-wide off-target counts) come
     out of the sharded flow exactly as from one scan of the whole list -- with contigs cut into pieces
