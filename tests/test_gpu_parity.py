@@ -770,7 +770,7 @@ def test_randomised_arenas_vs_oracle(engine, oracle):
     anchors = [0, 1, 30, 63, 64, 65, 16383, 16384, 16385, 2 * 16384 - 1, 2 * 16384, 2 * 16384 + 1, 3 * 16384 + 7,
                4 * 16384 - 1, 4 * 16384, 4 * 16384 + 65]
     total_hits = 0
-    for trial in range(60):
+    for trial in range(int(os.environ.get("CROPSR_FUZZ_TRIALS", "60"))):  # (more for a long soak on the GPU box)
         contigs = []
         for _ in range(int(rng.integers(1, 9))):
             n = max(0, int(anchors[rng.integers(len(anchors))] + rng.integers(-40, 41)))

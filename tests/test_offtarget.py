@@ -251,6 +251,32 @@ def test_gpu_counts_vs_all_pairs_on_a_megabase(engine, oracle):
 
 
 @gpu
+def test_gpu_randomised_genomes_vs_oracle(engine, oracle):
+    """Seeded fuzz: random contig counts and lengths (around word and tile borders), alphabets, guide lengths and
+    arena splits; seeds, histogram and all four counts against the oracle's enumeration method."""
+    rng = np.random.default_rng(424242)
+    alphabets = [b"ACGT", b"ACGTacgtN", b"GGCC", b"ACGTUZuzN')],", b"GGGGGGCCCCCCAT", b"ACGTACGTACGTN"]
+    anchors = [0, 1, 30, 63, 64, 65, 16383, 16384, 16385, 2 * 16384 + 1, 40000]
+    for trial in range(int(os.environ.get("CROPSR_FUZZ_TRIALS", "25"))):
+        contigs = []
+        for _ in range(int(rng.integers(1, 7))):
+            n = max(0, int(anchors[rng.integers(len(anchors))] + rng.integers(-40, 41)))
+            body = rng.choice(np.frombuffer(alphabets[rng.integers(len(alphabets))], dtype=np.uint8), n).tobytes()
+            deco = rng.integers(3)
+            contigs.append(body if deco == 0 else b"'" + body + (b"')," if deco == 1 else b"')]"))
+        l = 20 if rng.random() < 0.6 else int(rng.integers(9, 31))
+        max_words = None if rng.random() < 0.5 else int(rng.integers(1200, 4000))
+        try:
+            out, seeds, hits = gpu_offtarget(engine, contigs, l, max_words)
+        except ValueError:  # a contig longer than the arena size drawn for this trial
+            out, seeds, hits = gpu_offtarget(engine, contigs, l, None)
+        want = oracle.offtarget_genome(contigs, l)
+        for k in range(len(contigs)):
+            for key in ("ot_plus", "ot_minus"):
+                assert out[k][key].shape == want[k][key].shape and (out[k][key] == want[k][key]).all(), (trial, k, key, l)
+
+
+@gpu
 @pytest.mark.parametrize("l", [11, 12, 19, 21, 50])
 def test_gpu_guide_lengths(engine, oracle, l):
     rng = np.random.default_rng(l)
