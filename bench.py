@@ -285,10 +285,11 @@ def main():
             per = {k: pot[k]["ms"] / max(1, pot[k]["launches"]) for k in ("ot_seed", "ot_ball", "ot_lookup", "ot_reduce")}
             hits = n_plus + n_minus
             # algorithmic bytes of one step on this rank: seeds 4 B pos in + 4 B seed out
-            # per hit + the 12 characters next to the PAM out of 4 planes (counted as 4 x 8 B words); partition 4 B seed
-            # in + 2 B out per site, bucket histograms 2 B in per site + 64 MiB in and out; ball passes 64 MiB in,
-            # 3 x 256 MiB out, 2 x 256 MiB back in; look-up 4 + 16 + 16 B per hit
-            seed_bytes = hits * (4 + 4 + 32) + hits * 4 + sites * 4 + 2 * (1 << 26)
+            # per hit + the 12 characters next to the PAM out of 4 planes (counted as 4 x 8 B words); partition level 1
+            # 4 B seed in per hit + 4 B out per site, level 2 4 B in + 2 B out per site, bucket histograms 2 B in per
+            # site + 64 MiB in and out; ball passes 64 MiB in, 3 x 256 MiB out, 2 x 256 MiB back in; look-up
+            # 4 + 16 + 16 B per hit
+            seed_bytes = hits * (4 + 4 + 32) + hits * 4 + sites * (4 + 4 + 2 + 2) + 2 * (1 << 26)
             ball_bytes = (1 << 24) * (4 + 16 * 5)
             look_bytes = hits * (4 + 16 + 16)
             ot = {"metric": "guides off-target-scanned/sec", "value": hits_all * args.offtarget_steps / dt_ot,

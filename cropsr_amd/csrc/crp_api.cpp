@@ -121,6 +121,7 @@ int crp_destroy(crp_ctx *ctx)
     (void)hipFree(ctx->d_ot_hist);
     (void)hipFree(ctx->d_ot_ball);
     (void)hipFree(ctx->d_ot_part);
+    (void)hipFree(ctx->d_ot_part1);
     (void)hipFree(ctx->d_ot_bucket);
     crp::comm_release(ctx);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);

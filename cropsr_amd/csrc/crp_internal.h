@@ -44,6 +44,8 @@ struct crp_ctx {
     uint4 *d_ot_ball = nullptr;     // 4^12 x {sites at distance 0, 1, 2, 3}
     uint16_t *d_ot_part = nullptr;  // partition scratch: low 12 seed bits of one strand's sites, bucket by bucket
     uint64_t ot_part_cap = 0;
+    uint32_t *d_ot_part1 = nullptr;  // first partition level: whole codes, grouped by the top 6 seed bits
+    uint64_t ot_part1_cap = 0;
     uint32_t *d_ot_bucket = nullptr;  // 4096 bucket totals, 4096 + 1 bucket starts, 4096 write cursors
     bool ot_solved = false;
     uint64_t ot_epoch = 0;          // bumped by crp_offtarget_reset: arenas added before it are stale

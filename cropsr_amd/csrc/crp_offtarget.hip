@@ -74,9 +74,11 @@ __device__ __forceinline__ uint32_t spread12(uint32_t x)
 //                        global bucket totals with CONTIGUOUS atomics (64 consecutive counters per wave
 //                        instruction: the fast path, one instruction per 64 buckets and workgroup)
 //   ot_bucket_scan       exclusive scan of the 4096 totals (one workgroup)
-//   ot_partition_kernel  every workgroup recounts its chunk, reserves a range in every bucket with
-//                        one contiguous atomic sweep, and scatters the seeds' low 12 bits there
-//                        (order inside a bucket does not matter)
+//   ot_partition1_kernel / ot_partition_kernel
+//                        two scatter passes (top 6 seed bits, then the next 6): every workgroup recounts its
+//                        chunk, reserves a range in every bucket with one contiguous atomic sweep and scatters
+//                        there -- whole codes first, the low 12 bits at the end (order inside a bucket does
+//                        not matter); two levels so that every run a chunk writes is a few hundred bytes long
 //   ot_bucket_hist       one workgroup per bucket: 4096-bin histogram of its entries in LDS, added to
 //                        the bucket's slice of the global histogram with plain 16-byte accesses
 // Chunks: workgroup w owns hits [w * OT_CHUNK, (w + 1) * OT_CHUNK) of a strand's table in both passes.
@@ -87,11 +89,9 @@ constexpr uint32_t OT_BUCKETS = 4096;
 constexpr uint32_t OT_CHUNK = CRP_OT_CHUNK;
 
 template <bool MINUS>
-__device__ __forceinline__ uint32_t seed_of_hit(const Planes &pl, uint64_t p, const uint64_t *__restrict__ own, uint32_t n_own)
+__device__ __forceinline__ uint32_t seed_of_windows(uint32_t h, uint32_t w, uint32_t u, uint32_t a, uint64_t p,
+                                                    const uint64_t *__restrict__ own, uint32_t n_own)
 {
-    const uint64_t q = MINUS ? p + 3 : p - CRP_OT_SEED_LEN;
-    uint32_t h = window12(pl.plane[0], q), w = window12(pl.plane[1], q);
-    const uint32_t u = window12(pl.plane[2], q), a = window12(pl.plane[3], q);
     const bool valid = ((a | u) & 0xfffu) == 0xfffu;
     if (!MINUS) {
         w ^= u;  // complement = flip the low code bit, upper case only
@@ -111,6 +111,8 @@ __device__ __forceinline__ uint32_t seed_of_hit(const Planes &pl, uint64_t p, co
     return (spread12(h) << 1) | spread12(w);
 }
 
+// (Staging each round's stretch of the planes through LDS -- coalesced copies, windows cut from LDS -- was measured:
+// 2 x 0.34 ms instead of 2 x 0.29, the two extra barriers per round cost more than the divergent loads.)
 template <bool MINUS>
 __global__ __launch_bounds__(BLOCK) void ot_seed_kernel(Planes pl, const uint32_t *__restrict__ pos, uint64_t n,
                                                          const uint64_t *__restrict__ own, uint32_t n_own,
@@ -121,7 +123,10 @@ __global__ __launch_bounds__(BLOCK) void ot_seed_kernel(Planes pl, const uint32_
     __syncthreads();
     const uint64_t lo = (uint64_t)blockIdx.x * OT_CHUNK, hi = lo + OT_CHUNK < n ? lo + OT_CHUNK : n;
     for (uint64_t t = lo + threadIdx.x; t < hi; t += BLOCK) {
-        const uint32_t code = seed_of_hit<MINUS>(pl, pos[t], own, n_own);
+        const uint64_t p = pos[t];
+        const uint64_t q = MINUS ? p + 3 : p - CRP_OT_SEED_LEN;
+        const uint32_t code = seed_of_windows<MINUS>(window12(pl.plane[0], q), window12(pl.plane[1], q), window12(pl.plane[2], q),
+                                                     window12(pl.plane[3], q), p, own, n_own);
         seeds[t] = code;
         if (code < OT_SEEDS) atomicAdd(&cnt[code >> 12], 1u);
     }
@@ -133,6 +138,7 @@ __global__ __launch_bounds__(BLOCK) void ot_seed_kernel(Planes pl, const uint32_
 // bucket_total[4096] -> cursor[4096] = exclusive prefix (the partition's write cursors), *n_sites = sum
 __global__ __launch_bounds__(1024) void ot_bucket_scan_kernel(const uint32_t *__restrict__ bucket_total,
                                                                uint32_t *__restrict__ bucket_start, uint32_t *__restrict__ cursor,
+                                                               uint32_t *__restrict__ cursor1,
                                                                unsigned long long *__restrict__ n_sites)
 {
     __shared__ uint32_t part[1024];
@@ -156,6 +162,7 @@ __global__ __launch_bounds__(1024) void ot_bucket_scan_kernel(const uint32_t *__
     for (int k = 0; k < 4; ++k) {
         bucket_start[4 * tid + k] = ex;
         cursor[4 * tid + k] = ex;
+        if ((4 * tid + k) % 64 == 0) cursor1[(4 * tid + k) / 64] = ex;  // a super-bucket = 64 consecutive buckets
         ex += v[k];
     }
     if (tid == 1023) {
@@ -164,10 +171,41 @@ __global__ __launch_bounds__(1024) void ot_bucket_scan_kernel(const uint32_t *__
     }
 }
 
+// Level 1: the sites of a chunk go to their SUPER-bucket (the seed's top 6 bits, 64 buckets of the final 4096) as
+// whole 24-bit codes: a chunk of 16 384 hits writes runs of ~256 x 4 bytes, full lines -- where scattering straight
+// into 4096 buckets wrote ~4 x 2 bytes per bucket and chunk (partial lines: 0.44 ms per strand on the bench genome).
+__global__ __launch_bounds__(BLOCK) void ot_partition1_kernel(const uint32_t *__restrict__ seeds, uint64_t n,
+                                                               uint32_t *__restrict__ cursor1, uint32_t *__restrict__ part1)
+{
+    __shared__ uint32_t cnt[64];
+    if (threadIdx.x < 64) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t lo = (uint64_t)blockIdx.x * OT_CHUNK, hi = lo + OT_CHUNK < n ? lo + OT_CHUNK : n;
+    for (uint64_t t = lo + threadIdx.x; t < hi; t += BLOCK) {
+        const uint32_t code = seeds[t];
+        if (code < OT_SEEDS) atomicAdd(&cnt[code >> 18], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const uint32_t c = cnt[threadIdx.x];
+        cnt[threadIdx.x] = c ? atomicAdd(&cursor1[threadIdx.x], c) : 0;
+    }
+    __syncthreads();
+    for (uint64_t t = lo + threadIdx.x; t < hi; t += BLOCK) {
+        const uint32_t code = seeds[t];
+        if (code < OT_SEEDS) part1[atomicAdd(&cnt[code >> 18], 1u)] = code;
+    }
+}
+
+// Level 2 (n_ptr: the number of entries, known on the device only): entries grouped by super-bucket -> their final
+// bucket; a chunk now lies inside one or two super-buckets, so it writes runs of ~256 x 2 bytes.
 __global__ __launch_bounds__(BLOCK) void ot_partition_kernel(const uint32_t *__restrict__ seeds, uint64_t n,
+                                                              const unsigned long long *__restrict__ n_ptr,
                                                               uint32_t *__restrict__ cursor, uint16_t *__restrict__ part)
 {
     __shared__ uint32_t cnt[OT_BUCKETS];  // first the chunk's count per bucket, then its next write index
+    if (n_ptr) n = *n_ptr;
+    if ((uint64_t)blockIdx.x * OT_CHUNK >= n) return;
     for (uint32_t b = threadIdx.x; b < OT_BUCKETS; b += BLOCK) cnt[b] = 0;
     __syncthreads();
     const uint64_t lo = (uint64_t)blockIdx.x * OT_CHUNK, hi = lo + OT_CHUNK < n ? lo + OT_CHUNK : n;
@@ -280,17 +318,42 @@ __global__ __launch_bounds__(1024) void ot_ball_kernel(const uint32_t *__restric
     }
 }
 
+#ifndef CRP_OT_LOOKUP_ILP
+#define CRP_OT_LOOKUP_ILP 1
+#endif
+// ILP independent gathers in flight per lane.  Measured: 1, 2, 4, 8 all run at the same rate,
+// and a table cut down to 4 MB (L2-resident) is only 2x faster -- the gather is bound by the ~6 cycles the vector
+// memory path spends per divergent lane, neither by latency nor by HBM bandwidth.
 __global__ __launch_bounds__(BLOCK) void ot_lookup_kernel(const uint32_t *__restrict__ seeds, uint64_t n,
                                                            const uint4 *__restrict__ ball, uint4 *__restrict__ out)
 {
-    for (uint64_t t = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; t < n; t += (uint64_t)gridDim.x * BLOCK) {
-        const uint32_t s = seeds[t];
-        uint4 v = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
-        if (s < OT_SEEDS) {
-            v = ball[s];
-            v.x -= 1;  // the hit itself is one of the sites at distance 0
+    constexpr int ILP = CRP_OT_LOOKUP_ILP;
+    const uint64_t span = (uint64_t)gridDim.x * BLOCK;
+    for (uint64_t t0 = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; t0 < n; t0 += span * ILP) {
+        uint32_t s[ILP];
+        uint4 v[ILP];
+#pragma unroll
+        for (int k = 0; k < ILP; ++k) {
+            const uint64_t t = t0 + k * span;
+            s[k] = t < n ? seeds[t] : OT_NOT_A_SITE;
         }
-        out[t] = v;
+#pragma unroll
+        for (int k = 0; k < ILP; ++k) {
+            v[k] = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
+            if (s[k] < OT_SEEDS) {
+#ifdef CRP_EXPERIMENT_OT_LOOKUP_MASK  // measurement only (wrong counts): how the gather's rate depends on the table's span
+                v[k] = ball[s[k] & CRP_EXPERIMENT_OT_LOOKUP_MASK];
+#else
+                v[k] = ball[s[k]];
+#endif
+                v[k].x -= 1;  // the hit itself is one of the sites at distance 0
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < ILP; ++k) {
+            const uint64_t t = t0 + k * span;
+            if (t < n) out[t] = v[k];
+        }
     }
 }
 
@@ -347,9 +410,11 @@ int crp_offtarget_add(crp_arena *a, int guide_len, const uint64_t *own_ranges, u
     // scratch of the partition: the low 12 bits of every site of one strand's table, 3 x 4096(+1) counters
     const uint64_t n_max = std::max(a->n_hits[0], a->n_hits[1]);
     int rc0 = crp::grow(ctx, reinterpret_cast<void **>(&ctx->d_ot_part), &ctx->ot_part_cap, n_max, sizeof(uint16_t));
+    if (rc0 == CRP_OK) rc0 = crp::grow(ctx, reinterpret_cast<void **>(&ctx->d_ot_part1), &ctx->ot_part1_cap, n_max, sizeof(uint32_t));
     if (rc0 != CRP_OK) return rc0;
-    if (!ctx->d_ot_bucket) CRP_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_ot_bucket), (3 * crp::OT_BUCKETS + 8) * sizeof(uint32_t)));
+    if (!ctx->d_ot_bucket) CRP_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_ot_bucket), (3 * crp::OT_BUCKETS + 8 + 64) * sizeof(uint32_t)));
     uint32_t *d_total = ctx->d_ot_bucket, *d_start = d_total + crp::OT_BUCKETS, *d_cursor = d_start + crp::OT_BUCKETS + 4;
+    uint32_t *d_cursor1 = d_cursor + crp::OT_BUCKETS + 4;
     crp::Planes pl{{a->d_plane[0], a->d_plane[1], a->d_plane[2], a->d_plane[3]}};
     unsigned long long *d_n = reinterpret_cast<unsigned long long *>(ctx->d_scalar);
     uint64_t sites = 0;
@@ -370,9 +435,12 @@ int crp_offtarget_add(crp_arena *a, int guide_len, const uint64_t *own_ranges, u
             else
                 hipLaunchKernelGGL(crp::ot_seed_kernel<true>, dim3(chunks), dim3(crp::BLOCK), 0, ctx->stream, pl, a->d_pos[1], n,
                                    a->d_ot_own, (uint32_t)n_ranges, a->d_ot_seed[1], d_total);
-            hipLaunchKernelGGL(crp::ot_bucket_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_total, d_start, d_cursor, d_n + s);
-            hipLaunchKernelGGL(crp::ot_partition_kernel, dim3(chunks), dim3(crp::BLOCK), 0, ctx->stream, a->d_ot_seed[s], n, d_cursor,
-                               ctx->d_ot_part);
+            hipLaunchKernelGGL(crp::ot_bucket_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_total, d_start, d_cursor, d_cursor1,
+                               d_n + s);
+            hipLaunchKernelGGL(crp::ot_partition1_kernel, dim3(chunks), dim3(crp::BLOCK), 0, ctx->stream, a->d_ot_seed[s], n, d_cursor1,
+                               ctx->d_ot_part1);
+            hipLaunchKernelGGL(crp::ot_partition_kernel, dim3(chunks), dim3(crp::BLOCK), 0, ctx->stream, ctx->d_ot_part1, n,
+                               reinterpret_cast<const unsigned long long *>(d_n + s), d_cursor, ctx->d_ot_part);
             hipLaunchKernelGGL(crp::ot_bucket_hist_kernel, dim3(crp::OT_BUCKETS), dim3(1024), 0, ctx->stream, ctx->d_ot_part, d_start,
                                ctx->d_ot_hist);
             CRP_HIP(ctx, hipGetLastError());
