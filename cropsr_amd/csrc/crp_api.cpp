@@ -321,6 +321,20 @@ int crp_arena_add_contig_packed(crp_arena *a, const uint64_t *hi, const uint64_t
     return CRP_OK;
 }
 
+// Word 3 of both chain headers = device address of the arena's pinned h_totals: the single-launch kernel
+// writes its fail flag and totals there as well, and the host reads them after the stream synchronisation
+// without a device-to-host copy in between.
+static int chain_headers_point_at_host(crp_arena *a)
+{
+    crp_ctx *ctx = a->ctx;
+    void *dev = nullptr;
+    CRP_HIP(ctx, hipHostGetDevicePointer(&dev, a->h_totals, 0));
+    a->h_totals[3] = reinterpret_cast<uint64_t>(dev);
+    for (int b = 0; b < 2; ++b)
+        CRP_HIP(ctx, hipMemcpyAsync(a->d_chain[b] + 3, &a->h_totals[3], sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+    return CRP_OK;
+}
+
 int crp_arena_seal(crp_arena *a)
 {
     if (!a) return CRP_ERR_INVALID;
@@ -337,6 +351,8 @@ int crp_arena_seal(crp_arena *a)
     }
     CRP_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&a->d_totals), 2 * sizeof(uint64_t)));
     CRP_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&a->h_totals), 4 * sizeof(uint64_t), hipHostMallocDefault));
+    int rc = chain_headers_point_at_host(a);
+    if (rc != CRP_OK) return rc;
     CRP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     a->sealed = true;
     return CRP_OK;
@@ -445,17 +461,19 @@ static int scan_single_pass(crp_arena *a, const crp::Planes &pl, uint64_t eff_wo
         if (rc != CRP_OK) return rc;
         const crp::HitTables out = table_args(a, want_pre);
         uint64_t *cur = a->d_chain[a->chain_cur], *next = a->d_chain[a->chain_cur ^ 1];
+        a->h_totals[0] = a->h_totals[1] = a->h_totals[2] = 0;
         prof_begin(ctx, 2);
         CRP_HIP(ctx, crp::launch_emit_chained(ctx->stream, pl, eff_words, guide_len, cur, next, out, ctx->mute_tile,
                                                   ctx->chain_timeout_ticks));
         prof_end(ctx, 2);
-        // header: ticket | fail << 32, total '+', total '-'
-        CRP_HIP(ctx, hipMemcpyAsync(a->h_totals, cur, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+        // header: ticket | fail << 32, total '+', total '-' -- the kernel also writes it to h_totals (pinned)
         CRP_HIP(ctx, hipStreamSynchronize(ctx->stream));
         a->chain_cur ^= 1;  // the kernel left the other buffer zeroed
         if (a->h_totals[0] >> 32) {  // fail flag: a look-back spin ran out; neither buffer can be trusted now
             for (int b = 0; b < 2; ++b)
                 CRP_HIP(ctx, hipMemsetAsync(a->d_chain[b], 0, crp::chain_bytes(a->n_tiles), ctx->stream));
+            int rc2 = chain_headers_point_at_host(a);
+            if (rc2 != CRP_OK) return rc2;
             *chain_failed = true;
             return CRP_ERR_STATE;
         }

@@ -515,7 +515,12 @@ __device__ __forceinline__ uint64_t lookback_resolve(uint64_t *desc, uint32_t ti
                     give_up |= __hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
                 }
                 if (give_up) {
-                    if (lane == 0) atomicExch(fail, 1u);
+                    if (lane == 0) {
+                        atomicExch(fail, 1u);
+                        // header word 3: where the host reads the outcome without a copy (see chain_resolve)
+                        uint64_t *const host = reinterpret_cast<uint64_t *>(reinterpret_cast<uint64_t *>(fail - 1)[3]);
+                        if (host) host[0] = 1ull << 32;
+                    }
                     return 0;
                 }
                 __builtin_amdgcn_s_sleep(8);
@@ -557,6 +562,13 @@ __device__ __forceinline__ void chain_resolve(const ChainArgs &ch, uint64_t (&lb
             const uint64_t all = e + ch.total;
             ch.totals[0] = all & 0xffffffffull;
             ch.totals[1] = all >> 32;
+            // header word 3 (set once by the host, never zeroed): a pinned host copy of the header, so that the
+            // host needs no device-to-host copy between the launch and its synchronisation
+            uint64_t *const host = reinterpret_cast<uint64_t *>(ch.totals[2]);
+            if (host) {
+                host[1] = all & 0xffffffffull;
+                host[2] = all >> 32;
+            }
         }
     }
 }
@@ -570,7 +582,8 @@ __device__ __forceinline__ void emit_rounds(uint64_t (*sh)[TW + 2], uint16_t *li
 
 // CHAINED = true : single pass.  Table offsets come from the decoupled look-back above;
 //                  `chain` holds a 32-byte header -- tile ticket (u32), fail flag (u32), the two
-//                  table totals (u64 each, written by the last tile), padding -- then one
+//                  table totals (u64 each, written by the last tile), a device pointer to a pinned
+//                  host copy of the first three words (or 0; never touched by the kernel) -- then one
 //                  descriptor per tile; it must be all zero at launch.  Launches alternate
 //                  between two such buffers and every tile zeroes its slot of the other one
 //                  (`chain_next`), so no memset runs between scans.  The tile
@@ -711,7 +724,7 @@ __global__ __launch_bounds__(EMIT_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8
             if (tile != mute_tile) lookback_publish(ch.desc, tile, total);
             // leave the OTHER descriptor buffer zeroed for the next launch (no memset between scans)
             chain_next[CHAIN_HEADER_WORDS + tile] = 0;
-            if (tile == 0) chain_next[0] = chain_next[1] = chain_next[2] = chain_next[3] = 0;
+            if (tile == 0) chain_next[0] = chain_next[1] = chain_next[2] = 0;  // (word 3 is the host's)
         }
 #if CRP_PRIO_UNTIL_PUBLISH == 1
         __builtin_amdgcn_s_setprio(0);

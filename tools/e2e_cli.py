@@ -73,7 +73,8 @@ def main():
         os.remove(fa)
         return
     from cropsr_amd import cli
-    args = cli.build_parser().parse_args(argv)
+    stages_json = os.path.join(tmp, "stages.json")
+    args = cli.build_parser().parse_args(argv + ["--bench-json", stages_json])
     os.chdir(tmp)
     sink = io.StringIO()
     prof = cProfile.Profile() if a.profile else None
@@ -89,7 +90,7 @@ def main():
         rows = sum(chunk.count(b"\n") for chunk in iter(lambda: f.read(1 << 24), b"")) - 1
     print(json.dumps({"workload": wl.name, "bases": wl.n_bases, "rows": rows, "csv_bytes": size,
                       "fasta_write_s": round(t_gen, 2), "cli_wall_s": round(wall, 3),
-                      "rows_per_s": round(rows / wall), "phases": getattr(cli, "LAST_PHASES", None)}))
+                      "rows_per_s": round(rows / wall), "phases": json.load(open(stages_json))}))
     if prof:
         s = io.StringIO()
         pstats.Stats(prof, stream=s).sort_stats("cumulative").print_stats(30)
