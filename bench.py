@@ -16,7 +16,10 @@ collective on the data path; the path's one exchange -- the FINAL RCCL gatherv o
 tables to rank 0 (crp_gather_hits) -- runs once after the timed steps and is reported on its own
 (`gatherv`), together with the rate that includes it (`value_with_final_gatherv`).
 --gather-every-step puts it inside every step instead.  A failed exchange still prints the line
-(`gatherv_ok: false`) and then exits non-zero.
+(`gatherv_ok: false`) and then exits non-zero.  If the RCCL communicator cannot be CREATED (every rank
+learns that together, before any collective), the measurement still runs -- the scan needs no
+collective -- with the control sockets as fence and the host transport for the final exchange; the
+line then carries `rccl_error` and names the transport in `config.parallelism`, and stderr says so.
 Workload at N = 1: the >= 1 Gb crop genome BASELINE.json's target is quoted on
 ("switchgrass-like", SURVEY.md 8d cfg 5, seeded synthetic).  Weak scaling: N ranks
 process N such genomes (seeds 0..N-1), contigs dealt to ranks by LPT.
@@ -153,14 +156,26 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     local_rank = 0 if args.share_gpu0 else (group.local_rank if group else 0)
     # (CROPSR_BENCH_FORCE_RCCL=1 with --share-gpu0 asks RCCL for a communicator of ranks that share a GPU, which it
-    # refuses: a way to see the failure path -- every rank exits non-zero with the same message -- on a one-GPU box)
+    # refuses: a way to see, on a one-GPU box, what happens when the communicator cannot be created -- below)
     use_rccl = world > 1 and (not args.share_gpu0 or os.environ.get("CROPSR_BENCH_FORCE_RCCL") == "1")
 
     eng = Engine(local_rank)  # raises without libcropsr_hip.so / GPU: no fallback
     if args.two_pass:
         eng.configure(two_pass=True)
+    rccl_error = None
     if use_rccl:
-        eng.comm_init(group)  # RCCL communicator inside the library; the id travels over the control sockets
+        from cropsr_amd import rendezvous
+        try:
+            eng.comm_init(group)  # RCCL communicator inside the library; the id travels over the control sockets
+        except rendezvous.RankError as e:
+            # Every rank has the same error (comm_init agrees on it before anyone proceeds).  The scan itself needs no
+            # collective, so the measurement goes on with the control sockets as fence and host transport for the
+            # final exchange; the line says so (`rccl_error`, `parallelism`) and stderr says it loudly.
+            rccl_error = str(e)[:500]
+            nat.lib().crp_comm_destroy(eng._ctx)
+            use_rccl = False
+            sys.stderr.write("[bench rank %d] RCCL communicator unavailable, falling back to the host transport "
+                             "for fences and the final gatherv: %s\n" % (rank, rccl_error))
 
     # ---- workload: `world` genomes, contigs dealt to ranks by LPT (weak scaling)
     genomes = [make_workload(args.workload, g, args.scale) for g in range(world)]
@@ -260,7 +275,9 @@ def main():
 
     # ---- the opt-in off-target seed scan of cfg 5 on the same resident genome and hit tables
     ot = None
-    if args.offtarget_steps > 0 and not (gather_info and "error" in gather_info):
+    if args.offtarget_steps > 0 and rccl_error and world > 1:
+        ot = {"skipped": "the site histogram is summed over the ranks by an RCCL all-reduce, and RCCL is unavailable here"}
+    elif args.offtarget_steps > 0 and not (gather_info and "error" in gather_info):
         try:
             def ot_step():
                 eng.offtarget_reset()
@@ -355,6 +372,8 @@ def main():
             "pcie_inclusive": {"upload_pack_s": t_upload, "fetch_tables_s": t_fetch,
                                "gRNAs_per_s": scored / (t_upload + dt / args.steps + t_fetch)},
         }
+        if rccl_error:
+            line["rccl_error"] = rccl_error
         if ot is not None:
             if facts and "roofline" in ot:
                 ot["roofline"]["traffic"] = facts.get("offtarget_ball_hbm_bytes_per_step")
