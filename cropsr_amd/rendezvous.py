@@ -19,7 +19,10 @@ crp_offtarget_reduce).  This module is the small CONTROL plane around it:
     several ranks on one GPU, where RCCL cannot run.
 
 Star topology through rank 0; every operation is a collective that all ranks
-call in the same order.  Messages: 8-byte length + pickle (arrays: raw bytes).
+call in the same order.  Messages: 8-byte length + pickle (arrays: raw bytes),
+read back with an unpickler that builds plain containers, numbers, strings and
+numpy arrays only.  Rank 0 listens on 127.0.0.1 and admits only clients that
+present the run's random token (published in the 0600 rendezvous file).
 
 A second connection per rank is the ABORT channel, watched by a daemon thread: a
 rank that dies (its sockets close) or calls Group.abort(msg) makes every other
@@ -67,6 +70,28 @@ def _recv_msg(sock):
     return _recv_exact(sock, n)
 
 
+# What may come out of a message: plain containers, numbers, strings, bytes -- and numpy arrays of them.
+# Nothing else is ever sent, so nothing else is ever built from bytes read off a socket.
+_ALLOWED_GLOBALS = {
+    ("numpy", "ndarray"), ("numpy", "dtype"),
+    ("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"),
+    ("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "scalar"),
+    ("numpy.core.numeric", "_frombuffer"), ("numpy._core.numeric", "_frombuffer"),
+}
+
+
+class _Unpickler(pickle.Unpickler):
+    def find_class(self, module, name):
+        if (module, name) in _ALLOWED_GLOBALS:
+            return super().find_class(module, name)
+        raise pickle.UnpicklingError("control message names %s.%s: refused" % (module, name))
+
+
+def _loads(data):
+    import io
+    return _Unpickler(io.BytesIO(bytes(data))).load()
+
+
 LAST_GROUP = None  # the most recent multi-rank Group of this process (for top-level abort handlers)
 
 
@@ -86,6 +111,9 @@ class Group:
         self._closing = False
         self._listener = None
         self._file = None
+        # a run's clients prove they belong to it: rank 0 draws a token and publishes it in the rendezvous file
+        # (mode 0600); with an explicit endpoint there is no file, and the token is CROPSR_RDZV_TOKEN (or empty)
+        self._token = os.environ.get("CROPSR_RDZV_TOKEN", "")
         if self.world == 1:
             return
         if self.rank == 0:
@@ -100,18 +128,28 @@ class Group:
             self._listener.settimeout(_CONNECT_TIMEOUT_S)
             if not endpoint:
                 host, port = self._listener.getsockname()
+                if not self._token:
+                    self._token = os.urandom(16).hex()
                 tmp = rdzv_file + ".%d.tmp" % os.getpid()
-                with open(tmp, "w") as f:
-                    json.dump({"host": host, "port": port, "world": self.world, "pid": os.getpid()}, f)
+                with open(os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o600), "w") as f:
+                    json.dump({"host": host, "port": port, "world": self.world, "pid": os.getpid(), "token": self._token}, f)
                 os.replace(tmp, rdzv_file)  # atomic: a reader never sees half a file
                 self._file = rdzv_file
             while len(self._peers) < self.world - 1 or len(self._abort_peers) < self.world - 1:
                 conn, _ = self._listener.accept()
                 conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                conn.settimeout(5.0)  # a client that says nothing must not hold up the others
+                try:
+                    hello = _loads(_recv_msg(conn))
+                except Exception:
+                    hello = None
                 conn.settimeout(_TIMEOUT_S)
-                hello = pickle.loads(_recv_msg(conn))
+                if not isinstance(hello, dict):
+                    conn.close()  # not one of ours
+                    continue
                 table = self._abort_peers if hello.get("abort") else self._peers
-                if hello.get("world") != self.world or hello.get("rank") in table or not 0 < hello.get("rank", 0) < self.world:
+                if hello.get("world") != self.world or hello.get("rank") in table or not 0 < hello.get("rank", 0) < self.world \
+                        or hello.get("token") != self._token:
                     conn.close()  # a stray client of another run
                     continue
                 table[hello["rank"]] = conn
@@ -131,15 +169,16 @@ class Group:
                         if info.get("world") != self.world:
                             raise OSError("stale rendezvous file")
                         host, port = info["host"], info["port"]
+                        self._token = info.get("token", "")
                     s = socket.create_connection((host, int(port)), timeout=5)
                     s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
                     s.settimeout(_TIMEOUT_S)
-                    _send_msg(s, pickle.dumps({"rank": self.rank, "world": self.world}))
+                    _send_msg(s, pickle.dumps({"rank": self.rank, "world": self.world, "token": self._token}))
                     a = socket.create_connection((host, int(port)), timeout=5)
                     a.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
                     a.settimeout(_TIMEOUT_S)
-                    _send_msg(a, pickle.dumps({"rank": self.rank, "world": self.world, "abort": True}))
-                    if pickle.loads(_recv_msg(s)) != "welcome":
+                    _send_msg(a, pickle.dumps({"rank": self.rank, "world": self.world, "abort": True, "token": self._token}))
+                    if _loads(_recv_msg(s)) != "welcome":
                         raise OSError("unexpected greeting")
                     a.settimeout(None)
                     self._hub, self._abort_hub = s, a
@@ -168,7 +207,7 @@ class Group:
                     for s in ready:
                         try:
                             msg = _recv_msg(s)
-                            why = "rank %d: %s" % (socks[s], pickle.loads(msg))
+                            why = "rank %d: %s" % (socks[s], _loads(msg))
                         except Exception:
                             why = "rank %d died (its connection closed)" % socks[s]
                         if self._closing:
@@ -182,7 +221,7 @@ class Group:
                         self._die(why)
             else:
                 try:
-                    why = pickle.loads(_recv_msg(self._abort_hub))
+                    why = _loads(_recv_msg(self._abort_hub))
                 except Exception:
                     why = "rank 0 died (its connection closed)"
                 if not self._closing:
@@ -253,13 +292,13 @@ class Group:
         if self.rank == 0:
             objs = [obj] + [None] * (self.world - 1)
             for r, s in self._peers.items():
-                objs[r] = pickle.loads(_recv_msg(s))
+                objs[r] = _loads(_recv_msg(s))
             blob = pickle.dumps(objs)
             for s in self._peers.values():
                 _send_msg(s, blob)
             return objs
         _send_msg(self._hub, pickle.dumps(obj))
-        return pickle.loads(_recv_msg(self._hub))
+        return _loads(_recv_msg(self._hub))
 
     def bcast(self, obj, src=0):
         return self.all_gather(obj if self.rank == src else None)[src]
@@ -294,6 +333,6 @@ class Group:
     def recv_array(self, src):
         """rank 0: the array rank `src` sent."""
         s = self._peers[src]
-        dtype, shape = pickle.loads(_recv_msg(s))
+        dtype, shape = _loads(_recv_msg(s))
         raw = _recv_msg(s)
         return np.frombuffer(raw, dtype=np.dtype(dtype)).reshape(shape)

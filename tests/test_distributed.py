@@ -298,3 +298,58 @@ def test_a_dead_or_aborting_rank_takes_every_rank_down_quickly(tmp_path):
     assert codes == [3, 3, 3], codes
     assert time.time() - t0 < 25 and time.time() - t1 < 15
     assert not any(f.startswith("rank") and open(tmp_path / f).read() == "survived" for f in os.listdir(tmp_path))
+
+
+def test_rendezvous_refuses_strangers(tmp_path):
+    """Rank 0 admits only clients that present the run's token, survives garbage on its port, and never builds
+    anything but plain data from what it reads off a socket."""
+    import json
+    import pickle
+    import struct
+    import threading
+    import time as _time
+    from cropsr_amd import rendezvous as rz
+
+    with pytest.raises(pickle.UnpicklingError):
+        rz._loads(pickle.dumps(os.system))  # a global that is not on the list
+    a = np.arange(5, dtype=np.uint64)
+    back = rz._loads(pickle.dumps((a, {"k": [1, 2.5, None, b"x"]})))
+    assert np.array_equal(back[0], a) and back[1] == {"k": [1, 2.5, None, b"x"]}
+
+    path = str(tmp_path / "rdzv.json")
+    groups = {}
+
+    def hub():
+        groups[0] = rz.Group(0, 2, 0, None, path)
+
+    t = threading.Thread(target=hub, daemon=True)
+    t.start()
+    for _ in range(200):
+        if os.path.exists(path):
+            break
+        _time.sleep(0.02)
+    info = json.load(open(path))
+    assert oct(os.stat(path).st_mode & 0o777) == "0o600" and len(info["token"]) == 32
+    # garbage, then a well-formed hello with the wrong token: both are dropped, the hub keeps listening
+    s = socket.create_connection((info["host"], info["port"]))
+    s.sendall(struct.pack("<Q", 5) + b"hello")
+    s.close()
+    s = socket.create_connection((info["host"], info["port"]))
+    blob = pickle.dumps({"rank": 1, "world": 2, "token": "0" * 32})
+    s.sendall(struct.pack("<Q", len(blob)) + blob)
+    _time.sleep(0.2)
+    assert 0 not in groups  # still waiting for the real rank 1
+    groups[1] = rz.Group(1, 2, 1, None, path)
+    t.join(10)
+    assert 0 in groups
+    res = {}
+    th = threading.Thread(target=lambda: res.setdefault(0, groups[0].all_gather("a")), daemon=True)
+    th.start()
+    assert groups[1].all_gather("b") == ["a", "b"]
+    th.join(10)
+    assert res[0] == ["a", "b"]
+    tc = threading.Thread(target=groups[0].close, daemon=True)
+    tc.start()
+    groups[1].close()
+    tc.join(10)
+    s.close()
