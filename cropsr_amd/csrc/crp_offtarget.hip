@@ -41,14 +41,16 @@ constexpr uint32_t OT_SEEDS = 1u << (2 * CRP_OT_SEED_LEN);  // 4^12
 constexpr uint32_t OT_NOT_A_SITE = 0xffffffffu;
 constexpr uint32_t OT_NOT_OWNED = 0xfffffffeu;
 
-// 12 consecutive arena positions starting at q, from one bit-plane
+// 12 consecutive arena positions starting at q, from one bit-plane: ONE unaligned 32-bit load at the byte the
+// window starts in (12 + 7 bits; gfx950 serves unaligned global loads) instead of one or two aligned 64-bit words.
+// (The bytes behind a window always exist: an arena ends in void padding words.)
+struct __attribute__((packed)) UnalignedU32 {
+    uint32_t v;
+};
 __device__ __forceinline__ uint32_t window12(const uint64_t *plane, uint64_t q)
 {
-    const uint64_t w = q >> 6;
-    const uint32_t sh = (uint32_t)q & 63u;
-    uint64_t v = plane[w] >> sh;
-    if (sh > 52) v |= plane[w + 1] << (64 - sh);
-    return (uint32_t)v & 0xfffu;
+    const uint32_t v = reinterpret_cast<const UnalignedU32 *>(reinterpret_cast<const uint8_t *>(plane) + (q >> 3))->v;
+    return (v >> ((uint32_t)q & 7u)) & 0xfffu;
 }
 
 // bit k of x -> bit 2k
@@ -111,8 +113,8 @@ __device__ __forceinline__ uint32_t seed_of_windows(uint32_t h, uint32_t w, uint
     return (spread12(h) << 1) | spread12(w);
 }
 
-// (Staging each round's stretch of the planes through LDS -- coalesced copies, windows cut from LDS -- was measured:
-// 2 x 0.34 ms instead of 2 x 0.29, the two extra barriers per round cost more than the divergent loads.)
+// (Staging each round's stretch of the planes through LDS -- coalesced copies, windows cut from LDS -- was measured
+// slower than divergent loads: two extra barriers per round.  What helped is window12's single unaligned load.)
 template <bool MINUS>
 __global__ __launch_bounds__(BLOCK) void ot_seed_kernel(Planes pl, const uint32_t *__restrict__ pos, uint64_t n,
                                                          const uint64_t *__restrict__ own, uint32_t n_own,
