@@ -23,7 +23,7 @@ constexpr int BLOCK = 256;     // threads per workgroup (4 wavefronts of 64)
 #define CRP_LB_FIRST 0
 #endif
 #ifndef CRP_NT_STORES
-#define CRP_NT_STORES 0  // hit-table stores with the non-temporal hint
+#define CRP_NT_STORES 1  // hit-table stores with the non-temporal hint: -1 % (0.470 vs 0.475 ms at steady clocks)
 #endif
 #ifndef CRP_ROTATE_WAVES
 #define CRP_ROTATE_WAVES 1  // single-launch mode: wave 0 (which also resolves the prefix) owns the last chunk of every four

@@ -15,7 +15,9 @@ RAW=gpurun_out/prof_$TAG
 OUT=gpurun_out/profiles_$TAG
 rm -rf "$RAW" "$OUT"
 mkdir -p "$RAW" "$OUT"
-BENCH="python3 bench.py --steps 10 --warmup 2 --cpu-sample-bases 0 --offtarget-steps 3"
+# 300 timed steps: rocprofv3's per-kernel AVERAGE is over every launch of the process, and the ~100 untimed launches
+# in front of the timed region include the ones that bring the clocks up (bench.py --preheat-ms)
+BENCH="python3 bench.py --steps 300 --warmup 2 --cpu-sample-bases 0 --offtarget-steps 3"
 
 rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/trace -- $BENCH > $OUT/bench_under_trace.json 2> $RAW/trace.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $RAW/fetch -- $BENCH > /dev/null 2> $RAW/fetch.err
