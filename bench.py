@@ -20,6 +20,10 @@ tables to rank 0 (crp_gather_hits) -- runs once after the timed steps and is rep
 learns that together, before any collective), the measurement still runs -- the scan needs no
 collective -- with the control sockets as fence and the host transport for the final exchange; the
 line then carries `rccl_error` and names the transport in `config.parallelism`, and stderr says so.
+The W warm-up steps run immediately before the timed region and are followed by further untimed steps
+until --preheat-ms (60) have passed: the GPU's clocks drop during the side measurements that precede
+them (a 0.6 GB copy of the tables to the host), and K = 20 steps of 0.5 ms are over before they are
+back up.  `untimed_steps_before` reports how many steps ran untimed in all.
 Workload at N = 1: the >= 1 Gb crop genome BASELINE.json's target is quoted on
 ("switchgrass-like", SURVEY.md 8d cfg 5, seeded synthetic).  Weak scaling: N ranks
 process N such genomes (seeds 0..N-1), contigs dealt to ranks by LPT.
