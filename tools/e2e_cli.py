@@ -40,6 +40,8 @@ def main():
                     help="run the CLI as that many processes under torch.distributed.run (the launcher only; all on "
                          "device 0, tables over the host transport: a rehearsal of the multi-GPU mode on a one-GPU box)")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--cli-flag", action="append", default=[], metavar="FLAG",
+                    help="extra flag for the CLI, e.g. --cli-flag=--offtarget (repeatable)")
     a = ap.parse_args()
     import bench_workload as bw
     name, _, scale = a.workload.partition(":")
@@ -57,6 +59,7 @@ def main():
     argv = ["-f", fa, "-g", gff, "-o", out_csv, "--cas9", "--seed", "1"]
     if not a.reference_behaviour:
         argv.append("--each-contig-once")
+    argv += a.cli_flag
     if a.procs > 1:
         import subprocess
         env = dict(os.environ, CROPSR_GATHER="host", PYTHONPATH=ROOT)  # all ranks on device 0: RCCL cannot run
