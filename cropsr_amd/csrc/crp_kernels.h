@@ -80,7 +80,12 @@ constexpr int BLOCK = 256;     // threads per workgroup (4 wavefronts of 64)
 #define CRP_TILE_WPT 2
 #endif
 #ifndef CRP_LIST_CAP_PER_WPT
-#define CRP_LIST_CAP_PER_WPT 1024  // LDS hit-list entries per round and per word-per-thread
+// LDS hit-list entries per round and per word-per-thread.  2 x 1344 = 2688 entries: the most that leaves the workgroup
+// (31.6 KB of LDS) at five per CU with some margin -- 2 x 1472 no longer fits five.  A tile with more kept hits than the
+// list holds pays a second list build; on the bench genome (1 520 hits per tile on average, soft-masked runs of ~2 kb)
+// 2 048 entries left about one tile in six in that state: 0.468 -> 0.457 ms.  Unmasked genomes (TAIR10-like: 2 100 per
+// tile) gain more.
+#define CRP_LIST_CAP_PER_WPT 1344
 #endif
 #ifndef CRP_EMIT_BLOCK
 #define CRP_EMIT_BLOCK 256
