@@ -73,6 +73,9 @@ constexpr int BLOCK = 256;     // threads per workgroup (4 wavefronts of 64)
 // bit peeling runs over items (no lane idles on an empty half); 0 = every lane peels its own halves
 #define CRP_LIST_COMPACT 0
 #endif
+#ifndef CRP_LIST_BY_STRAND
+#define CRP_LIST_BY_STRAND 1  // a tile whose hits overflow the list but fit it strand by strand takes one round per strand
+#endif
 #ifndef CRP_LIST_FASTPATH
 #define CRP_LIST_FASTPATH 1  // hit-list build without the capacity test when the tile's hits all fit
 #endif

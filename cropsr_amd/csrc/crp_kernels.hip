@@ -769,13 +769,20 @@ __device__ __forceinline__ void emit_rounds(uint64_t (*sh)[TW + 2], uint16_t *li
     const int tid = threadIdx.x;
     const uint32_t n_all = n_plus + n_minus;
     bool resolved = !CHAINED;  // single pass: this lane has not picked up off_plus / off_minus yet
-    for (uint32_t lo_rank = 0; lo_rank < n_all; lo_rank += CAP) {
+    // A tile with more kept hits than the list holds takes several rounds.  When each STRAND's hits fit (the usual
+    // overflow: an unmasked tile of a GC-rich genome has ~1 700 + 1 700 of them), the rounds are the two strands:
+    // each round peels only its own strand's masks, without capacity tests -- one list build's work in all, not two.
+    const bool by_strand = CRP_LIST_BY_STRAND && n_all > (uint32_t)CAP && n_plus <= (uint32_t)CAP && n_minus <= (uint32_t)CAP;
+    uint32_t hi_rank = 0;
+    for (uint32_t lo_rank = 0; lo_rank < n_all; lo_rank = hi_rank) {
+        hi_rank = by_strand ? (lo_rank == 0 ? n_plus : n_all) : min(lo_rank + (uint32_t)CAP, n_all);
         if (lo_rank) __syncthreads();  // previous round's readers are done
         // ---- compact: rank -> tile-local position, '+' hits first, then '-'
         // A tile whose hits all fit the list (the normal case; uniform over the workgroup) writes
         // without the per-entry capacity test.
-        auto compact = [&](auto check) {
+        auto compact = [&](auto check, auto with_plus, auto with_minus) {
             constexpr bool CHECK = decltype(check)::value;
+            constexpr bool PLUS = decltype(with_plus)::value, MINUS = decltype(with_minus)::value;
             uint32_t rp = (uint32_t)ex - lo_rank;                    // rank of next '+' hit, window-relative
             uint32_t rm = n_plus + (uint32_t)(ex >> 32) - lo_rank;  // same for '-'
 #pragma unroll
@@ -783,24 +790,28 @@ __device__ __forceinline__ void emit_rounds(uint64_t (*sh)[TW + 2], uint16_t *li
                 const uint32_t wbase = (uint32_t)(tid * WPT + k) * 64u;
                 // 32-bit halves: find-first-bit, clear-lowest and the compare are one
                 // VALU instruction each instead of two
+                if (PLUS) {
 #pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    uint32_t m = (uint32_t)(mp[k] >> (32 * half));
-                    while (m) {
-                        const uint32_t b = __builtin_ctz(m);
-                        m &= m - 1;
-                        if (!CHECK || rp < (uint32_t)CAP) list[rp] = (uint16_t)(wbase + 32 * half + b);
-                        ++rp;
+                    for (int half = 0; half < 2; ++half) {
+                        uint32_t m = (uint32_t)(mp[k] >> (32 * half));
+                        while (m) {
+                            const uint32_t b = __builtin_ctz(m);
+                            m &= m - 1;
+                            if (!CHECK || rp < (uint32_t)CAP) list[rp] = (uint16_t)(wbase + 32 * half + b);
+                            ++rp;
+                        }
                     }
                 }
+                if (MINUS) {
 #pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    uint32_t m = (uint32_t)(mm[k] >> (32 * half));
-                    while (m) {
-                        const uint32_t b = __builtin_ctz(m);
-                        m &= m - 1;
-                        if (!CHECK || rm < (uint32_t)CAP) list[rm] = (uint16_t)(wbase + 32 * half + b);
-                        ++rm;
+                    for (int half = 0; half < 2; ++half) {
+                        uint32_t m = (uint32_t)(mm[k] >> (32 * half));
+                        while (m) {
+                            const uint32_t b = __builtin_ctz(m);
+                            m &= m - 1;
+                            if (!CHECK || rm < (uint32_t)CAP) list[rm] = (uint16_t)(wbase + 32 * half + b);
+                            ++rm;
+                        }
                     }
                 }
             }
@@ -856,12 +867,14 @@ __device__ __forceinline__ void emit_rounds(uint64_t (*sh)[TW + 2], uint16_t *li
             }
         };
         if (n_all <= (uint32_t)CAP) compact_balanced();
-        else compact(std::true_type{});
+        else compact(std::true_type{}, std::true_type{}, std::true_type{});
 #elif CRP_LIST_FASTPATH
-        if (n_all <= (uint32_t)CAP) compact(std::false_type{});
-        else compact(std::true_type{});
+        if (n_all <= (uint32_t)CAP) compact(std::false_type{}, std::true_type{}, std::true_type{});
+        else if (by_strand && lo_rank == 0) compact(std::false_type{}, std::true_type{}, std::false_type{});
+        else if (by_strand) compact(std::false_type{}, std::false_type{}, std::true_type{});
+        else compact(std::true_type{}, std::true_type{}, std::true_type{});
 #else
-        compact(std::true_type{});
+        compact(std::true_type{}, std::true_type{}, std::true_type{});
 #endif
         if (CHAINED && tid == 0) *ch.s_next = 0;  // chunk counter of this round (read after the barrier below)
 #if CRP_EXPERIMENT_STOP == 2  // TIMING ONLY: ... + the hit list
@@ -877,7 +890,7 @@ __device__ __forceinline__ void emit_rounds(uint64_t (*sh)[TW + 2], uint16_t *li
         }
 #endif
         // ---- one hit per lane: extract the 30-window, score, store
-        const uint32_t n_round = min((uint32_t)CAP, n_all - lo_rank);
+        const uint32_t n_round = hi_rank - lo_rank;
         struct Hit {
             uint32_t e, r;
             double pre, score;
