@@ -31,6 +31,15 @@ def write_fasta(workload, path, width=60):
                 f.write(a[full:].tobytes() + b"\n")
 
 
+def file_md5(path):
+    import hashlib
+    h = hashlib.md5()
+    with open(path, "rb") as f:
+        for chunk in iter(lambda: f.read(1 << 24), b""):
+            h.update(chunk)
+    return h.hexdigest()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("workload")
@@ -40,6 +49,7 @@ def main():
                     help="run the CLI as that many processes under torch.distributed.run (the launcher only; all on "
                          "device 0, tables over the host transport: a rehearsal of the multi-GPU mode on a one-GPU box)")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--md5", action="store_true", help="print the CSV's md5 (to compare runs with different --procs)")
     ap.add_argument("--cli-flag", action="append", default=[], metavar="FLAG",
                     help="extra flag for the CLI, e.g. --cli-flag=--offtarget (repeatable)")
     a = ap.parse_args()
@@ -71,7 +81,8 @@ def main():
         if p.returncode != 0:
             sys.exit(p.stderr[-3000:])
         size = os.path.getsize(out_csv)
-        print(json.dumps({"workload": wl.name, "procs": a.procs, "csv_bytes": size, "wall_incl_process_start_s": round(wall, 3)}))
+        print(json.dumps({"workload": wl.name, "procs": a.procs, "csv_bytes": size, "wall_incl_process_start_s": round(wall, 3),
+                          "md5": file_md5(out_csv) if a.md5 else None}))
         os.remove(out_csv)
         os.remove(fa)
         return
@@ -93,7 +104,8 @@ def main():
         rows = sum(chunk.count(b"\n") for chunk in iter(lambda: f.read(1 << 24), b"")) - 1
     print(json.dumps({"workload": wl.name, "bases": wl.n_bases, "rows": rows, "csv_bytes": size,
                       "fasta_write_s": round(t_gen, 2), "cli_wall_s": round(wall, 3),
-                      "rows_per_s": round(rows / wall), "phases": json.load(open(stages_json))}))
+                      "rows_per_s": round(rows / wall), "phases": json.load(open(stages_json)),
+                      "md5": file_md5(out_csv) if a.md5 else None}))
     if prof:
         s = io.StringIO()
         pstats.Stats(prof, stream=s).sort_stats("cumulative").print_stats(30)
