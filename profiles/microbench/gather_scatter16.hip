@@ -51,6 +51,26 @@ __global__ __launch_bounds__(256) void gather16(const uint32_t *__restrict__ idx
     for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) out[i] = table[idx[i]];
 }
 
+// the same gather from a table of 8-byte entries (four 16-bit counts), widened to 16 bytes on the way out
+__global__ __launch_bounds__(256) void gather8(const uint32_t *__restrict__ idx, uint64_t n, const uint2 *__restrict__ table,
+                                               uint4 *__restrict__ out)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+        const uint2 v = table[idx[i]];
+        out[i] = make_uint4(v.x & 0xffffu, v.x >> 16, v.y & 0xffffu, v.y >> 16);
+    }
+}
+
+// ... and from 4-byte entries
+__global__ __launch_bounds__(256) void gather4(const uint32_t *__restrict__ idx, uint64_t n, const uint32_t *__restrict__ table,
+                                               uint4 *__restrict__ out)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+        const uint32_t v = table[idx[i]];
+        out[i] = make_uint4(v & 0xffu, (v >> 8) & 0xffu, (v >> 16) & 0xffu, v >> 24);
+    }
+}
+
 __global__ __launch_bounds__(256) void scatter16(const uint32_t *__restrict__ dst, uint64_t n, uint4 *__restrict__ out)
 {
     for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
@@ -101,9 +121,14 @@ int main()
     CHECK(hipDeviceSynchronize());
     const int grid = 16384;
     const float g = time_ms([&] { hipLaunchKernelGGL(gather16, dim3(grid), dim3(256), 0, 0, idx, n, table, out); }, 20);
+    const float g8 = time_ms(
+        [&] { hipLaunchKernelGGL(gather8, dim3(grid), dim3(256), 0, 0, idx, n, reinterpret_cast<const uint2 *>(table), out); }, 20);
+    const float g4 = time_ms(
+        [&] { hipLaunchKernelGGL(gather4, dim3(grid), dim3(256), 0, 0, idx, n, reinterpret_cast<const uint32_t *>(table), out); }, 20);
     const float s = time_ms([&] { hipLaunchKernelGGL(scatter16, dim3(grid), dim3(256), 0, 0, perm, n, out); }, 20);
     const float t = time_ms([&] { hipLaunchKernelGGL(scatter16_nt, dim3(grid), dim3(256), 0, 0, perm, n, out); }, 20);
-    printf("{\"items\": %llu, \"gather16_ms\": %.4f, \"scatter16_ms\": %.4f, \"scatter16_nontemporal_ms\": %.4f}\n",
-           (unsigned long long)n, g, s, t);
+    printf("{\"items\": %llu, \"gather16_ms\": %.4f, \"gather8_ms\": %.4f, \"gather4_ms\": %.4f, \"scatter16_ms\": %.4f, "
+           "\"scatter16_nontemporal_ms\": %.4f}\n",
+           (unsigned long long)n, g, g8, g4, s, t);
     return 0;
 }
