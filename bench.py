@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- gRNAs scored / s of the MI355X PAM-scan + score path.
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1: starts its N ranks itself, cropsr_amd/launch.py)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -14,7 +14,9 @@ count -> tile scan -> emit+score launch sequence instead) over the rank's arena,
 genome already resident in HBM.  Contigs are independent, so at N > 1 the steps run with NO
 collective on the data path; the path's one exchange -- the FINAL RCCL gatherv of the per-rank hit
 tables to rank 0 (crp_gather_hits) -- runs once after the timed steps and is reported on its own
-(`gatherv`), together with the rate that includes it (`value_with_final_gatherv`).
+(`gatherv`), together with the whole-job rate that includes it (`value_with_final_gatherv` = gRNAs of all
+ranks / (one step + the one exchange): the number a scaling curve should be built from, since `value`'s
+steps hold no collective; `per_rank` lists every rank's kernel time and share).
 --gather-every-step puts it inside every step instead.  A failed exchange still prints the line
 (`gatherv_ok: false`) and then exits non-zero.  If the RCCL communicator cannot be CREATED (every rank
 learns that together, before any collective), the measurement still runs -- the scan needs no
@@ -65,6 +67,8 @@ def parse_args():
     ap.add_argument("--share-gpu0", action="store_true",
                     help="rehearsal only: every rank uses device 0; fences and sums go over the control sockets and "
                          "the gatherv over the host transport (RCCL cannot put two ranks on one GPU)")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0,
+                    help="--gpus N without a launcher: stop the self-started ranks after this many seconds")
     ap.add_argument("--offtarget-steps", type=int, default=5,
                     help="timed steps of the off-target seed scan (0 = skip that block)")
     ap.add_argument("--cpu-sample-bases", type=int, default=40000000,
@@ -151,6 +155,16 @@ def load_profile_facts(build_id, workload):
 
 def main():
     args = parse_args()
+    from cropsr_amd import launch
+    if launch.wanted(args.gpus):
+        # `python bench.py --gpus N` with no launcher in the environment: this process -- which has not
+        # touched HIP or RCCL and never will -- starts the N ranks as fresh child processes of the same
+        # command line, lets rank 0's JSON line through (inherited stdout) and leaves with a status that is 0
+        # only if every rank's was (cropsr_amd/launch.py).  Under torch.distributed.run WORLD_SIZE is set
+        # and this branch is not taken.
+        sys.stdout.flush()
+        sys.exit(launch.spawn_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus,
+                                    timeout_s=args.launch_timeout))
     import numpy as np
 
     from cropsr_amd import Engine, parallel, rendezvous
@@ -281,6 +295,11 @@ def main():
 
     dt = reduce([dt], "max")[0]
     scored_all, bases_all, hits_all = reduce([scored, my_bases, n_plus + n_minus], "sum")
+    # every rank's own view of the timed region, for the line (control sockets: a few numbers per rank)
+    my_emit = prof["emit_score"]
+    mine_report = {"rank": rank, "device": local_rank, "kernel_ms": my_emit["ms"] / max(1, my_emit["launches"]),
+                   "bases": int(my_bases), "kept_hits": int(n_plus + n_minus), "gRNAs_scored": int(scored)}
+    per_rank = group.all_gather(mine_report) if group else [mine_report]
 
     # the final exchange, once, timed on its own (barrier + sync on both sides, max over ranks)
     gather_info = None
@@ -391,6 +410,7 @@ def main():
                                                     ("every step" if args.gather_every_step else "once, after the steps"))),
                        "device": info["name"].strip(), "library_build": build_id},
             "bases_per_s": bases_all * args.steps / dt,
+            "per_rank": per_rank,
             "roofline": roof,
             "setup_s": {"generate_pack_upload": t_gen},
             # host-buffer boundary: characters H2D + pack, one scan, tables D2H (never `value`)
@@ -409,7 +429,11 @@ def main():
             if "s" in gather_info:
                 moved = 12.0 * (hits_all - hits)  # bytes that crossed xGMI to rank 0
                 gather_info.update({"bytes_to_root": int(moved), "GB_per_s_into_root": moved / gather_info["s"] / 1e9})
-                line["value_with_final_gatherv"] = scored_all * args.steps / (dt + gather_info["s"])
+                # the WHOLE job of the path at N ranks = one scan on every rank + the one exchange: this, not
+                # `value` (whose timed steps hold no collective and therefore grow ~N-fold by construction),
+                # is the number to build a scaling curve from
+                line["value_with_final_gatherv"] = scored_all / (dt / args.steps + gather_info["s"])
+                line["ms_scan_plus_gatherv"] = (dt / args.steps + gather_info["s"]) * 1e3
             line["gatherv"] = gather_info
         if world == 1 and args.cpu_sample_bases > 0:
             from oracle import oracle as _o

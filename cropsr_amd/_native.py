@@ -88,6 +88,9 @@ ABI_VERSION = 2
 CRP_ERR_NO_DEVICE = -2
 CRP_ERR_IO = -8
 CRP_ERR_COMM = -9
+CRP_ERR_NOMEM, CRP_ERR_STATE, CRP_ERR_PEER = -4, -5, -10
+# what crp_gather_hits returns on EVERY rank together (agreed on before the exchange starts)
+AGREED_GATHER_ERRORS = (CRP_ERR_NOMEM, CRP_ERR_STATE, CRP_ERR_PEER)
 
 _lib = None
 

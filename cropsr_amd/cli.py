@@ -60,6 +60,10 @@ def build_parser():
     eng = p.add_argument_group("MI355X engine")
     eng.add_argument("--device", type=int, default=None,
                      help="HIP device index, default = 0 (LOCAL_RANK under torch.distributed.run)")
+    eng.add_argument("--gpus", type=int, default=1,
+                     help="run on this many GPUs of the node, one process per GPU: contigs (cut where longer than a "
+                          "GPU's share) are scanned in parallel and the hit tables gathered to the first one over RCCL; "
+                          "the ranks are started here unless a launcher (torch.distributed.run) already did")
     eng.add_argument("--seed", type=int, default=None,
                      help="seed numpy's global RNG so crispr_id is reproducible (reference: unseeded)")
     eng.add_argument("--csv-writer", choices=["native", "python"], default="native",
@@ -152,6 +156,7 @@ class EngineResident:
     def gather(self, group, dst, offtarget):
         """[rank][arena] -> column dict on dst.  With want_pre the f64 column carries the pre-sigmoid
         sum (the root finalises the score on its host)."""
+        from . import _native as nat
         from . import parallel
         eng = self.backend.engine
         if self.backend.transport != "rccl":
@@ -164,7 +169,14 @@ class EngineResident:
             err, counts = None, None
             try:
                 counts = eng.gather_hits(arena, dst, offtarget, pre=self.want_pre)
-            except Exception as e:
+            except nat.CropsrHipError as e:
+                # crp_gather_hits agrees on what can fail on one rank BEFORE the tables move (a rank without tables, a
+                # root that cannot size its receive buffers): every rank is back from the same call, so all of them
+                # reach check() below and raise the same RankError.  Anything else (an RCCL or HIP error inside the
+                # exchange) is this rank's alone, its peers may be blocked in ncclSend/Recv: take the run down NOW
+                # (abort channel; exits with status 3) instead of waiting for them in check().
+                if e.status not in nat.AGREED_GATHER_ERRORS:
+                    group.abort("%s: %s" % (type(e).__name__, e))
                 err = "%s: %s" % (type(e).__name__, e)
             group.check(err)
             if group.rank == dst:
@@ -453,6 +465,13 @@ def run(args, backend=None, out=sys.stdout, group=None):
 
 def main(argv=None):
     args = build_parser().parse_args(argv)
+    from . import launch
+    if launch.wanted(getattr(args, "gpus", 1)):
+        # no launcher in the environment: this process (which never touches the GPU) starts the ranks as fresh
+        # children of the same command line and leaves with their status (cropsr_amd/launch.py)
+        sys.stdout.flush()
+        sys.exit(launch.spawn_ranks([sys.executable, "-m", "cropsr_amd"] + list(sys.argv[1:] if argv is None else argv),
+                                    args.gpus))
     try:
         run(args)
     except Exception as e:

@@ -62,6 +62,7 @@ const char *crp_strerror(int status)
         case CRP_ERR_UNSUPPORTED: return "unsupported parameter";
         case CRP_ERR_IO: return "write to the output descriptor failed";
         case CRP_ERR_COMM: return "RCCL error";
+        case CRP_ERR_PEER: return "abandoned on every rank: another rank reported an error before the exchange";
         default: return "unknown status";
     }
 }

@@ -14,9 +14,11 @@
 // created here (rank 0) and carried to the other ranks by the host (cropsr_amd/rendezvous.py).
 #include <dlfcn.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <string>
 #include <vector>
 
 #include <rccl/rccl.h>
@@ -85,9 +87,12 @@ struct crp_comm {
     ncclComm_t comm = nullptr;
     int rank = 0, world = 0;
     // scratch in HBM: counts (2 per rank) and small reductions
-    uint64_t *d_counts = nullptr;  // 2 * world
+    uint64_t *d_counts = nullptr;  // 3 * world {n_plus, n_minus, status} + world (second agreement round)
     double *d_small = nullptr;     // 64 doubles in, 64 out
     std::vector<uint64_t> counts;  // last gather: {n_plus, n_minus} per rank
+    std::vector<uint64_t> raw;     // host copy of d_counts
+    int test_fail = 0;             // test hook, environment CRP_TEST_GATHER_FAIL: 1 = the root's receive buffers
+                                   // "do not fit", 2 = the last rank's arena "has no tables"
     // root's receive side of the last crp_gather_hits: column-wise, peers back to back in rank order
     uint32_t *d_gpos[2] = {nullptr, nullptr};
     double *d_gscore[2] = {nullptr, nullptr};
@@ -188,7 +193,7 @@ int crp_comm_init(crp_ctx *ctx, const uint8_t id[CRP_COMM_ID_BYTES], int rank, i
         crp::comm_release(ctx);
         return CRP_ERR_COMM;
     }
-    hipError_t e = hipMalloc(reinterpret_cast<void **>(&c->d_counts), 2 * (size_t)world * sizeof(uint64_t));
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&c->d_counts), 4 * (size_t)world * sizeof(uint64_t));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->d_small), 128 * sizeof(double));
     if (e != hipSuccess) {
         ctx->last_error = std::string("communicator scratch: ") + hipGetErrorString(e);
@@ -196,6 +201,8 @@ int crp_comm_init(crp_ctx *ctx, const uint8_t id[CRP_COMM_ID_BYTES], int rank, i
         return CRP_ERR_NOMEM;
     }
     c->counts.assign(2 * (size_t)world, 0);
+    c->raw.assign(4 * (size_t)world, 0);
+    if (const char *e = std::getenv("CRP_TEST_GATHER_FAIL")) c->test_fail = std::atoi(e);
     return CRP_OK;
 }
 
@@ -227,47 +234,88 @@ int crp_comm_barrier(crp_ctx *ctx)
     return crp_comm_allreduce_f64(ctx, &one, 1, CRP_REDUCE_SUM);
 }
 
+// Every rank's status word of one agreement round -> this rank's return value: its own error if it has
+// one, CRP_ERR_PEER if only others do, CRP_OK if nobody does.  The same words are seen by every rank (they
+// come out of an all-gather), so all ranks leave the call together and none enters the next collective.
+static int agreed_status(crp_ctx *ctx, const crp_comm *c, const uint64_t *status, size_t stride, int own, const char *what)
+{
+    int first_bad = -1;
+    for (int p = 0; p < c->world; ++p)
+        if (status[(size_t)p * stride] != 0 && first_bad < 0) first_bad = p;
+    if (first_bad < 0) return CRP_OK;
+    if (own != CRP_OK) return own;
+    ctx->last_error = std::string("crp_gather_hits abandoned on every rank: rank ") + std::to_string(first_bad) + " reported '" +
+                      crp_strerror(-(int)status[(size_t)first_bad * stride]) + "' " + what;
+    return CRP_ERR_PEER;
+}
+
 int crp_gather_hits(crp_ctx *ctx, crp_arena *a, int root, int flags, uint64_t *counts_all)
 {
     crp::Range roctx_range("crp: gatherv (RCCL)");
     if (!ctx) return CRP_ERR_INVALID;
     crp_comm *c = ctx->comm;
     if (!c) return CRP_ERR_STATE;
+    // (arguments that are the same on every rank by contract: a bad one fails everywhere alike)
     if (root < 0 || root >= c->world || (flags & ~(CRP_GATHER_OFFTARGET | CRP_GATHER_PRE))) return CRP_ERR_INVALID;
-    if (a && (a->ctx != ctx || !a->have_hits)) return CRP_ERR_STATE;
     const bool send_pre = (flags & CRP_GATHER_PRE) != 0;
-    if (send_pre && a && !a->have_pre) return CRP_ERR_STATE;
     const bool with_ot = (flags & CRP_GATHER_OFFTARGET) != 0;
-    if (with_ot && a && (!ctx->ot_solved || a->ot_epoch != ctx->ot_epoch)) return CRP_ERR_STATE;
+    // What can differ from rank to rank -- the state of this rank's arena, the root's allocation -- is never
+    // answered with an early return: a rank that left here alone would leave its peers inside a collective
+    // that cannot complete.  Each rank's status travels WITH its counts, and everyone acts on all of them.
+    int local = CRP_OK;
+    if (a && (a->ctx != ctx || !a->have_hits)) local = CRP_ERR_STATE;
+    else if (send_pre && a && !a->have_pre) local = CRP_ERR_STATE;
+    else if (with_ot && a && (!ctx->ot_solved || a->ot_epoch != ctx->ot_epoch)) local = CRP_ERR_STATE;
+    if (c->test_fail == 2 && c->rank == c->world - 1) local = CRP_ERR_STATE;  // test hook (CRP_TEST_GATHER_FAIL)
     const Rccl *r = rccl();
     CRP_HIP(ctx, hipSetDevice(ctx->device));
     c->have_gather = false;
-    const uint64_t mine[2] = {a ? a->n_hits[0] : 0, a ? a->n_hits[1] : 0};
-    crp::prof_begin(ctx, CRP_K_GATHER);
-    // 1. everyone learns every rank's two counts
-    CRP_HIP(ctx, hipMemcpyAsync(c->d_counts + 2 * c->rank, mine, sizeof mine, hipMemcpyHostToDevice, ctx->stream));
-    CRP_NCCL(ctx, r->AllGather(c->d_counts + 2 * c->rank, c->d_counts, 2, ncclUint64, c->comm, ctx->stream));
-    CRP_HIP(ctx, hipMemcpyAsync(c->counts.data(), c->d_counts, 2 * (size_t)c->world * sizeof(uint64_t),
-                                hipMemcpyDeviceToHost, ctx->stream));
+    const bool ok_local = local == CRP_OK;
+    const uint64_t mine[3] = {ok_local && a ? a->n_hits[0] : 0, ok_local && a ? a->n_hits[1] : 0, (uint64_t)(-local)};
+    const size_t W = (size_t)c->world;
+    // 1. everyone learns every rank's two counts and its status
+    CRP_HIP(ctx, hipMemcpyAsync(c->d_counts + 3 * c->rank, mine, sizeof mine, hipMemcpyHostToDevice, ctx->stream));
+    CRP_NCCL(ctx, r->AllGather(c->d_counts + 3 * c->rank, c->d_counts, 3, ncclUint64, c->comm, ctx->stream));
+    CRP_HIP(ctx, hipMemcpyAsync(c->raw.data(), c->d_counts, 3 * W * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
     CRP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (counts_all) std::memcpy(counts_all, c->counts.data(), 2 * (size_t)c->world * sizeof(uint64_t));
-    // 2. the tables: grouped point-to-point, peers -> root
+    for (size_t p = 0; p < W; ++p) {
+        c->counts[2 * p] = c->raw[3 * p];
+        c->counts[2 * p + 1] = c->raw[3 * p + 1];
+    }
+    if (counts_all) std::memcpy(counts_all, c->counts.data(), 2 * W * sizeof(uint64_t));
+    int rc = agreed_status(ctx, c, c->raw.data() + 2, 3, local, "before the exchange (its arena has no tables to send)");
+    if (rc != CRP_OK) return rc;
+    // 2. the root sizes its receive buffers; whether that worked is agreed on as well (one more word per rank)
+    int alloc = CRP_OK;
     if (c->rank == root) {
-        for (int s = 0; s < 2; ++s) {
-            c->goff[s].assign((size_t)c->world, 0);
+        for (int s = 0; s < 2 && alloc == CRP_OK; ++s) {
+            c->goff[s].assign(W, 0);
             uint64_t total = 0;
             for (int p = 0; p < c->world; ++p) {
                 c->goff[s][(size_t)p] = total;
                 if (p != root) total += c->counts[2 * (size_t)p + s];
             }
-            int rc = crp::grow(ctx, reinterpret_cast<void **>(&c->d_gpos[s]), &c->gpos_cap[s], total, sizeof(uint32_t));
-            if (rc == CRP_OK)
-                rc = crp::grow(ctx, reinterpret_cast<void **>(&c->d_gscore[s]), &c->gscore_cap[s], total, sizeof(double));
-            if (rc == CRP_OK && with_ot)
-                rc = crp::grow(ctx, reinterpret_cast<void **>(&c->d_got[s]), &c->got_cap[s], total, sizeof(uint4));
-            if (rc != CRP_OK) return rc;  // (the peers' sends then fail with the communicator: the caller aborts)
+            alloc = crp::grow(ctx, reinterpret_cast<void **>(&c->d_gpos[s]), &c->gpos_cap[s], total, sizeof(uint32_t));
+            if (alloc == CRP_OK)
+                alloc = crp::grow(ctx, reinterpret_cast<void **>(&c->d_gscore[s]), &c->gscore_cap[s], total, sizeof(double));
+            if (alloc == CRP_OK && with_ot)
+                alloc = crp::grow(ctx, reinterpret_cast<void **>(&c->d_got[s]), &c->got_cap[s], total, sizeof(uint4));
+        }
+        if (c->test_fail == 1) {  // test hook: as if the receive buffers did not fit
+            alloc = CRP_ERR_NOMEM;
+            ctx->last_error = "gatherv receive buffers: out of memory (injected by CRP_TEST_GATHER_FAIL)";
         }
     }
+    const uint64_t word = (uint64_t)(-alloc);
+    uint64_t *d_status = c->d_counts + 3 * W;
+    CRP_HIP(ctx, hipMemcpyAsync(d_status + c->rank, &word, sizeof word, hipMemcpyHostToDevice, ctx->stream));
+    CRP_NCCL(ctx, r->AllGather(d_status + c->rank, d_status, 1, ncclUint64, c->comm, ctx->stream));
+    CRP_HIP(ctx, hipMemcpyAsync(c->raw.data(), d_status, W * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    CRP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    rc = agreed_status(ctx, c, c->raw.data(), 1, alloc, "while sizing the root's receive buffers");
+    if (rc != CRP_OK) return rc;
+    // 3. the tables: grouped point-to-point, peers -> root
+    crp::prof_begin(ctx, CRP_K_GATHER);
     CRP_NCCL(ctx, r->GroupStart());
     ncclResult_t st = ncclSuccess;
     if (c->rank == root) {
@@ -293,11 +341,13 @@ int crp_gather_hits(crp_ctx *ctx, crp_arena *a, int root, int flags, uint64_t *c
         }
     }
     const ncclResult_t st_end = r->GroupEnd();
+    crp::prof_end(ctx, CRP_K_GATHER);
     if (st != ncclSuccess || st_end != ncclSuccess) {
+        // not agreed on: the communicator is in an unknown state and the peers may be inside the exchange --
+        // the caller must take the whole run down (cli.EngineResident.gather: Group.abort)
         ctx->last_error = std::string("gatherv send/recv: ") + r->GetErrorString(st != ncclSuccess ? st : st_end);
         return CRP_ERR_COMM;
     }
-    crp::prof_end(ctx, CRP_K_GATHER);
     // the sends read the arena's tables: they must have left before the caller may scan or destroy it
     CRP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     crp::prof_collect(ctx, CRP_K_GATHER);

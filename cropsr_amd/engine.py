@@ -326,13 +326,17 @@ class Engine:
             st = L.crp_comm_unique_id(buf)
             if st != nat.CRP_OK:
                 err = "crp_comm_unique_id: " + L.crp_strerror(st).decode()
-            ident = bytes(buf)
+            else:
+                ident = bytes(buf)
+        # rank 0's failure to draw an id is agreed on FIRST: nobody enters the blocking ncclCommInitRank
+        # bootstrap with an id that was never drawn
+        group.check(err)
         ident = group.bcast(ident)
-        if ident is not None and err is None:
-            buf = (ctypes.c_uint8 * nat.COMM_ID_BYTES).from_buffer_copy(ident)
-            st = L.crp_comm_init(self._ctx, buf, group.rank, group.world)
-            if st != nat.CRP_OK:
-                err = "crp_comm_init: %s [%s]" % (L.crp_strerror(st).decode(), L.crp_last_error(self._ctx).decode())
+        buf = (ctypes.c_uint8 * nat.COMM_ID_BYTES).from_buffer_copy(ident)
+        st = L.crp_comm_init(self._ctx, buf, group.rank, group.world)
+        err = None
+        if st != nat.CRP_OK:
+            err = "crp_comm_init: %s [%s]" % (L.crp_strerror(st).decode(), L.crp_last_error(self._ctx).decode())
         group.check(err)
 
     def comm_barrier(self):

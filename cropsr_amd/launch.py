@@ -1,0 +1,106 @@
+"""Start the ranks of a one-node multi-GPU run without an external launcher.
+
+`python bench.py --gpus N` (and `python -m cropsr_amd --gpus N ...`) must work by
+themselves: the reference is one process (its only hint of parallelism is the dead
+cropsr_functions.py:256-273), so nothing upstream provides a launcher, and
+`python -m torch.distributed.run` is only one way to export RANK / WORLD_SIZE /
+LOCAL_RANK.  spawn_ranks() is the other: the calling process -- which must not have
+touched HIP or RCCL yet, and never does -- starts N FRESH child processes of the same
+command line (subprocess, no exec of a process that holds a GPU), each with
+
+    RANK, LOCAL_RANK = 0..N-1      WORLD_SIZE = N      MASTER_ADDR = 127.0.0.1
+    CROPSR_RDZV_KEY  = a key unique to this launch (rendezvous.Group.from_env)
+    CROPSR_LAUNCHED  = 1           (the child must not launch again)
+
+and waits for them.  Standard output and error are inherited, so rank 0's one JSON
+line (or the CLI's stdout) reaches the caller unchanged.  The parent's exit status is
+0 only if every rank's is; the first rank that fails decides it, its peers get a grace
+period to leave through the rendezvous abort channel and are then terminated -- by
+their exact pids, never by a pattern.
+"""
+import os
+import subprocess
+import sys
+import time
+
+ENV_MARK = "CROPSR_LAUNCHED"
+ABORTED_WITH_PEER = 3  # exit status of rendezvous.Group._die
+
+
+def wanted(n_ranks, env=None):
+    """True when this process should start the ranks itself: more than one rank is asked
+    for and no launcher (torch.distributed.run, a previous spawn_ranks) has set up the group."""
+    env = os.environ if env is None else env
+    return n_ranks > 1 and int(env.get("WORLD_SIZE", "1")) <= 1 and env.get(ENV_MARK) != "1"
+
+
+def rank_env(rank, world, key, base=None):
+    env = dict(os.environ if base is None else base)
+    env.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_WORLD_SIZE": str(world),
+                "MASTER_ADDR": "127.0.0.1", "CROPSR_RDZV_KEY": key, ENV_MARK: "1"})
+    env.setdefault("MASTER_PORT", "0")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this stack
+    return env
+
+
+def spawn_ranks(argv, world, timeout_s=None, grace_s=20.0, poll_s=0.05, env=None):
+    """Run `argv` as `world` processes (ranks 0..world-1) and wait.  Returns the exit
+    status for the caller: 0 if all ranks returned 0, else the status of the first rank
+    seen failing (a rank killed by a signal counts as 128 + signal); 124 on timeout."""
+    key = "self_%d_%s" % (os.getpid(), os.urandom(4).hex())
+    procs = []
+    try:
+        for r in range(world):
+            procs.append(subprocess.Popen(list(argv), env=rank_env(r, world, key, env)))
+        deadline = None if timeout_s is None else time.monotonic() + timeout_s
+        status, first_fail_at, seen = 0, None, set()
+        while True:
+            codes = [p.poll() for p in procs]
+            for r, c in enumerate(codes):
+                if c in (None, 0) or r in seen:
+                    continue
+                seen.add(r)
+                c = c if c > 0 else 128 - c
+                sys.stderr.write("[cropsr_amd.launch] rank %d exited with status %d\n" % (r, c))
+                # status 3 is how a rank leaves when ANOTHER rank died or asked for an abort (rendezvous.Group._die):
+                # the rank at fault decides the status, whichever of them the polling sees first
+                if status == 0 or (status == ABORTED_WITH_PEER and c != ABORTED_WITH_PEER):
+                    status = c
+                if first_fail_at is None:
+                    first_fail_at = time.monotonic()
+            if all(c is not None for c in codes):
+                return status
+            now = time.monotonic()
+            if deadline is not None and now > deadline and status == 0:
+                status, first_fail_at = 124, now - grace_s  # no grace: the run is over time
+                sys.stderr.write("[cropsr_amd.launch] ranks still running after %.0f s: stopping them\n" % timeout_s)
+            if first_fail_at is not None and now - first_fail_at > grace_s:
+                break  # the peers did not leave by themselves (abort channel): stop them below
+            time.sleep(poll_s)
+        return status
+    finally:
+        _stop(procs)
+
+
+def _stop(procs):
+    """Terminate whatever is still running (exact pids), then make sure it is gone."""
+    alive = [p for p in procs if p.poll() is None]
+    for p in alive:
+        try:
+            p.terminate()
+        except OSError:
+            pass
+    t0 = time.monotonic()
+    while alive and time.monotonic() - t0 < 5.0:
+        alive = [p for p in alive if p.poll() is None]
+        time.sleep(0.05)
+    for p in alive:
+        try:
+            p.kill()
+        except OSError:
+            pass
+    for p in procs:
+        try:
+            p.wait(timeout=5)
+        except Exception:
+            pass

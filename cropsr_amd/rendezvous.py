@@ -31,6 +31,7 @@ call, which has no time-out of its own.  A collective that cannot complete ends
 in a non-zero exit, never in a hang.  Group.close() is itself a barrier, so a
 rank that merely finishes first does not look like one that died.
 """
+import hmac
 import json
 import os
 import pickle
@@ -121,6 +122,8 @@ class Group:
             self._listener.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
             if endpoint:
                 host, port = endpoint.rsplit(":", 1)
+                if not self._token and host not in ("127.0.0.1", "localhost", "::1"):
+                    raise ValueError("CROPSR_RDZV_ENDPOINT on a non-loopback address needs CROPSR_RDZV_TOKEN")
                 self._listener.bind((host, int(port)))
             else:
                 self._listener.bind(("127.0.0.1", 0))
@@ -131,7 +134,12 @@ class Group:
                 if not self._token:
                     self._token = os.urandom(16).hex()
                 tmp = rdzv_file + ".%d.tmp" % os.getpid()
-                with open(os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o600), "w") as f:
+                try:
+                    os.unlink(tmp)  # (a leftover of a crashed run with the same pid)
+                except OSError:
+                    pass
+                # O_EXCL | O_NOFOLLOW: never write the token through a file or link someone else put there
+                with open(os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL | getattr(os, "O_NOFOLLOW", 0), 0o600), "w") as f:
                     json.dump({"host": host, "port": port, "world": self.world, "pid": os.getpid(), "token": self._token}, f)
                 os.replace(tmp, rdzv_file)  # atomic: a reader never sees half a file
                 self._file = rdzv_file
@@ -144,13 +152,20 @@ class Group:
                 except Exception:
                     hello = None
                 conn.settimeout(_TIMEOUT_S)
-                if not isinstance(hello, dict):
-                    conn.close()  # not one of ours
-                    continue
-                table = self._abort_peers if hello.get("abort") else self._peers
-                if hello.get("world") != self.world or hello.get("rank") in table or not 0 < hello.get("rank", 0) < self.world \
-                        or hello.get("token") != self._token:
-                    conn.close()  # a stray client of another run
+                # Whatever arrives on the port is judged before it is used: the token first (constant time),
+                # then the types, and nothing a stranger sends may raise out of this loop.
+                try:
+                    ok = (isinstance(hello, dict) and isinstance(hello.get("token"), str)
+                          and hmac.compare_digest(hello["token"].encode(), self._token.encode())
+                          and type(hello.get("rank")) is int and type(hello.get("world")) is int
+                          and hello["world"] == self.world and 0 < hello["rank"] < self.world)
+                    table = (self._abort_peers if hello.get("abort") else self._peers) if ok else None
+                    if ok and hello["rank"] in table:
+                        ok = False
+                except Exception:
+                    ok = False
+                if not ok:
+                    conn.close()  # not one of ours: a stray client of another run, or garbage
                     continue
                 table[hello["rank"]] = conn
             for r in sorted(self._peers):

@@ -50,7 +50,9 @@ typedef enum crp_status {
     CRP_ERR_CAPACITY = -6,    /* arena capacity exceeded */
     CRP_ERR_UNSUPPORTED = -7, /* e.g. guide length outside [1, 50] */
     CRP_ERR_IO = -8,          /* write(2) on the caller's descriptor failed; errno is left set */
-    CRP_ERR_COMM = -9         /* an RCCL call failed or librccl.so could not be loaded; see crp_last_error */
+    CRP_ERR_COMM = -9,        /* an RCCL call failed or librccl.so could not be loaded; see crp_last_error */
+    CRP_ERR_PEER = -10        /* a collective call was abandoned ON EVERY RANK because another rank reported an error
+                               * before the exchange started (crp_gather_hits); this rank itself was fine */
 } crp_status;
 
 typedef struct crp_ctx crp_ctx;
@@ -234,7 +236,12 @@ int crp_comm_allreduce_f64(crp_ctx *ctx, double *values, int n, int op);
  * '+' and '-' tables (pos u32, score f64) of every rank into root's HBM.  flags (the same on every
  * rank): CRP_GATHER_OFFTARGET also gathers the per-hit off-target counts (crp_offtarget_counts must
  * have run on `arena`).  counts_all (2 x world values, may be NULL) receives every rank's
- * {n_plus, n_minus} on every rank. */
+ * {n_plus, n_minus} on every rank.
+ * Failure is collective: whatever can go wrong on ONE rank before the tables move -- its arena has no
+ * (matching) tables: CRP_ERR_STATE; the root cannot size its receive buffers: CRP_ERR_NOMEM -- travels with
+ * the counts, and every rank returns from the same call without starting the exchange: the rank at fault with
+ * its own status, the others with CRP_ERR_PEER (crp_last_error names the rank).  The communicator stays
+ * usable.  CRP_ERR_COMM / CRP_ERR_HIP from inside the exchange are NOT agreed on: the caller must end the run. */
 #define CRP_GATHER_OFFTARGET 1
 /* CRP_GATHER_PRE: the f64 column that travels is the pre-sigmoid sum (crp_scan_score with want_pre)
  * instead of the score -- for a root that applies its own host's exp (cli --score-finalize=host). */

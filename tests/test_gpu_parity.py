@@ -761,6 +761,89 @@ def test_bench_line_contract():
     assert o["value"] > 0 and o["roofline"]["bound"] == "hbm" and o["sites_total"] > 0 and "error" not in o
 
 
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with NO launcher in the environment (what the driver's N > 1 command looks
+    like if it has the N = 1 command's shape): the parent starts two fresh ranks itself (cropsr_amd/launch.py),
+    rank 0 prints the ONE line, the status is 0.  One GPU here, so --share-gpu0 puts both ranks on device 0 with the
+    host transport for fences and the final gatherv."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "CROPSR_LAUNCHED")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu0", "--scale", "0.02",
+                        "--steps", "3", "--warmup", "1", "--offtarget-steps", "0"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["gatherv_ok"] is True and d["value"] > 0 and d["scaling"] == "weak"
+    assert d["value_with_final_gatherv"] > 0 and d["value_with_final_gatherv"] < d["value"]
+    ranks = d["per_rank"]
+    assert [r["rank"] for r in ranks] == [0, 1] and all(r["kernel_ms"] > 0 and r["kept_hits"] > 0 for r in ranks)
+    assert sum(r["kept_hits"] for r in ranks) == d["config"]["kept_hits_total"]
+
+
+def test_cli_starts_its_own_ranks(manifest, tmp_path):
+    """`python -m cropsr_amd --gpus 2 ...` without a launcher writes the reference's bytes (both ranks on the one GPU
+    here, host transport)."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    out_csv = tmp_path / "out.csv"
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "CROPSR_LAUNCHED")}
+    env.update(CROPSR_GATHER="host", CROPSR_DIST_MAX_PIECE="100", PYTHONPATH=ROOT)
+    p = subprocess.run([sys.executable, "-m", "cropsr_amd", "--gpus", "2", "--device", "0", "-o", str(out_csv),
+                        "-f", os.path.join(GOLDEN, "probe_mixed.fa"), "-g", os.path.join(GOLDEN, "sample_head.gff"), "--cas9",
+                        "--seed", str(manifest["seed"])], capture_output=True, text=True, timeout=600, cwd=str(tmp_path), env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert manifest["cases"]["mixed"]["stdout"] in p.stdout
+    assert out_csv.read_bytes() == read_golden_csv("mixed")
+
+
+def _gather_failure_world1(out_path, mode):
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, ROOT)
+    os.environ["CRP_TEST_GATHER_FAIL"] = str(mode)
+    from cropsr_amd import Engine, rendezvous
+    from cropsr_amd import _native as nat
+    eng = Engine(0)
+    eng.comm_init(rendezvous.Group(0, 1))
+    arena = eng.arena([b"ACGGTCCAGGTTCCAAGG" * 500])
+    arena.scan_score_device(20)
+    status, text = 0, ""
+    try:
+        eng.gather_hits(arena, 0)
+    except nat.CropsrHipError as e:
+        status, text = e.status, str(e)
+    # the failure was agreed on BEFORE the exchange: the communicator is still usable
+    after = eng.comm_allreduce([2.0], "sum")
+    arena.close()
+    eng.close()
+    with open(out_path, "w") as f:
+        f.write("%d|%s|%r" % (status, text, after))
+
+
+@pytest.mark.parametrize("mode,want", [(1, -4), (2, -5)])
+def test_gather_failure_is_agreed_on_before_the_exchange(tmp_path, mode, want):
+    """a root that cannot size its receive buffers (mode 1, injected) or a rank whose arena
+    has no tables (mode 2) must not return alone from crp_gather_hits and leave its peers in ncclSend/Recv.  The
+    status now travels with the counts (all-gather) and every rank returns from the same call; with one rank the
+    visible part is: the call fails with the rank's OWN status after both agreement rounds ran on RCCL, and the
+    communicator still works.  (N > 1 on real GPUs is the driver's to run.)"""
+    import multiprocessing as mp
+    out = str(tmp_path / "r.txt")
+    p = mp.get_context("spawn").Process(target=_gather_failure_world1, args=(out, mode))
+    p.start()
+    p.join(600)
+    assert p.exitcode == 0
+    status, text, after = open(out).read().split("|")
+    assert int(status) == want, text
+    assert after == "[2.0]"
+
+
 def test_randomised_arenas_vs_oracle(engine, oracle):
     """Seeded fuzz: arenas with random contig counts, lengths clustered around word (64) and
     tile (16384) boundaries, random alphabets / decoration / guide lengths / packers."""
