@@ -71,6 +71,9 @@ def parse_args():
                     help="--gpus N without a launcher: stop the self-started ranks after this many seconds")
     ap.add_argument("--offtarget-steps", type=int, default=5,
                     help="timed steps of the off-target seed scan (0 = skip that block)")
+    ap.add_argument("--offtarget-seeds-from-planes", action="store_true",
+                    help="off-target block: the seed stage reads the planes itself (ot_seed_kernel) instead of taking the "
+                         "seed words from the scan")
     ap.add_argument("--cpu-sample-bases", type=int, default=40000000,
                     help="upper bound on the bases of the same workload timed on the CPU port; the actual "
                          "sample is sized for about 12 s of CPU work per leg (0 = skip)")
@@ -321,6 +324,16 @@ def main():
         ot = {"skipped": "the site histogram is summed over the ranks by an RCCL all-reduce, and RCCL is unavailable here"}
     elif args.offtarget_steps > 0 and not (gather_info and "error" in gather_info):
         try:
+            # The scan hands the seed words over (CRP_SCAN_SEEDS: the emit kernel writes them from the windows it
+            # holds anyway); what that costs the scan is measured here and reported beside the step.
+            eng.profile(1)
+            eng.profile_read(reset=True)
+            for _ in range(8):
+                arena.scan_score_device(20, want_pre=False, want_seeds=not args.offtarget_seeds_from_planes)
+            scan_seeds = eng.profile_read(reset=True)["emit_score"]
+            eng.profile(0)
+            scan_seeds_ms = scan_seeds["ms"] / max(1, scan_seeds["launches"])
+
             def ot_step():
                 eng.offtarget_reset()
                 sites = arena.offtarget_add(20)
@@ -345,25 +358,41 @@ def main():
             sites_all = reduce([sites], "sum")[0]
             per = {k: pot[k]["ms"] / max(1, pot[k]["launches"]) for k in ("ot_seed", "ot_ball", "ot_lookup", "ot_reduce")}
             hits = n_plus + n_minus
-            # algorithmic bytes of one step on this rank: seeds 4 B pos in + 4 B seed out
-            # per hit + the 12 characters next to the PAM out of 4 planes (counted as 4 x 8 B words); partition level 1
-            # 4 B seed in per hit + 4 B out per site, level 2 4 B in + 2 B out per site, bucket histograms 2 B in per
-            # site + 64 MiB in and out; ball passes 64 MiB in, 3 x 256 MiB out, 2 x 256 MiB back in; look-up
-            # 4 + 16 + 16 B per hit
-            seed_bytes = hits * (4 + 4 + 32) + hits * 4 + sites * (4 + 4 + 2 + 2) + 2 * (1 << 26)
+            # Algorithmic bytes of one step on this rank.  Seed stage: the seed words in (4 B per
+            # hit; with --offtarget-seeds-from-planes instead the planes once, 0.5 B per character, + 4 B of position) and
+            # the Morton codes out (4 B per hit); partition level 1: 4 B in per hit, 4 B out per site; level 2: 4 B in,
+            # 2 B out per site; bucket histograms: 2 B in per site + 64 MiB in and out.  Ball passes: 64 MiB in,
+            # 3 x 256 MiB out, 2 x 256 MiB back in.  Look-up: 4 B seed + 16 B gather + 16 B out per hit.
+            n_chars_r = arena.stats()["n_chars"]
+            seed_in = (n_chars_r // 2 + 4 * hits) if args.offtarget_seeds_from_planes else 4 * hits
+            seed_bytes = seed_in + 4 * hits + 4 * hits + sites * (4 + 4 + 2 + 2) + 2 * (1 << 26)
             ball_bytes = (1 << 24) * (4 + 16 * 5)
             look_bytes = hits * (4 + 16 + 16)
+            step_ms = dt_ot / args.offtarget_steps * 1e3
+            kernels_ms = per["ot_seed"] + per["ot_ball"] + per["ot_lookup"]
+            frac = lambda nbytes, ms: (nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms else None
+            total_bytes = seed_bytes + ball_bytes + look_bytes
             ot = {"metric": "guides off-target-scanned/sec", "value": hits_all * args.offtarget_steps / dt_ot,
-                  "unit": "guides/s", "steps": args.offtarget_steps, "ms_per_step": dt_ot / args.offtarget_steps * 1e3,
+                  "unit": "guides/s", "steps": args.offtarget_steps, "ms_per_step": step_ms,
                   "sites_total": int(sites_all), "seed_len": 12, "max_mismatches": 3,
                   "kernels_ms": per,
-                  "roofline": {"bound": "hbm", "kernel": "ot_ball_kernel x3 (Hamming-ball sums over all 4^12 seeds)",
-                               "achieved": ball_bytes / (per["ot_ball"] * 1e-3) / 1e9 if per["ot_ball"] else None,
-                               "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": ball_bytes / (per["ot_ball"] * 1e-3) / 1e9 / HBM_PEAK_GBS if per["ot_ball"] else None,
-                               "traffic": None, "algorithmic_bytes_per_launch": int(ball_bytes),
-                               "seed_kernel_GBps": seed_bytes / (per["ot_seed"] * 1e-3) / 1e9 if per["ot_seed"] else None,
-                               "lookup_kernel_GBps": look_bytes / (per["ot_lookup"] * 1e-3) / 1e9 if per["ot_lookup"] else None},
+                  "seeds": "from the planes (ot_seed_kernel)" if args.offtarget_seeds_from_planes else
+                           "from the scan (CRP_SCAN_SEEDS): the emit kernel writes a seed word per hit",
+                  # what the hand-over costs the scan's own kernel (per scan, not part of ms_per_step)
+                  "scan_kernel_ms_with_seed_words": scan_seeds_ms,
+                  "scan_kernel_ms_plain": prof["emit_score"]["ms"] / max(1, prof["emit_score"]["launches"]),
+                  # the WHOLE step against the HBM roofline, and every stage beside it: the look-up (one random 16-byte
+                  # gather per hit out of a 256 MiB table) is the dominant kernel and runs at the memory system's
+                  # gather rate, not at its streaming rate
+                  "roofline": {"bound": "hbm", "kernel": "whole step: seeds + partition + histogram, 3 ball passes, look-up",
+                               "achieved": total_bytes / (kernels_ms * 1e-3) / 1e9 if kernels_ms else None,
+                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": frac(total_bytes, kernels_ms),
+                               "traffic": None, "algorithmic_bytes_per_step": int(total_bytes),
+                               "stage_frac": {"seed_partition_histogram": frac(seed_bytes, per["ot_seed"]),
+                                              "ball_passes": frac(ball_bytes, per["ot_ball"]),
+                                              "lookup_gather": frac(look_bytes, per["ot_lookup"])},
+                               "stage_bytes": {"seed_partition_histogram": int(seed_bytes), "ball_passes": int(ball_bytes),
+                                               "lookup_gather": int(look_bytes)}},
                   "parity": "unpinned: the reference has no off-target step (oracle: oracle/crp_oracle.c all-pairs)"}
         except Exception as e:
             ot = {"error": repr(e)[:300]}
@@ -421,7 +450,9 @@ def main():
             line["rccl_error"] = rccl_error
         if ot is not None:
             if facts and "roofline" in ot:
-                ot["roofline"]["traffic"] = facts.get("offtarget_ball_hbm_bytes_per_step")
+                # counter traffic exists for the ball passes only (streaming reads, where the gfx950 FETCH_SIZE correction
+                # is calibrated); the look-up's gathers and the partition's scatters are not calibrated: whole step = null
+                ot["roofline"]["stage_traffic"] = {"ball_passes": facts.get("offtarget_ball_hbm_bytes_per_step")}
                 ot["roofline"]["traffic_source"] = facts_src
             line["offtarget"] = ot
         if gather_info is not None:

@@ -82,9 +82,10 @@ KINDS = ("count", "tile_scan", "emit_score", "ot_seed", "ot_ball", "ot_lookup", 
 REDUCE_SUM, REDUCE_MAX = 0, 1
 COMM_ID_BYTES = 128
 GATHER_OFFTARGET, GATHER_PRE = 1, 2
+SCAN_PRE, SCAN_SEEDS = 1, 2
 OT_SEEDS = 1 << 24
 OT_NOT_A_SITE, OT_NOT_OWNED = 0xFFFFFFFF, 0xFFFFFFFE
-ABI_VERSION = 2
+ABI_VERSION = 3
 CRP_ERR_NO_DEVICE = -2
 CRP_ERR_IO = -8
 CRP_ERR_COMM = -9

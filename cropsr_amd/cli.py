@@ -223,11 +223,12 @@ class EngineBackend:
         genome.close()
         return out
 
-    def scan_resident(self, texts, guide_len):
-        """The same scan with the tables left in HBM, for parallel.sharded_scan."""
+    def scan_resident(self, texts, guide_len, offtarget=False):
+        """The same scan with the tables left in HBM, for parallel.sharded_scan.  offtarget: the off-target step
+        follows, so the scan also writes the seed words it works on."""
         want_pre = self.finalize == "host"
         genome = self.engine.genome(texts)
-        counts = [a.scan_score_device(guide_len, want_pre) for a in genome.arenas]
+        counts = [a.scan_score_device(guide_len, want_pre, want_seeds=offtarget) for a in genome.arenas]
         return EngineResident(self, genome, counts, guide_len, want_pre)
 
     def finalize_gathered(self, all_hits):

@@ -239,6 +239,7 @@ int crp_arena_destroy(crp_arena *a)
         (void)hipFree(a->d_pos[s]);
         (void)hipFree(a->d_score[s]);
         (void)hipFree(a->d_pre[s]);
+        (void)hipFree(a->d_ot_raw[s]);
         (void)hipFree(a->d_ot_seed[s]);
         (void)hipFree(a->d_ot_cnt[s]);
     }
@@ -374,7 +375,12 @@ using crp::prof_begin;
 using crp::prof_collect;
 using crp::prof_end;
 
-static int reserve_tables(crp_arena *a, const uint64_t n[2], int want_pre)
+// scan flags of one crp_scan_score call
+struct ScanWant {
+    bool pre, seeds;
+};
+
+static int reserve_tables(crp_arena *a, const uint64_t n[2], ScanWant want)
 {
     crp_ctx *ctx = a->ctx;
     for (int s = 0; s < 2; ++s) {
@@ -383,31 +389,48 @@ static int reserve_tables(crp_arena *a, const uint64_t n[2], int want_pre)
         if (rc == CRP_OK) rc = grow(ctx, reinterpret_cast<void **>(&a->d_score[s]), &cap_score, n[s], sizeof(double));
         if (rc != CRP_OK) { a->tab_cap[s] = 0; return rc; }
         a->tab_cap[s] = std::min(cap_pos, cap_score);
-        if (want_pre) {
+        if (want.pre) {
             rc = grow(ctx, reinterpret_cast<void **>(&a->d_pre[s]), &a->pre_cap[s], n[s], sizeof(double));
+            if (rc != CRP_OK) return rc;
+        }
+        if (want.seeds) {
+            rc = grow(ctx, reinterpret_cast<void **>(&a->d_ot_raw[s]), &a->raw_cap[s], n[s], sizeof(uint32_t));
             if (rc != CRP_OK) return rc;
         }
     }
     return CRP_OK;
 }
 
-static crp::HitTables table_args(const crp_arena *a, int want_pre)
+// every column the launch writes holds at least cap_* rows
+static crp::HitTables table_args(const crp_arena *a, ScanWant want)
 {
-    return crp::HitTables{a->d_pos[0], a->d_score[0], want_pre ? a->d_pre[0] : nullptr,
-                          a->d_pos[1], a->d_score[1], want_pre ? a->d_pre[1] : nullptr,
-                          want_pre ? std::min(a->tab_cap[0], a->pre_cap[0]) : a->tab_cap[0],
-                          want_pre ? std::min(a->tab_cap[1], a->pre_cap[1]) : a->tab_cap[1]};
+    uint64_t cap[2];
+    for (int s = 0; s < 2; ++s) {
+        cap[s] = a->tab_cap[s];
+        if (want.pre) cap[s] = std::min(cap[s], a->pre_cap[s]);
+        if (want.seeds) cap[s] = std::min(cap[s], a->raw_cap[s]);
+    }
+    return crp::HitTables{a->d_pos[0], a->d_score[0], want.pre ? a->d_pre[0] : nullptr,
+                          a->d_pos[1], a->d_score[1], want.pre ? a->d_pre[1] : nullptr, cap[0], cap[1],
+                          want.seeds ? a->d_ot_raw[0] : nullptr, want.seeds ? a->d_ot_raw[1] : nullptr};
+}
+
+static bool tables_exist(const crp_arena *a, ScanWant want)
+{
+    for (int s = 0; s < 2; ++s)
+        if (!a->tab_cap[s] || (want.pre && !a->pre_cap[s]) || (want.seeds && !a->raw_cap[s])) return false;
+    return true;
 }
 
 // count -> tile scan -> emit.  The table sizes must be known before the emit: once an arena has been
 // scanned the tables exist and the emit is queued speculatively (stores are bounds-checked, totals
 // compared afterwards); the very first scan of an arena waits for the totals instead.
-static int scan_two_pass(crp_arena *a, const crp::Planes &pl, uint64_t eff_words, int guide_len, int want_pre,
+static int scan_two_pass(crp_arena *a, const crp::Planes &pl, uint64_t eff_words, int guide_len, ScanWant want,
                          uint64_t n[2])
 {
     crp_ctx *ctx = a->ctx;
     const uint32_t n_tiles = a->n_tiles;
-    const bool speculative = a->tab_cap[0] && a->tab_cap[1] && (!want_pre || (a->pre_cap[0] && a->pre_cap[1]));
+    const bool speculative = tables_exist(a, want);
     prof_begin(ctx, 0);
     CRP_HIP(ctx, crp::launch_count(ctx->stream, pl, eff_words, guide_len, a->d_tile_cnt, n_tiles));
     prof_end(ctx, 0);
@@ -419,10 +442,10 @@ static int scan_two_pass(crp_arena *a, const crp::Planes &pl, uint64_t eff_words
         CRP_HIP(ctx, hipStreamSynchronize(ctx->stream));
         n[0] = a->h_totals[0];
         n[1] = a->h_totals[1];
-        int rc = reserve_tables(a, n, want_pre);
+        int rc = reserve_tables(a, n, want);
         if (rc != CRP_OK) return rc;
     }
-    crp::HitTables out = table_args(a, want_pre);
+    crp::HitTables out = table_args(a, want);
     prof_begin(ctx, 2);
     CRP_HIP(ctx, crp::launch_emit(ctx->stream, pl, eff_words, guide_len, a->d_tile_off, out));
     prof_end(ctx, 2);
@@ -434,9 +457,9 @@ static int scan_two_pass(crp_arena *a, const crp::Planes &pl, uint64_t eff_words
     if (n[0] > out.cap_plus || n[1] > out.cap_minus) {
         // a speculative run met more hits than the tables hold (e.g. another guide length):
         // nothing was written out of bounds; size exactly and emit again
-        int rc = reserve_tables(a, n, want_pre);
+        int rc = reserve_tables(a, n, want);
         if (rc != CRP_OK) return rc;
-        out = table_args(a, want_pre);
+        out = table_args(a, want);
         CRP_HIP(ctx, crp::launch_emit(ctx->stream, pl, eff_words, guide_len, a->d_tile_off, out));
         CRP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
@@ -450,24 +473,24 @@ static int scan_two_pass(crp_arena *a, const crp::Planes &pl, uint64_t eff_words
 // with the exact sizes.
 // One launch: offsets from the chained scan inside the emit kernel.  Returns CRP_ERR_STATE with
 // *chain_failed = true when a look-back timed out (the caller then runs the three-launch sequence).
-static int scan_single_pass(crp_arena *a, const crp::Planes &pl, uint64_t eff_words, int guide_len, int want_pre,
+static int scan_single_pass(crp_arena *a, const crp::Planes &pl, uint64_t eff_words, int guide_len, ScanWant want,
                             uint64_t n[2], bool *chain_failed)
 {
     crp_ctx *ctx = a->ctx;
     *chain_failed = false;
-    uint64_t want[2] = {std::max<uint64_t>(a->tab_cap[0], a->n_chars / 8 + 1024),
+    uint64_t rows[2] = {std::max<uint64_t>(a->tab_cap[0], a->n_chars / 8 + 1024),
                         std::max<uint64_t>(a->tab_cap[1], a->n_chars / 8 + 1024)};
     for (int attempt = 0; attempt < 2; ++attempt) {
-        int rc = reserve_tables(a, want, want_pre);
+        int rc = reserve_tables(a, rows, want);
         if (rc != CRP_OK) return rc;
-        const crp::HitTables out = table_args(a, want_pre);
+        const crp::HitTables out = table_args(a, want);
         uint64_t *cur = a->d_chain[a->chain_cur], *next = a->d_chain[a->chain_cur ^ 1];
         a->h_totals[0] = a->h_totals[1] = a->h_totals[2] = 0;
         prof_begin(ctx, 2);
         CRP_HIP(ctx, crp::launch_emit_chained(ctx->stream, pl, eff_words, guide_len, cur, next, out, ctx->mute_tile,
                                                   ctx->chain_timeout_ticks));
         prof_end(ctx, 2);
-        // header: ticket | fail << 32, total '+', total '-' -- the kernel also writes it to h_totals (pinned)
+        // header: fail << 32, total '+', total '-' -- the kernel also writes it to h_totals (pinned)
         CRP_HIP(ctx, hipStreamSynchronize(ctx->stream));
         a->chain_cur ^= 1;  // the kernel left the other buffer zeroed
         if (a->h_totals[0] >> 32) {  // fail flag: a look-back spin ran out; neither buffer can be trusted now
@@ -482,31 +505,34 @@ static int scan_single_pass(crp_arena *a, const crp::Planes &pl, uint64_t eff_wo
         n[0] = a->h_totals[1];
         n[1] = a->h_totals[2];
         if (n[0] <= out.cap_plus && n[1] <= out.cap_minus) return CRP_OK;
-        want[0] = n[0];
-        want[1] = n[1];
+        rows[0] = n[0];
+        rows[1] = n[1];
     }
     ctx->last_error = "emit kernel: tables still too small after resizing";
     return CRP_ERR_STATE;
 }
 
-int crp_scan_score(crp_arena *a, int guide_len, int want_pre, uint64_t *n_plus, uint64_t *n_minus)
+int crp_scan_score(crp_arena *a, int guide_len, int flags, uint64_t *n_plus, uint64_t *n_minus)
 {
     crp::Range roctx_range("crp: scan + score");
-    if (!a) return CRP_ERR_INVALID;
+    if (!a || (flags & ~(CRP_SCAN_PRE | CRP_SCAN_SEEDS))) return CRP_ERR_INVALID;
     if (!a->sealed) return CRP_ERR_STATE;
     if (guide_len < 1 || guide_len > 50) return CRP_ERR_UNSUPPORTED;
     crp_ctx *ctx = a->ctx;
     CRP_HIP(ctx, hipSetDevice(ctx->device));
     a->have_hits = false;
+    a->have_raw = false;
+    // seed words come out of the l = 20 kernel only; for other lengths the off-target step derives them itself
+    const ScanWant want{(flags & CRP_SCAN_PRE) != 0, (flags & CRP_SCAN_SEEDS) != 0 && guide_len == 20};
     const uint64_t eff_words = (uint64_t)a->n_tiles * crp::TILE_WORDS;
     crp::Planes pl{{a->d_plane[0], a->d_plane[1], a->d_plane[2], a->d_plane[3]}};
     uint64_t n[2] = {0, 0};
     int rc;
     if (ctx->two_pass || ctx->two_pass_latched) {
-        rc = scan_two_pass(a, pl, eff_words, guide_len, want_pre, n);
+        rc = scan_two_pass(a, pl, eff_words, guide_len, want, n);
     } else {
         bool chain_failed = false;
-        rc = scan_single_pass(a, pl, eff_words, guide_len, want_pre, n, &chain_failed);
+        rc = scan_single_pass(a, pl, eff_words, guide_len, want, n, &chain_failed);
         if (chain_failed) {
             // A workgroup waited longer than CRP_OPT_CHAIN_TIMEOUT_US for a predecessor's counts (a
             // shared or pre-empted GPU can do that; a wrong assumption about dispatch order would
@@ -516,7 +542,7 @@ int crp_scan_score(crp_arena *a, int guide_len, int want_pre, uint64_t *n_plus, 
             if (++ctx->timeout_streak >= 3) ctx->two_pass_latched = true;
             ctx->last_error = "single-launch scan: a chained look-back timed out; this scan was repeated with the "
                               "count / scan / emit sequence";
-            rc = scan_two_pass(a, pl, eff_words, guide_len, want_pre, n);
+            rc = scan_two_pass(a, pl, eff_words, guide_len, want, n);
         } else if (rc == CRP_OK) {
             ctx->timeout_streak = 0;
         }
@@ -525,7 +551,8 @@ int crp_scan_score(crp_arena *a, int guide_len, int want_pre, uint64_t *n_plus, 
     a->n_hits[0] = n[0];
     a->n_hits[1] = n[1];
     a->have_hits = true;
-    a->have_pre = want_pre != 0;
+    a->have_pre = want.pre;
+    a->have_raw = want.seeds;
     if (n_plus) *n_plus = n[0];
     if (n_minus) *n_minus = n[1];
     return CRP_OK;

@@ -76,6 +76,10 @@ struct crp_arena {
     uint64_t pre_cap[2] = {0, 0};
     uint64_t n_hits[2] = {0, 0};
     bool have_hits = false, have_pre = false;
+    // off-target: raw seed words written by the scan itself (CRP_SCAN_SEEDS; same order and capacity as the hit tables)
+    uint32_t *d_ot_raw[2] = {nullptr, nullptr};
+    uint64_t raw_cap[2] = {0, 0};
+    bool have_raw = false;  // the last scan wrote them
     // off-target: per-hit seed codes and counts, same order as the hit tables
     uint32_t *d_ot_seed[2] = {nullptr, nullptr};
     uint4 *d_ot_cnt[2] = {nullptr, nullptr};

@@ -16,12 +16,12 @@
 // (i-l >= 5, j+3 >= 5, j+3+l <= len+10, j+2 < len, complete 30-window) becomes a
 // test of a void bit at a fixed distance, and no kernel needs a contig table.
 //
-// Work decomposition: one 256-thread workgroup per tile of 256*WPT words.  PAM
+// Work decomposition: one 256-thread workgroup per tile of 512 words.  PAM
 // masks are 64-wide bit-parallel per lane; kept hits are ranked with popcounts and
 // a block scan, compacted to an LDS list, and then scored one hit per lane so the
 // f64 work is balanced and the table stores are coalesced.  Output order is
-// ascending arena position per strand (two-pass count / scan / emit, no atomics):
-// bitwise reproducible and identical to the reference's row order.
+// ascending arena position per strand (offsets from a chained scan across tiles, or
+// from the count / scan passes): bitwise reproducible, identical to the reference's row order.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -30,12 +30,6 @@
 #include "crp_kernels.h"
 #include "crp_score.h"
 #include "crp_score_generic.h"
-
-#if CRP_NT_STORES  // the tables are written once and not read again by this kernel
-#define CRP_TABLE_STORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
-#else
-#define CRP_TABLE_STORE(ptr, val) (*(ptr) = (val))
-#endif
 
 namespace crp {
 
@@ -66,67 +60,6 @@ __device__ __forceinline__ uint64_t behind(uint64_t prev, uint64_t cur, int e)
     return pair64(funnel(c0, p1, 64 - e), funnel(p1, p0, 64 - e));
 }
 
-struct WordTriple {
-    uint64_t p, c, n;
-};
-
-// Kept-hit masks of one 64-position word.
-//   plus : (?=.GG) at i  <=>  G(i+1) & G(i+2);  keep  i - l >= 5   (CROPSR.py:419)
-//   minus: (?=CC.) at j  <=>  C(j) & C(j+1) & exists(j+2);
-//          keep  j+3 >= 5  and  j+3+l <= len+10               (CROPSR.py:430)
-// "exists"/"index >= 0"/"index < len" are void tests at fixed distances.
-__device__ __forceinline__ void word_masks(const WordTriple &hi, const WordTriple &lo,
-                                           const WordTriple &up, const WordTriple &ac, int l,
-                                           uint64_t &mplus, uint64_t &mminus)
-{
-    const uint64_t g_c = hi.c & lo.c & up.c & ac.c, g_n = hi.n & lo.n & up.n & ac.n;
-    const uint64_t c_c = hi.c & ~lo.c & up.c & ac.c, c_n = hi.n & ~lo.n & up.n & ac.n;
-    const uint64_t v_p = hi.p & lo.p & ~up.p & ~ac.p;
-    const uint64_t v_c = hi.c & lo.c & ~up.c & ~ac.c;
-    const uint64_t v_n = hi.n & lo.n & ~up.n & ~ac.n;
-
-    mplus = ahead(g_c, g_n, 1) & ahead(g_c, g_n, 2) & ~behind(v_p, v_c, l + 5);
-
-    uint64_t m = c_c & ahead(c_c, c_n, 1) & ~ahead(v_c, v_n, 2) & ~behind(v_p, v_c, 2);
-    if (l > 8) m &= ~ahead(v_c, v_n, l - 8);
-    mminus = m;
-}
-
-// Stage TW words (+ one halo word each side) of the four planes into LDS.
-// sh[p][0] = word t0-1, sh[p][1+k] = word t0+k, sh[p][TW+1] = word t0+TW.
-// The arena allocation is padded to a multiple of the tile, so the body is
-// always in range; halos beyond the arena read as void.
-template <int TW>
-__device__ __forceinline__ void stage_tile(const Planes &pl, uint64_t t0, uint64_t n_words_padded,
-                                           uint64_t (*sh)[TW + 2])
-{
-    const int tid = threadIdx.x;
-    constexpr int PAIRS = TW / 2;  // 16-byte units per plane
-#pragma unroll
-    for (int it = 0; it < (4 * PAIRS) / EMIT_BLOCK; ++it) {
-        const int q = tid + it * EMIT_BLOCK;
-        const int p = q / PAIRS, k = q % PAIRS;
-        const uint64_t *src = pl.plane[p] + t0 + 2 * k;
-        const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(src);
-        sh[p][1 + 2 * k] = v.x;
-        sh[p][2 + 2 * k] = v.y;
-    }
-    if (tid < 8) {
-        const int p = tid >> 1;
-        const bool right = tid & 1;
-        const uint64_t voidw = (p < 2) ? ALL : 0ull;
-        uint64_t w;
-        if (right) {
-            const uint64_t idx = t0 + TW;
-            w = idx < n_words_padded ? pl.plane[p][idx] : voidw;
-            sh[p][TW + 1] = w;
-        } else {
-            w = t0 > 0 ? pl.plane[p][t0 - 1] : voidw;
-            sh[p][0] = w;
-        }
-    }
-}
-
 // 64-bit inclusive scan across the wave.
 __device__ __forceinline__ uint64_t wave_inclusive_scan(uint64_t v)
 {
@@ -142,7 +75,7 @@ __device__ __forceinline__ uint64_t wave_inclusive_scan(uint64_t v)
 // Block-wide exclusive scan of a packed (plus | minus << 32) count.
 // `wave_tot` is LDS scratch of BLOCK/64 entries.  Returns the exclusive prefix,
 // sets `total` to the block total.
-// The per-lane counts are small (<= 64*WPT per strand), so both fit one 32-bit
+// The per-lane counts are small (<= 128 per strand), so both fit one 32-bit
 // word as 16-bit fields and the wave scan is six DPP adds (row_shr 1,2,4,8 inside
 // each row of 16 lanes, then row_bcast:15 / row_bcast:31 across rows) instead of
 // twelve 64-bit shuffles through the LDS crossbar.
@@ -164,24 +97,17 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan_u32(uint32_t v)
     return v;
 }
 
-// WIDE: a wave's per-strand total can reach 2^16 (tiles of 1024 words or more): scan the halves apart
-template <bool WIDE>
 __device__ __forceinline__ uint64_t block_exclusive_scan(uint64_t v, uint64_t *wave_tot, uint64_t &total)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint64_t inc;
-    if (WIDE) {
-        inc = (uint64_t)wave_inclusive_scan_u32((uint32_t)v) | ((uint64_t)wave_inclusive_scan_u32((uint32_t)(v >> 32)) << 32);
-    } else {
-        const uint32_t v16 = (uint32_t)v | ((uint32_t)(v >> 32) << 16);  // plus | minus << 16
-        const uint32_t inc16 = wave_inclusive_scan_u32(v16);
-        inc = (uint64_t)(inc16 & 0xffffu) | ((uint64_t)(inc16 >> 16) << 32);
-    }
+    const uint32_t v16 = (uint32_t)v | ((uint32_t)(v >> 32) << 16);  // plus | minus << 16
+    const uint32_t inc16 = wave_inclusive_scan_u32(v16);
+    const uint64_t inc = (uint64_t)(inc16 & 0xffffu) | ((uint64_t)(inc16 >> 16) << 32);
     if (lane == 63) wave_tot[wave] = inc;
     __syncthreads();
     uint64_t base = 0, tot = 0;
 #pragma unroll
-    for (int w = 0; w < EMIT_BLOCK / 64; ++w) {
+    for (int w = 0; w < BLOCK / 64; ++w) {
         const uint64_t t = wave_tot[w];
         if (w < wave) base += t;
         tot += t;
@@ -190,28 +116,13 @@ __device__ __forceinline__ uint64_t block_exclusive_scan(uint64_t v, uint64_t *w
     return base + inc - v;
 }
 
-template <int WPT, int TW>
-__device__ __forceinline__ void thread_masks(uint64_t (*sh)[TW + 2], int l, uint64_t (&mp)[WPT],
-                                             uint64_t (&mm)[WPT])
-{
-    const int w0 = threadIdx.x * WPT;  // tile-local first word of this thread
-#pragma unroll
-    for (int k = 0; k < WPT; ++k) {
-        const int s = 1 + w0 + k;
-        WordTriple t[4];
-#pragma unroll
-        for (int p = 0; p < 4; ++p) t[p] = WordTriple{sh[p][s - 1], sh[p][s], sh[p][s + 1]};
-        word_masks(t[0], t[1], t[2], t[3], l, mp[k], mm[k]);
-    }
-}
-
 // -------------------------------------------------------------- pass 1: count
 // Pure streaming pass: no LDS staging, no barrier before the loads.  A wavefront
 // covers 128 consecutive words (two per lane, one 16-byte load per plane and lane
 // = 64 bytes in flight per lane); the words a lane does not own come from its
 // neighbours by wave shuffles of the DERIVED G / C / void masks, and only lanes 0
 // and 63 touch memory for the words just outside the wave.  A workgroup of four
-// waves produces the counts of two emit tiles (TILE_WORDS = 256 words each).
+// waves produces the counts of one emit tile.
 __device__ __forceinline__ void derive(uint64_t hi, uint64_t lo, uint64_t up, uint64_t ac, uint64_t &g,
                                        uint64_t &c, uint64_t &v)
 {
@@ -220,16 +131,11 @@ __device__ __forceinline__ void derive(uint64_t hi, uint64_t lo, uint64_t up, ui
     v = hi & lo & ~up & ~ac;
 }
 
-__device__ __forceinline__ uint64_t counts_of(uint64_t g_c, uint64_t g_n, uint64_t c_c, uint64_t c_n,
-                                              uint64_t v_p, uint64_t v_c, uint64_t v_n, int l)
-{
-    const uint64_t mplus = ahead(g_c, g_n, 1) & ahead(g_c, g_n, 2) & ~behind(v_p, v_c, l + 5);
-    uint64_t m = c_c & ahead(c_c, c_n, 1) & ~ahead(v_c, v_n, 2) & ~behind(v_p, v_c, 2);
-    if (l > 8) m &= ~ahead(v_c, v_n, l - 8);
-    return (uint64_t)__popcll(mplus) | ((uint64_t)__popcll(m) << 32);
-}
-
-// the same two masks for one word, from the derived G / C / void masks of the word and its neighbours
+// Kept-hit masks of one 64-position word, from the derived G / C / void masks of the word and its neighbours:
+//   plus : (?=.GG) at i  <=>  G(i+1) & G(i+2);  keep  i - l >= 5   (CROPSR.py:419)
+//   minus: (?=CC.) at j  <=>  C(j) & C(j+1) & exists(j+2);
+//          keep  j+3 >= 5  and  j+3+l <= len+10               (CROPSR.py:430)
+// "exists" / "index >= 0" / "index < len" are void tests at fixed distances.
 __device__ __forceinline__ void masks_of(uint64_t g_c, uint64_t g_n, uint64_t c_c, uint64_t c_n, uint64_t v_p,
                                          uint64_t v_c, uint64_t v_n, int l, uint64_t &mplus, uint64_t &mminus)
 {
@@ -246,18 +152,12 @@ __global__ __launch_bounds__(BLOCK) void count_kernel(Planes pl, uint64_t n_word
                                                        uint2 *__restrict__ tile_cnt)
 {
     const int l = LFIX > 0 ? LFIX : l_arg;
-    // a workgroup covers COUNT_WORDS words = COUNT_TPB emit tiles; a wave takes 128 words at a time
-    constexpr int COUNT_WORDS = TILE_WORDS > 512 ? TILE_WORDS : 512;
-    constexpr int COUNT_TPB = COUNT_WORDS / TILE_WORDS;
-    constexpr int REPS = COUNT_WORDS / 512;
-    static_assert(BLOCK == 256 && (TILE_WORDS == 256 || TILE_WORDS % 512 == 0), "count pass geometry");
-    const uint32_t pair = blockIdx.x;
+    static_assert(BLOCK == 256 && TILE_WORDS == 512, "count pass geometry: one workgroup = one emit tile, 128 words per wave");
+    const uint32_t tile = blockIdx.x;
     __shared__ uint64_t wave_tot[BLOCK / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint64_t c = 0;
-#pragma unroll
-    for (int rep = 0; rep < REPS; ++rep) {
-    const uint64_t w0 = (uint64_t)pair * COUNT_WORDS + (uint64_t)(wave * REPS + rep) * 128;  // first word of this pass
+    const uint64_t w0 = (uint64_t)tile * TILE_WORDS + (uint64_t)wave * 128;  // first word of this wave
     if (w0 < n_words_padded) {
         const uint64_t wa = w0 + 2 * lane;  // this lane owns words wa, wa+1
         ulonglong2 q[4];
@@ -281,22 +181,21 @@ __global__ __launch_bounds__(BLOCK) void count_kernel(Planes pl, uint64_t n_word
         uint64_t g_right = __shfl_down(ga, 1, 64), c_right = __shfl_down(ca, 1, 64), v_right = __shfl_down(va, 1, 64);
         if (lane == 0) v_left = ve;
         if (lane == 63) { g_right = ge; c_right = ce; v_right = ve; }
-        c += counts_of(ga, gb, ca, cb, v_left, va, vb, l) + counts_of(gb, g_right, cb, c_right, va, vb, v_right, l);
-    }
+        uint64_t mp, mm;
+        masks_of(ga, gb, ca, cb, v_left, va, vb, l, mp, mm);
+        c = (uint64_t)__popcll(mp) | ((uint64_t)__popcll(mm) << 32);
+        masks_of(gb, g_right, cb, c_right, va, vb, v_right, l, mp, mm);
+        c += (uint64_t)__popcll(mp) | ((uint64_t)__popcll(mm) << 32);
     }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d, 64);
     if (lane == 0) wave_tot[wave] = c;
     __syncthreads();
-    if (threadIdx.x < COUNT_TPB) {
-        const uint64_t tile = (uint64_t)pair * COUNT_TPB + threadIdx.x;
-        if (tile * TILE_WORDS < n_words_padded) {
-            constexpr int WAVES = (BLOCK / 64) / COUNT_TPB;
-            uint64_t t = 0;
+    if (threadIdx.x == 0 && (uint64_t)tile * TILE_WORDS < n_words_padded) {
+        uint64_t t = 0;
 #pragma unroll
-            for (int w = 0; w < WAVES; ++w) t += wave_tot[WAVES * threadIdx.x + w];
-            tile_cnt[tile] = make_uint2((uint32_t)t, (uint32_t)(t >> 32));
-        }
+        for (int w = 0; w < BLOCK / 64; ++w) t += wave_tot[w];
+        tile_cnt[tile] = make_uint2((uint32_t)t, (uint32_t)(t >> 32));
     }
 }
 
@@ -423,11 +322,10 @@ __device__ __forceinline__ uint64_t desc_unpack(uint64_t v)
 // (plus | minus << 32) counts as an AGGREGATE as soon as its block scan is done, and later
 // -- once it knows the sum over all earlier tiles -- as an inclusive PREFIX.  A tile only
 // ever waits for tiles with a lower number, and those have started before it: workgroups are
-// dispatched in index order (or, with CRP_CHAIN_TICKET, numbered by an atomic ticket in start
-// order).  Spins are bounded all the same: on timeout *fail is set, every later look-back
-// gives up at once, and the host repeats the scan with the count / scan / emit sequence
-// instead of using the result -- a wrong assumption about dispatch order would cost time
-// once, never a wrong table.
+// dispatched in index order.  Spins are bounded all the same: on timeout *fail is set, every
+// later look-back gives up at once, and the host repeats the scan with the count / scan / emit
+// sequence instead of using the result -- a wrong assumption about dispatch order would cost
+// time once, never a wrong table.
 constexpr int CHAIN_HEADER_WORDS = 4;
 constexpr int LB_DEPTH = 2;  // descriptors per lane and round trip: 128 tiles (measured: 1 and 2 equal, 4 and 8 slower)
 
@@ -449,25 +347,16 @@ __device__ __forceinline__ void lookback_load(const uint64_t *desc, int64_t base
     }
 }
 
-// Called by ONE wave; `v` holds the descriptors lookback_load fetched earlier for
-// base = tile - 1 (the loads were issued before the wave scored its first hits, so they
-// cost no wait here).  Returns the exclusive prefix in every lane and publishes the
-// inclusive one.
-#if CRP_LB_NOINLINE
-__device__ __attribute__((noinline)) uint64_t lookback_resolve(uint64_t *desc, uint32_t tile, uint64_t total,
-#else
-__device__ __forceinline__ uint64_t lookback_resolve(uint64_t *desc, uint32_t tile, uint64_t total,
-#endif
-                                                     uint64_t (&v)[LB_DEPTH], uint32_t *fail, bool muted,
-                                                     uint32_t timeout_ticks)
+// Called by ONE wave.  Returns the exclusive prefix in every lane and publishes the inclusive one.
+__device__ __forceinline__ uint64_t lookback_resolve(uint64_t *desc, uint32_t tile, uint64_t total, uint32_t *fail,
+                                                     bool muted, uint32_t timeout_ticks)
 {
     const int lane = threadIdx.x & 63;
     if (tile == 0) return 0;
-#if CRP_EXPERIMENT_NO_LB == 1  // TIMING ONLY (wrong tables): what the look-back costs altogether
-    return 0;
-#endif
+    uint64_t v[LB_DEPTH];
     uint64_t excl = 0;
     int64_t base = (int64_t)tile - 1;
+    lookback_load(desc, base, v);
     uint32_t spins = 0;
     uint64_t t_first_stall = 0;  // 100 MHz real-time counter at the first stalled look of this tile
     bool stalled_before = false;
@@ -493,9 +382,6 @@ __device__ __forceinline__ uint64_t lookback_resolve(uint64_t *desc, uint32_t ti
                 }
             }
         }
-#if CRP_EXPERIMENT_NO_LB == 2  // TIMING ONLY (wrong tables): the look-back's loads and analysis, but no waiting
-        if (stall) break;
-#endif
         if (stall) {
             // Wait on that ONE descriptor (a single 8-byte load per look instead of the whole
             // window and its analysis), then read the window again.
@@ -546,16 +432,17 @@ struct ChainArgs {
     uint64_t *totals;   // written by the last tile
     uint64_t *s_excl;   // LDS hand-over from the resolving wave to the workgroup
     uint32_t *s_flag;   // LDS: s_excl is valid
-    uint32_t *s_next;   // LDS: next chunk of 64 list entries to hand out (CRP_DYN_CHUNKS)
     uint32_t tile, n_tiles;
     uint64_t total;     // this tile's (plus | minus << 32)
     bool muted;         // test hook: this tile publishes nothing
     uint32_t timeout_ticks;  // look-back allowance in ticks of the 100 MHz real-time counter
 };
 
-__device__ __forceinline__ void chain_resolve(const ChainArgs &ch, uint64_t (&lb)[LB_DEPTH])
+// ONE wave: look back, hand the tile's exclusive prefix to the workgroup through LDS, raise the flag;
+// the last tile also publishes the table totals
+__device__ __forceinline__ void chain_resolve(const ChainArgs &ch)
 {
-    const uint64_t e = lookback_resolve(ch.desc, ch.tile, ch.total, lb, ch.fail, ch.muted, ch.timeout_ticks);
+    const uint64_t e = lookback_resolve(ch.desc, ch.tile, ch.total, ch.fail, ch.muted, ch.timeout_ticks);
     if ((threadIdx.x & 63) == 0) {
         *ch.s_excl = e;
         if (ch.tile == ch.n_tiles - 1) {
@@ -571,86 +458,160 @@ __device__ __forceinline__ void chain_resolve(const ChainArgs &ch, uint64_t (&lb
             }
         }
     }
+    __hip_atomic_store(ch.s_flag, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-template <int WPT, int TW, int CAP, bool PAM, bool CHAINED>
-__device__ __forceinline__ void emit_rounds(uint64_t (*sh)[TW + 2], uint16_t *list, uint64_t *exp_tab, double *score_tab,
-                                            const uint64_t (&mp)[WPT], const uint64_t (&mm)[WPT], uint64_t ex,
+// exp table + chain-prefix tables as ONE image in global memory, in the order the emit kernel keeps them in LDS
+struct TabsImage {
+    uint64_t exp_tab[256];
+    double score_tab[CRP_SCORE_TAB_N];
+};
+static_assert(sizeof(TabsImage) % 16 == 0, "staged in 16-byte units");
+__device__ const TabsImage CRP_TABS = {{
+#include "exp_table.inc"
+                                       },
+                                       CRP_SCORE_TAB_DATA};
+
+// ---- table stores: buffer stores through per-tile descriptors
+// A tile's rows go to table rows [first, first + n): the descriptor's base is moved to row `first - skip`
+// (`skip` = the tile-local rank of the strand's first row: 0 for '+', n_plus for '-'), so that BOTH strands
+// address their rows with the same per-lane offset, rank * element size, and the hardware's range check
+// (offset + size <= num_records) is the capacity test: a row past the table's end is dropped by the store
+// itself -- no 64-bit address arithmetic and no compare per row.  All of it is scalar (SALU): the inputs
+// are wave-uniform.  num_records saturates at 2^32 - 1 bytes; a tile's own offsets stay below 2^20.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rows_rsrc(void *table, uint64_t cap, uint64_t first, uint32_t skip,
+                                                            uint32_t elem)
+{
+    const uint64_t room = cap > first ? cap - first : 0;
+    uint64_t bytes = room ? (room + skip) * elem : 0;
+    if (bytes > 0xffffffffull) bytes = 0xffffffffull;
+    char *base = reinterpret_cast<char *>(table) + ((int64_t)first - (int64_t)skip) * (int64_t)elem;
+    return __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)(uint32_t)bytes, 0x00020000);
+}
+
+struct TileStores {
+    __amdgpu_buffer_rsrc_t pos[2], score[2], pre[2], seed[2];
+};
+
+constexpr int STORE_AUX = CRP_NT_STORES ? 2 : 0;  // gfx950 cache policy bits of a buffer store: bit 1 = nt
+typedef uint32_t u32x2 __attribute__((__vector_size__(2 * sizeof(uint32_t))));
+__device__ __forceinline__ u32x2 f64_words(double v)
+{
+    u32x2 w;
+    w[0] = (uint32_t)__double2loint(v);
+    w[1] = (uint32_t)__double2hiint(v);
+    return w;
+}
+
+__device__ __forceinline__ uint64_t uniform64(uint64_t v)
+{
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
+           (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+}
+
+template <bool PRE, bool SEEDS>
+__device__ __forceinline__ void tile_stores(TileStores &ts, const HitTables &out, uint64_t off_plus, uint64_t off_minus,
+                                            uint32_t n_plus)
+{
+    ts.pos[0] = rows_rsrc(out.pos_plus, out.cap_plus, off_plus, 0, 4);
+    ts.pos[1] = rows_rsrc(out.pos_minus, out.cap_minus, off_minus, n_plus, 4);
+    ts.score[0] = rows_rsrc(out.score_plus, out.cap_plus, off_plus, 0, 8);
+    ts.score[1] = rows_rsrc(out.score_minus, out.cap_minus, off_minus, n_plus, 8);
+    if (PRE) {
+        ts.pre[0] = rows_rsrc(out.pre_plus, out.cap_plus, off_plus, 0, 8);
+        ts.pre[1] = rows_rsrc(out.pre_minus, out.cap_minus, off_minus, n_plus, 8);
+    }
+    if (SEEDS) {
+        ts.seed[0] = rows_rsrc(out.seed_plus, out.cap_plus, off_plus, 0, 4);
+        ts.seed[1] = rows_rsrc(out.seed_minus, out.cap_minus, off_minus, n_plus, 4);
+    }
+}
+
+// ---- hit list: rank -> tile-local position, built by the lanes that own the mask words
+// Appends the positions of the set bits of m (ascending) as 16-bit entries at LDS byte address `addr`, which
+// advances past them.  `base` = tile-local position of bit 0 of m (a multiple of 32, so OR = ADD).
+// The loop in ISA: find-first-bit, clear-lowest (2), position, address, compare-into-exec -- 6 VALU per trip
+// (the compiler's version of the same C loop carries a separate trip counter and re-derives `base | 32`: 7-8 per
+// trip, +1.7 % on the kernel).  A wave runs to the
+// largest popcount among its lanes; lanes that are done sit out with their exec bit cleared.
+__device__ __forceinline__ void peel32(uint32_t m, uint32_t base, uint32_t &addr)
+{
+    uint32_t b, t;
+    uint64_t saved;
+    asm volatile(
+        "s_mov_b64 %[saved], exec\n\t"
+        "v_cmpx_ne_u32_e32 vcc, 0, %[m]\n\t"
+        "s_cbranch_execz 2f\n"
+        "1:\n\t"
+        "v_ffbl_b32_e32 %[b], %[m]\n\t"
+        "v_add_u32_e32 %[t], -1, %[m]\n\t"
+        "v_or_b32_e32 %[b], %[b], %[base]\n\t"
+        "v_and_b32_e32 %[m], %[t], %[m]\n\t"
+        "ds_write_b16 %[addr], %[b]\n\t"
+        "v_add_u32_e32 %[addr], 2, %[addr]\n\t"
+        "v_cmpx_ne_u32_e32 vcc, 0, %[m]\n\t"
+        "s_cbranch_execnz 1b\n"
+        "2:\n\t"
+        "s_mov_b64 exec, %[saved]"
+        : [m] "+v"(m), [addr] "+v"(addr), [b] "=&v"(b), [t] "=&v"(t), [saved] "=&s"(saved)
+        : [base] "v"(base)
+        : "vcc", "memory");
+}
+
+template <bool PAM, bool CHAINED, bool PRE, bool SEEDS>
+__device__ __forceinline__ void emit_rounds(uint64_t (*sh)[TILE_WORDS + 2], uint16_t *list, uint64_t *exp_tab, double *score_tab,
+                                            const uint64_t (&mp)[TILE_WPT], const uint64_t (&mm)[TILE_WPT], uint64_t ex,
                                             uint32_t n_plus, uint32_t n_minus, int l, uint32_t tile_pos,
                                             uint64_t off_plus, uint64_t off_minus, const HitTables &out,
                                             const ChainArgs &ch);
 
 // CHAINED = true : single pass.  Table offsets come from the decoupled look-back above;
-//                  `chain` holds a 32-byte header -- tile ticket (u32), fail flag (u32), the two
+//                  `chain` holds a 32-byte header -- unused (u32), fail flag (u32), the two
 //                  table totals (u64 each, written by the last tile), a device pointer to a pinned
 //                  host copy of the first three words (or 0; never touched by the kernel) -- then one
 //                  descriptor per tile; it must be all zero at launch.  Launches alternate
 //                  between two such buffers and every tile zeroes its slot of the other one
 //                  (`chain_next`), so no memset runs between scans.  The tile
-//                  publishes its counts right after the block scan, builds its hit list
-//                  and scores the first hit of every lane BEFORE it needs its offsets, so
-//                  the look-back's round trip hides under that work.  Stores are
-//                  bounds-checked against the table capacities, totals are published by
-//                  the last tile.
+//                  publishes its counts right after the block scan -- reached without a barrier or an
+//                  LDS round trip, at raised wave priority: later tiles wait for exactly that --, then
+//                  stages the scorer's tables and builds its hit list; wave 0 resolves the prefix
+//                  before it scores anything and raises an LDS flag, the other waves score their
+//                  first hits meanwhile and look at the flag only when those are ready to be stored.
+//                  Rows past the table capacities are dropped by the stores' range check, totals are
+//                  published by the last tile.
 // CHAINED = false: third pass of the count / scan / emit sequence (offsets from tile_off).
-template <int WPT, bool CHAINED, int LFIX>
-__global__ __launch_bounds__(EMIT_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8))) void emit_kernel(Planes pl, uint64_t n_words_padded, int l_arg,
-                                                      const uint2 *__restrict__ tile_off, uint64_t *chain,
-                                                      uint64_t *__restrict__ chain_next, HitTables out,
-                                                      uint32_t mute_tile, uint32_t timeout_ticks)
+// PRE: the pre-sigmoid column is written too.  SEEDS: so is the off-target scan's raw seed word.
+template <bool CHAINED, int LFIX, bool PRE, bool SEEDS>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8))) void emit_kernel(
+    Planes pl, uint64_t n_words_padded, int l_arg, const uint2 *__restrict__ tile_off, uint64_t *chain,
+    uint64_t *__restrict__ chain_next, HitTables out, uint32_t mute_tile, uint32_t timeout_ticks)
 {
     const int l = LFIX > 0 ? LFIX : l_arg;
-    constexpr int TW = EMIT_BLOCK * WPT;
-    constexpr int CAP = CRP_LIST_CAP_PER_WPT * WPT;  // list entries per round; typical tiles need one round
+    constexpr int TW = TILE_WORDS;
     __shared__ uint64_t sh[4][TW + 2];
-    // exp table (256 words) + chain-prefix tables of the scorer, one block: until the hit list is built the
-    // same bytes are the list build's work-list scratch (CRP_LIST_COMPACT)
+    // exp table (256 words) + chain-prefix tables of the scorer
     __shared__ uint64_t tabs[256 + CRP_SCORE_TAB_N];
     uint64_t *const exp_tab = tabs;
     double *const score_tab = reinterpret_cast<double *>(tabs + 256);
-    __shared__ uint64_t wave_tot[EMIT_BLOCK / 64];
+    __shared__ uint64_t wave_tot[BLOCK / 64];
     __shared__ uint64_t s_excl;
     __shared__ uint32_t s_flag;
-    __shared__ uint32_t s_next;
-#if CRP_CHAIN_TICKET
-    __shared__ uint32_t s_tile;
-#endif
-    __shared__ uint16_t list[CAP];
-#if CRP_EXPERIMENT_LDS_PAD  // TIMING ONLY: occupancy sensitivity (bytes of unused LDS per workgroup)
-    __shared__ uint8_t lds_pad[CRP_EXPERIMENT_LDS_PAD];
-    if (n_words_padded == 12345) lds_pad[threadIdx.x] = 1;
-#endif
+    __shared__ uint16_t list[LIST_CAP];
 
     const int tid = threadIdx.x;
-    uint32_t tile = blockIdx.x;
-    if (CHAINED) {
-#if CRP_CHAIN_TICKET
-        // tile ids in START order, whatever order the hardware dispatches workgroups in
-        if (tid == 0) {
-            s_flag = 0;
-            s_tile = atomicAdd(reinterpret_cast<uint32_t *>(chain), 1u);
-        }
-        __syncthreads();
-        tile = s_tile;
-#else
-        if (tid == 0) s_flag = 0;
-#endif
-    }
+    const uint32_t tile = blockIdx.x;  // dispatch order = index order: every tile this one waits for has started
+    if (CHAINED && tid == 0) s_flag = 0;
     const uint64_t t0 = (uint64_t)tile * TW;
-#if CRP_PRIO_UNTIL_PUBLISH
     // single-launch mode: later tiles wait for this tile's counts, so the short phase that produces
-    // them (stage, masks, block scan) runs ahead of the scoring of the other workgroups on this CU
-    if (CHAINED) __builtin_amdgcn_s_setprio(CRP_PRIO_LEVEL);
-#endif
-#if CRP_STREAM_MASKS
+    // them (loads, masks, block scan) runs ahead of the scoring of the other workgroups on this CU
+    if (CHAINED) __builtin_amdgcn_s_setprio(3);
     // Every thread loads the two words it owns of each plane (one 16-byte load per plane) and derives
     // its hit masks from those REGISTERS, taking the neighbouring words' G / C / void masks from the
     // adjacent lanes by wave shuffles (lanes 0 and 63 read the word just outside the wave from
     // memory) -- the count pass's scheme.  The words also go to LDS, but only the window extraction
     // after the block scan reads them there: no barrier and no LDS round trip stand between the loads
-    // and the tile's counts, which in single-launch mode is what later tiles wait for.
-    static_assert(WPT == 2 && EMIT_BLOCK % 64 == 0, "streamed masks: two words per thread");
-    uint64_t mp[WPT], mm[WPT];
+    // and the tile's counts.
+    uint64_t mp[TILE_WPT], mm[TILE_WPT];
     {
         const int lane = tid & 63;
         const uint64_t wa = t0 + 2 * (uint64_t)tid;          // this thread owns words wa, wa + 1
@@ -688,36 +649,17 @@ __global__ __launch_bounds__(EMIT_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8
         masks_of(ga, gb, ca, cb, v_left, va, vb, l, mp[0], mm[0]);
         masks_of(gb, g_right, cb, c_right, va, vb, v_right, l, mp[1], mm[1]);
     }
-#else
-    stage_tile<TW>(pl, t0, n_words_padded, sh);
-#endif
-#if !CRP_LIST_COMPACT
-    auto stage_tables = [&]() {
-        for (int k = tid; k < 256; k += EMIT_BLOCK) exp_tab[k] = CRP_EXP_TAB[k];
-        if (LFIX == 20)
-            for (int k = tid; k < CRP_SCORE_TAB_N; k += EMIT_BLOCK) score_tab[k] = CRP_SCORE_TAB[k];
-    };
-#endif
-#if !CRP_TABLES_AFTER_PUBLISH && !CRP_LIST_COMPACT
-    stage_tables();
-#endif
-#if !CRP_STREAM_MASKS
-    __syncthreads();
-
-    uint64_t mp[WPT], mm[WPT];
-    thread_masks<WPT, TW>(sh, l, mp, mm);
-#endif
     uint64_t c = 0;
 #pragma unroll
-    for (int k = 0; k < WPT; ++k) c += (uint64_t)__popcll(mp[k]) | ((uint64_t)__popcll(mm[k]) << 32);
+    for (int k = 0; k < TILE_WPT; ++k) c += (uint64_t)__popcll(mp[k]) | ((uint64_t)__popcll(mm[k]) << 32);
     uint64_t total;
-    const uint64_t ex = block_exclusive_scan<(EMIT_BLOCK * WPT >= 1024)>(c, wave_tot, total);
+    const uint64_t ex = block_exclusive_scan(c, wave_tot, total);
     const uint32_t n_plus = (uint32_t)total, n_minus = (uint32_t)(total >> 32);
     const uint32_t n_all = n_plus + n_minus;
     uint64_t off_plus = 0, off_minus = 0;
     ChainArgs ch{};
     if (CHAINED) {
-        ch = ChainArgs{chain + CHAIN_HEADER_WORDS, reinterpret_cast<uint32_t *>(chain) + 1, chain + 1, &s_excl, &s_flag, &s_next,
+        ch = ChainArgs{chain + CHAIN_HEADER_WORDS, reinterpret_cast<uint32_t *>(chain) + 1, chain + 1, &s_excl, &s_flag,
                        tile, gridDim.x, total, tile == mute_tile, timeout_ticks};
         if (tid == 0) {
             // mute_tile (normally none): a tile that never publishes, to exercise the time-out path
@@ -726,19 +668,11 @@ __global__ __launch_bounds__(EMIT_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8
             chain_next[CHAIN_HEADER_WORDS + tile] = 0;
             if (tile == 0) chain_next[0] = chain_next[1] = chain_next[2] = 0;  // (word 3 is the host's)
         }
-#if CRP_PRIO_UNTIL_PUBLISH == 1
         __builtin_amdgcn_s_setprio(0);
-#elif CRP_PRIO_UNTIL_PUBLISH == 2  // the wave that will resolve the tile's prefix keeps its priority until it has
-        if (tid >= 64) __builtin_amdgcn_s_setprio(0);
-#endif
         if (n_all == 0) {
             // nothing to store: the aggregate (0) is all later tiles need; only the last tile
             // must still learn its prefix, to publish the totals
-            if (tile == ch.n_tiles - 1 && tid < 64) {
-                uint64_t lb[LB_DEPTH];
-                lookback_load(ch.desc, (int64_t)tile - 1, lb);
-                chain_resolve(ch, lb);
-            }
+            if (tile == ch.n_tiles - 1 && tid < 64) chain_resolve(ch);
             return;
         }
     } else {
@@ -747,167 +681,106 @@ __global__ __launch_bounds__(EMIT_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8
         off_minus = off.y;
         if (n_all == 0) return;
     }
-#if CRP_EXPERIMENT_STOP == 1  // TIMING ONLY: load + masks + block scan + publish, nothing else
-    if (CHAINED) return;
-#endif
-#if CRP_TABLES_AFTER_PUBLISH && !CRP_LIST_COMPACT
-    // the scorer's tables are first read after the barrier that follows the hit-list build
-    stage_tables();
-#endif
-    emit_rounds<WPT, TW, CAP, LFIX == 20, CHAINED>(sh, list, exp_tab, score_tab, mp, mm, ex, n_plus, n_minus, l, (uint32_t)(t0 * 64),
-                                                   off_plus, off_minus, out, ch);
+    // the scorer's tables are first read after the barrier that follows the hit-list build; staging them
+    // only now keeps them out of the way of the counts that later tiles wait for (-3.5 %)
+    // The scorer's tables (exp: 2 KiB; chain prefixes: 7.5 KiB, l = 20 only) are first read after the barrier that
+    // follows the hit-list build; staging them only now keeps them out of the way of the counts that later tiles wait
+    // for (-3.5 %).  (Staging by LDS-DMA, or requesting the words earlier and writing them here, both measured
+    // slower: profiles/EXPERIMENTS.md.)
+    for (int k = tid; k < 256; k += BLOCK) exp_tab[k] = CRP_TABS.exp_tab[k];
+    if (LFIX == 20)
+        for (int k = tid; k < CRP_SCORE_TAB_N; k += BLOCK) score_tab[k] = CRP_TABS.score_tab[k];
+    emit_rounds<LFIX == 20, CHAINED, PRE, SEEDS>(sh, list, exp_tab, score_tab, mp, mm, ex, n_plus, n_minus, l, (uint32_t)(t0 * 64),
+                                                 off_plus, off_minus, out, ch);
 }
 
-// Compact the kept hits of one staged tile and score them, CAP list entries per round.
-template <int WPT, int TW, int CAP, bool PAM, bool CHAINED>
-__device__ __forceinline__ void emit_rounds(uint64_t (*sh)[TW + 2], uint16_t *list, uint64_t *exp_tab, double *score_tab,
-                                            const uint64_t (&mp)[WPT], const uint64_t (&mm)[WPT], uint64_t ex,
+// Compact the kept hits of one staged tile and score them, LIST_CAP list entries per round.
+template <bool PAM, bool CHAINED, bool PRE, bool SEEDS>
+__device__ __forceinline__ void emit_rounds(uint64_t (*sh)[TILE_WORDS + 2], uint16_t *list, uint64_t *exp_tab, double *score_tab,
+                                            const uint64_t (&mp)[TILE_WPT], const uint64_t (&mm)[TILE_WPT], uint64_t ex,
                                             uint32_t n_plus, uint32_t n_minus, int l, uint32_t tile_pos,
                                             uint64_t off_plus, uint64_t off_minus, const HitTables &out,
                                             const ChainArgs &ch)
 {
+    constexpr uint32_t CAP = LIST_CAP;
     const int tid = threadIdx.x;
     const uint32_t n_all = n_plus + n_minus;
-    bool resolved = !CHAINED;  // single pass: this lane has not picked up off_plus / off_minus yet
+    TileStores ts;
+    bool resolved = !CHAINED;  // single pass: this wave has not picked up the tile's table offsets yet
+    if (!CHAINED) tile_stores<PRE, SEEDS>(ts, out, uniform64(off_plus), uniform64(off_minus), n_plus);
     // A tile with more kept hits than the list holds takes several rounds.  When each STRAND's hits fit (the usual
     // overflow: an unmasked tile of a GC-rich genome has ~1 700 + 1 700 of them), the rounds are the two strands:
     // each round peels only its own strand's masks, without capacity tests -- one list build's work in all, not two.
-    const bool by_strand = CRP_LIST_BY_STRAND && n_all > (uint32_t)CAP && n_plus <= (uint32_t)CAP && n_minus <= (uint32_t)CAP;
+    const bool by_strand = n_all > CAP && n_plus <= CAP && n_minus <= CAP;
+    const uint32_t list_lds = (uint32_t)(uintptr_t)list;  // LDS byte address of the list
     uint32_t hi_rank = 0;
     for (uint32_t lo_rank = 0; lo_rank < n_all; lo_rank = hi_rank) {
-        hi_rank = by_strand ? (lo_rank == 0 ? n_plus : n_all) : min(lo_rank + (uint32_t)CAP, n_all);
+        hi_rank = by_strand ? (lo_rank == 0 ? n_plus : n_all) : min(lo_rank + CAP, n_all);
         if (lo_rank) __syncthreads();  // previous round's readers are done
         // ---- compact: rank -> tile-local position, '+' hits first, then '-'
-        // A tile whose hits all fit the list (the normal case; uniform over the workgroup) writes
-        // without the per-entry capacity test.
-        auto compact = [&](auto check, auto with_plus, auto with_minus) {
-            constexpr bool CHECK = decltype(check)::value;
-            constexpr bool PLUS = decltype(with_plus)::value, MINUS = decltype(with_minus)::value;
-            uint32_t rp = (uint32_t)ex - lo_rank;                    // rank of next '+' hit, window-relative
-            uint32_t rm = n_plus + (uint32_t)(ex >> 32) - lo_rank;  // same for '-'
+        const uint32_t rp0 = (uint32_t)ex - lo_rank;                    // window-relative rank of this thread's first '+' hit
+        const uint32_t rm0 = n_plus + (uint32_t)(ex >> 32) - lo_rank;  // same for '-'
+        if (n_all <= CAP || by_strand) {
+            // every entry of this round fits: no per-entry capacity test
+            const bool with_plus = !by_strand || lo_rank == 0, with_minus = !by_strand || lo_rank != 0;
+            uint32_t ap = list_lds + 2 * rp0, am = list_lds + 2 * rm0;
 #pragma unroll
-            for (int k = 0; k < WPT; ++k) {
-                const uint32_t wbase = (uint32_t)(tid * WPT + k) * 64u;
-                // 32-bit halves: find-first-bit, clear-lowest and the compare are one
-                // VALU instruction each instead of two
-                if (PLUS) {
-#pragma unroll
-                    for (int half = 0; half < 2; ++half) {
-                        uint32_t m = (uint32_t)(mp[k] >> (32 * half));
-                        while (m) {
-                            const uint32_t b = __builtin_ctz(m);
-                            m &= m - 1;
-                            if (!CHECK || rp < (uint32_t)CAP) list[rp] = (uint16_t)(wbase + 32 * half + b);
-                            ++rp;
-                        }
-                    }
+            for (int k = 0; k < TILE_WPT; ++k) {
+                const uint32_t wbase = (uint32_t)(tid * TILE_WPT + k) * 64u;
+                if (with_plus) {
+                    peel32((uint32_t)mp[k], wbase, ap);
+                    peel32((uint32_t)(mp[k] >> 32), wbase + 32, ap);
                 }
-                if (MINUS) {
-#pragma unroll
-                    for (int half = 0; half < 2; ++half) {
-                        uint32_t m = (uint32_t)(mm[k] >> (32 * half));
-                        while (m) {
-                            const uint32_t b = __builtin_ctz(m);
-                            m &= m - 1;
-                            if (!CHECK || rm < (uint32_t)CAP) list[rm] = (uint16_t)(wbase + 32 * half + b);
-                            ++rm;
-                        }
-                    }
+                if (with_minus) {
+                    peel32((uint32_t)mm[k], wbase, am);
+                    peel32((uint32_t)(mm[k] >> 32), wbase + 32, am);
                 }
             }
-        };
-#if CRP_LIST_COMPACT
-        // Balanced build (a tile whose hits all fit the list).  The peeling loops above run to the wave's
-        // MAXIMUM popcount while most lanes have nothing left -- soft-masking clusters the hits, half the lanes
-        // of a wave own no hit at all.  So the non-empty 32-bit halves are first compacted into a work list
-        // (one 8-byte item each: mask, position base, rank base; slots from the compare's own lane mask +
-        // v_mbcnt, no loop), and the peeling then runs over ITEMS, 64 at a time: no lane idles on an empty
-        // half.  Scratch = the scorer's table block of LDS, which is staged only after the list is complete;
-        // one word of every thread per pass, so a wave never has more than 256 items (its share holds 304).
-        auto compact_balanced = [&]() {
-            const int lane = tid & 63;
-            constexpr uint32_t PER_WAVE = (256 + CRP_SCORE_TAB_N) / (EMIT_BLOCK / 64);
-            static_assert(PER_WAVE >= 256, "work-list scratch: 4 halves x 64 lanes per pass");
-            uint2 *const scr = reinterpret_cast<uint2 *>(exp_tab) + (tid >> 6) * PER_WAVE;
-            uint32_t rp = (uint32_t)ex;                    // rank of this thread's next '+' hit
-            uint32_t rm = n_plus + (uint32_t)(ex >> 32);  // same for '-'
+        } else {
+            // rare (a tile with more than LIST_CAP hits on ONE strand: poly-G and the like): windows of CAP ranks
+            uint32_t rp = rp0, rm = rm0;
 #pragma unroll
-            for (int k = 0; k < WPT; ++k) {
-                const uint32_t wbase = (uint32_t)(tid * WPT + k) * 64u;
-                uint32_t n_items = 0;  // wave-uniform
-                auto push = [&](uint32_t m, uint32_t pbase, uint32_t r) {
-                    const uint64_t nz = __ballot(m != 0);
-                    const uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(nz >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nz, n_items));
-                    if (m) scr[slot] = make_uint2(m, pbase | (r << 16));
-                    n_items += (uint32_t)__popcll(nz);
-                };
-                const uint32_t p0 = (uint32_t)mp[k], p1 = (uint32_t)(mp[k] >> 32);
-                const uint32_t m0 = (uint32_t)mm[k], m1 = (uint32_t)(mm[k] >> 32);
-                push(p0, wbase, rp);
-                rp += __popc(p0);
-                push(p1, wbase + 32, rp);
-                rp += __popc(p1);
-                push(m0, wbase, rm);
-                rm += __popc(m0);
-                push(m1, wbase + 32, rm);
-                rm += __popc(m1);
-                // (LDS serves a wave's accesses in order: the items are there when they are read back)
-                for (uint32_t b = 0; b < n_items; b += 64) {
-                    uint2 it = make_uint2(0, 0);
-                    if (b + lane < n_items) it = scr[b + lane];
-                    uint32_t m = it.x;
-                    const uint32_t pbase = it.y & 0xffffu;
-                    uint16_t *dst = list + (it.y >> 16);
-                    while (m) {
-                        const uint32_t bit = __builtin_ctz(m);
-                        m &= m - 1;
-                        *dst++ = (uint16_t)(pbase + bit);
-                    }
-                }
+            for (int k = 0; k < TILE_WPT; ++k) {
+                const uint32_t wbase = (uint32_t)(tid * TILE_WPT + k) * 64u;
+                for (uint64_t m = mp[k]; m; m &= m - 1, ++rp)
+                    if (rp < CAP) list[rp] = (uint16_t)(wbase + __builtin_ctzll(m));
+                for (uint64_t m = mm[k]; m; m &= m - 1, ++rm)
+                    if (rm < CAP) list[rm] = (uint16_t)(wbase + __builtin_ctzll(m));
             }
-        };
-        if (n_all <= (uint32_t)CAP) compact_balanced();
-        else compact(std::true_type{}, std::true_type{}, std::true_type{});
-#elif CRP_LIST_FASTPATH
-        if (n_all <= (uint32_t)CAP) compact(std::false_type{}, std::true_type{}, std::true_type{});
-        else if (by_strand && lo_rank == 0) compact(std::false_type{}, std::true_type{}, std::false_type{});
-        else if (by_strand) compact(std::false_type{}, std::false_type{}, std::true_type{});
-        else compact(std::true_type{}, std::true_type{}, std::true_type{});
-#else
-        compact(std::true_type{}, std::true_type{}, std::true_type{});
-#endif
-        if (CHAINED && tid == 0) *ch.s_next = 0;  // chunk counter of this round (read after the barrier below)
-#if CRP_EXPERIMENT_STOP == 2  // TIMING ONLY: ... + the hit list
-        if (CHAINED) return;
-#endif
-        __syncthreads();
-#if CRP_LIST_COMPACT
-        if (lo_rank == 0) {  // the list is complete, its scratch is free: now the scorer's tables move in
-            for (int k = tid; k < 256; k += EMIT_BLOCK) exp_tab[k] = CRP_EXP_TAB[k];
-            if (PAM)
-                for (int k = tid; k < CRP_SCORE_TAB_N; k += EMIT_BLOCK) score_tab[k] = CRP_SCORE_TAB[k];
-            __syncthreads();
         }
-#endif
+        __syncthreads();
         // ---- one hit per lane: extract the 30-window, score, store
         const uint32_t n_round = hi_rank - lo_rank;
         struct Hit {
-            uint32_t e, r;
+            uint32_t e, r, seed;
             double pre, score;
         };
-        auto compute = [&](uint32_t k) -> Hit {  // list entry k of this round
-            Hit hit{list[k], lo_rank + k, -1.0, -1.0};
-            const bool minus = hit.r >= n_plus;
+        // what a row needs from LDS before anything can be computed: its list entry and the four 31-bit windows
+        struct Fetched {
+            uint32_t e, r, h, w, u, a;
+        };
+        auto fetch = [&](uint32_t k) -> Fetched {  // list entry k of this round
+            Fetched f{list[k], lo_rank + k, 0, 0, 0, 0};
             // '+': long_sequence = T(s[i-l-5 : i+5])       (CROPSR.py:421)
             // '-': long_sequence = T(R(s[j-2 : j+l+8]))     (CROPSR.py:432)
+            const uint32_t q = 64u + f.e - (f.r >= n_plus ? 2u : (uint32_t)(l + 5));
+            if (l >= 20) {
+                f.h = window31(sh[0], q);
+                f.w = window31(sh[1], q);
+                f.u = window31(sh[2], q);
+                f.a = window31(sh[3], q);
+            }
+            return f;
+        };
+        auto score = [&](const Fetched &f) -> Hit {
+            Hit hit{f.e, f.r, SEED_RAW_NONE, -1.0, -1.0};
+            const bool minus = hit.r >= n_plus;
             // Python clamps the slice at len(s); the row is scored iff the result
             // has exactly 30 characters (CROPSR.py:458,466): for l = 20 a complete
             // window, for l > 20 a window cut to 30 by the end of the string, for
             // l < 20 never.
-            const uint32_t q = 64u + hit.e - (minus ? 2u : (uint32_t)(l + 5));
             if (l >= 20) {
-                uint32_t h = window31(sh[0], q), w = window31(sh[1], q);
-                uint32_t u = window31(sh[2], q), a = window31(sh[3], q);
+                uint32_t h = f.h, w = f.w, u = f.u, a = f.a;
                 const uint32_t vd = h & w & ~u & ~a;  // void positions
                 const bool complete = (vd & 0x3fffffffu) == 0 && (l == 20 || (vd >> 30));
                 h &= 0x3fffffffu;
@@ -922,172 +795,77 @@ __device__ __forceinline__ void emit_rounds(uint64_t (*sh)[TW + 2], uint16_t *li
                     w = reverse30(w ^ u);
                     valid = reverse30(valid);
                 }
+                if (SEEDS) {
+                    // Off-target scan (crp_offtarget.hip): seed character k (k = 0 next to the PAM) is character k of the
+                    // `sequence` column -- '+': s[i-1-k] = window bit l+4-k = bit 25-l+k after the reversal; '-': s[j+3+k]
+                    // = window bit 5+k.  For l = 20 (the only length this variant is built for) both are bit 5+k.
+                    static_assert(!SEEDS || PAM, "seed words are emitted by the l = 20 variant only");
+                    if (((valid >> 5) & 0xfffu) == 0xfffu) hit.seed = (((h >> 5) & 0xfffu) << 12) | ((w >> 5) & 0xfffu);
+                }
                 if (complete) {
                     const uint32_t mG = h & w & valid, mC = h & ~w & valid;
                     const uint32_t mT = ~h & w & valid, mA = ~h & ~w & valid;
-#if defined(CRP_EXPERIMENT_NO_SCORE)
-                    hit.score = __hiloint2double((int)(mA ^ mT), (int)(mC ^ mG));
-#else
                     crp_score_masks<PAM>(mA, mT, mC, mG, exp_tab, score_tab, hit.pre, hit.score);
-#endif
                 }
             }
             return hit;
         };
         auto store = [&](const Hit &hit) {
-#if CRP_EXPERIMENT_NO_STORE  // TIMING ONLY: nothing is written unless an impossible score turns up
-            if (hit.score != 12345.0) return;
-#endif
             const uint32_t pos = tile_pos + hit.e;
-            if (hit.r >= n_plus) {
-                const uint64_t o = off_minus + (hit.r - n_plus);
-                if (o < out.cap_minus) {
-                    CRP_TABLE_STORE(&out.pos_minus[o], pos);
-                    CRP_TABLE_STORE(&out.score_minus[o], hit.score);
-                    if (out.pre_minus) CRP_TABLE_STORE(&out.pre_minus[o], hit.pre);
-                }
-            } else {
-                const uint64_t o = off_plus + hit.r;
-                if (o < out.cap_plus) {
-                    CRP_TABLE_STORE(&out.pos_plus[o], pos);
-                    CRP_TABLE_STORE(&out.score_plus[o], hit.score);
-                    if (out.pre_plus) CRP_TABLE_STORE(&out.pre_plus[o], hit.pre);
+            const int o4 = (int)(hit.r * 4u), o8 = (int)(hit.r * 8u);
+            const bool minus = hit.r >= n_plus;
+            // Two guarded regions, one per strand, NOT an if / else: the compiler would fold an if / else into one store
+            // through a per-lane SELECTED descriptor, which no longer lives in SGPRs (a "waterfall" loop per store).
+            // A 64-row chunk is of one strand except at the seam, so one of the regions is normally skipped (execz).
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                if (minus == (st == 1)) {
+                    __builtin_amdgcn_raw_buffer_store_b32(pos, ts.pos[st], o4, 0, STORE_AUX);
+                    __builtin_amdgcn_raw_buffer_store_b64(f64_words(hit.score), ts.score[st], o8, 0, STORE_AUX);
+                    if (PRE) __builtin_amdgcn_raw_buffer_store_b64(f64_words(hit.pre), ts.pre[st], o8, 0, STORE_AUX);
+                    if (SEEDS) __builtin_amdgcn_raw_buffer_store_b32(hit.seed, ts.seed[st], o4, 0, STORE_AUX);
+                    // (distinct tails keep the optimiser from sinking the two regions' stores into one)
+                    if (st == 0) asm volatile("; '+' rows stored" ::: "memory");
+                    else asm volatile("; '-' rows stored" ::: "memory");
                 }
             }
         };
-        if (!CHAINED) {
-            for (uint32_t k = tid; k < n_round; k += EMIT_BLOCK) store(compute(k));
-        } else {
-            // Single pass: the table offsets are not known yet.  Every wave scores its first
-            // hits; wave 0 then walks the descriptors (its round trip is exposed to that wave
-            // only) and raises the LDS flag; the other waves go on scoring and store one
-            // iteration behind, so they look at the flag one full iteration (~4 us) later and
-            // normally find it set.  No workgroup barrier is involved.
-            auto settle = [&]() {
-                if (resolved) return;
-                while (__hip_atomic_load(ch.s_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0)
-                    __builtin_amdgcn_s_sleep(1);
-                const uint64_t e = *ch.s_excl;
-                off_plus = e & 0xffffffffull;
-                off_minus = e >> 32;
-                resolved = true;
-            };
-#if CRP_DYN_CHUNKS
-            // The waves draw chunks of 64 list entries from a counter in LDS instead of owning every
-            // fourth one: whatever time wave 0 spends in the look-back (round trip + waiting for
-            // predecessors), the other three take over its share of the hits, so the look-back
-            // lengthens no wave's critical path; the tail of the list is balanced the same way.
-            const int lane = tid & 63;
-            auto grab = [&]() -> uint32_t {
-                uint32_t c = 0;
-                if (lane == 0) c = atomicAdd(ch.s_next, 1u);
-                return (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
-            };
-            auto look_back = [&]() {
-                uint64_t lb[LB_DEPTH];
-                lookback_load(ch.desc, (int64_t)ch.tile - 1, lb);
-                chain_resolve(ch, lb);
-                __hip_atomic_store(ch.s_flag, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            };
-            const bool scanner = lo_rank == 0 && tid < 64;  // wave-uniform: once per tile
-#if CRP_LB_FIRST
-            if (scanner) look_back();
-#endif
-            uint32_t c = grab();
-            bool have_cur = false, first = true;
-            Hit cur{};
-            while (c * 64u < n_round) {
-                const uint32_t k = c * 64u + (uint32_t)lane;
-                Hit nxt{0xffffffffu, 0, -1.0, -1.0};
-                if (k < n_round) nxt = compute(k);
-                c = grab();  // (the atomic's round trip hides under the stores below)
-#if !CRP_LB_FIRST
-                if (scanner && first) look_back();
-#endif
-                first = false;
-                if (have_cur) {
-                    settle();
-                    if (cur.e != 0xffffffffu) store(cur);
-                }
-                cur = nxt;
-                have_cur = true;
-            }
-#if !CRP_LB_FIRST
-            if (scanner && first) look_back();  // wave 0 drew no chunk at all
-#endif
-            if (have_cur) {
-                settle();
-                if (cur.e != 0xffffffffu) store(cur);
-            }
-#else
-#if CRP_ROTATE_WAVES
-            // The workgroup's slot (LDS, wave slots) is held until its LAST wave is done, and wave 0 also
-            // resolves the tile's prefix.  So wave 0 takes the chunks of 64 rows nobody would miss: waves
-            // 1, 2, 3 own chunks 0, 1, 2 (mod 4) and wave 0 chunk 3 -- when the row count is not a multiple
-            // of 256 it is wave 0 that has one chunk less, not one more.
-            uint32_t k = (uint32_t)(tid & 63) | ((((uint32_t)tid >> 6) + (EMIT_BLOCK / 64 - 1)) % (EMIT_BLOCK / 64)) << 6;
-#else
-            uint32_t k = tid;
-#endif
+        // Rows k, k + 256, ... of one lane.  `before_first_store` runs once, after the first row is scored: from the
+        // second row on a row is stored as soon as it is scored -- nothing is parked in registers.  (Issuing the next
+        // row's LDS reads ahead of the current row's arithmetic was measured: +4 %, profiles/EXPERIMENTS.md.)
+        auto run_rows = [&](uint32_t k, auto before_first_store) {
             const bool any = k < n_round;
-            Hit cur{};
-#if CRP_LB_FIRST_STATIC
-            // the whole look-back BEFORE the wave scores anything (nothing of the scorer is live then)
-            if (lo_rank == 0 && tid < 64) {
-                uint64_t lb0[LB_DEPTH];
-                lookback_load(ch.desc, (int64_t)ch.tile - 1, lb0);
-                chain_resolve(ch, lb0);
-                __hip_atomic_store(ch.s_flag, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-#if CRP_PRIO_UNTIL_PUBLISH == 2
-                __builtin_amdgcn_s_setprio(0);
-#endif
-            }
-#endif
-#if CRP_LB_EARLY
-            // the descriptors are requested BEFORE the wave scores its first hits and looked at after:
-            // their round trip hides under that work (a snapshot that turns out too old costs a second one)
-            uint64_t lb[LB_DEPTH];
-            if (lo_rank == 0 && tid < 64) lookback_load(ch.desc, (int64_t)ch.tile - 1, lb);
-#endif
-            if (any) cur = compute(k);
-            if (!CRP_LB_FIRST_STATIC && lo_rank == 0 && tid < 64) {  // wave-uniform: once per tile
-#if !CRP_LB_EARLY
-                uint64_t lb[LB_DEPTH];
-                lookback_load(ch.desc, (int64_t)ch.tile - 1, lb);
-#endif
-                chain_resolve(ch, lb);
-                __hip_atomic_store(ch.s_flag, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-#if CRP_PRIO_UNTIL_PUBLISH == 2
-                __builtin_amdgcn_s_setprio(0);
-#endif
-            }
+            Hit first{};
+            if (any) first = score(fetch(k));
+            before_first_store(any);
             if (any) {
-#if CRP_PIPE_UNROLL
-                // two iterations per trip with the roles of the two parked hits swapped: no register copies
-                Hit alt{};
-                while (true) {
-                    k += EMIT_BLOCK;
-                    if (k >= n_round) { settle(); store(cur); break; }
-                    alt = compute(k);
-                    settle();
-                    store(cur);
-                    k += EMIT_BLOCK;
-                    if (k >= n_round) { store(alt); break; }
-                    cur = compute(k);
-                    store(alt);
-                }
-#else
-                for (k += EMIT_BLOCK; k < n_round; k += EMIT_BLOCK) {
-                    const Hit nxt = compute(k);
-                    settle();
-                    store(cur);
-                    cur = nxt;
-                }
-                settle();
-                store(cur);
-#endif
+                store(first);
+                for (k += BLOCK; k < n_round; k += BLOCK) store(score(fetch(k)));
             }
-#endif
+        };
+        if (!CHAINED) {
+            run_rows(tid, [](bool) {});
+        } else {
+            // Single pass.  The workgroup's slot (LDS, wave slots) is held until its LAST wave is done, and wave 0
+            // also resolves the tile's prefix.  So wave 0 takes the chunks of 64 rows nobody would miss: waves 1, 2,
+            // 3 own chunks 0, 1, 2 (mod 4) and wave 0 chunk 3 -- when the row count is not a multiple of 256 it is
+            // wave 0 that has one chunk less, not one more.
+            const uint32_t k0 = (uint32_t)(tid & 63) | ((((uint32_t)tid >> 6) + (BLOCK / 64 - 1)) % (BLOCK / 64)) << 6;
+            // the whole look-back BEFORE wave 0 scores anything (nothing of the scorer is live then)
+            if (lo_rank == 0 && tid < 64) chain_resolve(ch);
+            // The other waves score their first rows meanwhile and need the offsets only to STORE them: by then
+            // (one scoring iteration, ~4 us, after wave 0 started looking back) the flag is normally up.  From
+            // the second iteration on a row is stored as soon as it is scored -- nothing is parked in registers.
+            run_rows(k0, [&](bool any) {
+                // wave-uniform (the descriptors must stay in SGPRs): a wave with rows waits for the flag once per tile
+                if (!resolved && __ballot(any)) {
+                    while (__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(ch.s_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) == 0)
+                        __builtin_amdgcn_s_sleep(1);
+                    const uint64_t e = uniform64(*ch.s_excl);
+                    tile_stores<PRE, SEEDS>(ts, out, e & 0xffffffffull, e >> 32, n_plus);
+                    resolved = true;
+                }
+            });
         }
     }
 }
@@ -1221,12 +999,10 @@ hipError_t launch_count(hipStream_t s, const Planes &pl, uint64_t n_words_padded
                         uint32_t n_tiles)
 {
     if (n_tiles == 0) return hipSuccess;
-    constexpr uint32_t TPB = (TILE_WORDS > 512 ? TILE_WORDS : 512) / TILE_WORDS;  // emit tiles per count workgroup
-    const dim3 grid((n_tiles + TPB - 1) / TPB);
     if (l == 20)
-        hipLaunchKernelGGL(count_kernel<20>, grid, dim3(BLOCK), 0, s, pl, n_words_padded, l, tile_cnt);
+        hipLaunchKernelGGL(count_kernel<20>, dim3(n_tiles), dim3(BLOCK), 0, s, pl, n_words_padded, l, tile_cnt);
     else
-        hipLaunchKernelGGL(count_kernel<0>, grid, dim3(BLOCK), 0, s, pl, n_words_padded, l, tile_cnt);
+        hipLaunchKernelGGL(count_kernel<0>, dim3(n_tiles), dim3(BLOCK), 0, s, pl, n_words_padded, l, tile_cnt);
     return hipGetLastError();
 }
 
@@ -1239,19 +1015,40 @@ hipError_t launch_tile_scan(hipStream_t s, const uint2 *tile_cnt, uint32_t n_til
     return hipGetLastError();
 }
 
+// the emit kernel's variants: guide length 20 (compile-time windows, chain-prefix tables) or any; with or without the
+// pre-sigmoid column; with or without the off-target scan's seed words (l = 20 only)
+template <bool CHAINED>
+static hipError_t launch_emit_variant(hipStream_t s, const Planes &pl, uint64_t n_words_padded, int l, const uint2 *tile_off,
+                                      uint64_t *chain, uint64_t *chain_next, const HitTables &out, uint32_t mute_tile,
+                                      uint32_t timeout_ticks)
+{
+    const uint32_t n_tiles = (uint32_t)(n_words_padded / TILE_WORDS);
+    if (n_tiles == 0) return hipSuccess;
+    const bool pre = out.pre_plus != nullptr, seeds = out.seed_plus != nullptr;
+    if (seeds && l != 20) return hipErrorInvalidValue;
+#define CRP_LAUNCH(LFIX, PRE, SEEDS)                                                                                      \
+    hipLaunchKernelGGL((emit_kernel<CHAINED, LFIX, PRE, SEEDS>), dim3(n_tiles), dim3(BLOCK), 0, s, pl, n_words_padded, l, \
+                       tile_off, chain, chain_next, out, mute_tile, timeout_ticks)
+    if (l == 20) {
+        if (seeds) {
+            if (pre) CRP_LAUNCH(20, true, true);
+            else CRP_LAUNCH(20, false, true);
+        } else {
+            if (pre) CRP_LAUNCH(20, true, false);
+            else CRP_LAUNCH(20, false, false);
+        }
+    } else {
+        if (pre) CRP_LAUNCH(0, true, false);
+        else CRP_LAUNCH(0, false, false);
+    }
+#undef CRP_LAUNCH
+    return hipGetLastError();
+}
+
 hipError_t launch_emit(hipStream_t s, const Planes &pl, uint64_t n_words_padded, int l, const uint2 *tile_off,
                        const HitTables &out)
 {
-    constexpr int TW = EMIT_BLOCK * TILE_WPT;
-    const uint32_t n_tiles = (uint32_t)(n_words_padded / TW);
-    if (n_tiles == 0) return hipSuccess;
-    if (l == 20)
-        hipLaunchKernelGGL((emit_kernel<TILE_WPT, false, 20>), dim3(n_tiles), dim3(EMIT_BLOCK), 0, s, pl, n_words_padded,
-                           l, tile_off, (uint64_t *)nullptr, (uint64_t *)nullptr, out, 0xffffffffu, 0u);
-    else
-        hipLaunchKernelGGL((emit_kernel<TILE_WPT, false, 0>), dim3(n_tiles), dim3(EMIT_BLOCK), 0, s, pl, n_words_padded,
-                           l, tile_off, (uint64_t *)nullptr, (uint64_t *)nullptr, out, 0xffffffffu, 0u);
-    return hipGetLastError();
+    return launch_emit_variant<false>(s, pl, n_words_padded, l, tile_off, nullptr, nullptr, out, 0xffffffffu, 0u);
 }
 
 size_t chain_bytes(uint32_t n_tiles) { return (CHAIN_HEADER_WORDS + (size_t)n_tiles) * sizeof(uint64_t); }
@@ -1259,15 +1056,7 @@ size_t chain_bytes(uint32_t n_tiles) { return (CHAIN_HEADER_WORDS + (size_t)n_ti
 hipError_t launch_emit_chained(hipStream_t s, const Planes &pl, uint64_t n_words_padded, int l, uint64_t *chain,
                                uint64_t *chain_next, const HitTables &out, uint32_t mute_tile, uint32_t timeout_ticks)
 {
-    constexpr int TW = EMIT_BLOCK * TILE_WPT;
-    const uint32_t n_tiles = (uint32_t)(n_words_padded / TW);
-    if (l == 20)
-        hipLaunchKernelGGL((emit_kernel<TILE_WPT, true, 20>), dim3(n_tiles), dim3(EMIT_BLOCK), 0, s, pl, n_words_padded,
-                           l, (const uint2 *)nullptr, chain, chain_next, out, mute_tile, timeout_ticks);
-    else
-        hipLaunchKernelGGL((emit_kernel<TILE_WPT, true, 0>), dim3(n_tiles), dim3(EMIT_BLOCK), 0, s, pl, n_words_padded,
-                           l, (const uint2 *)nullptr, chain, chain_next, out, mute_tile, timeout_ticks);
-    return hipGetLastError();
+    return launch_emit_variant<true>(s, pl, n_words_padded, l, nullptr, chain, chain_next, out, mute_tile, timeout_ticks);
 }
 
 hipError_t launch_score30(hipStream_t s, const uint8_t *rows, uint64_t n, int order, double *pre, double *score)

@@ -85,10 +85,7 @@ __device__ __forceinline__ uint32_t spread12(uint32_t x)
 //                        the bucket's slice of the global histogram with plain 16-byte accesses
 // Chunks: workgroup w owns hits [w * OT_CHUNK, (w + 1) * OT_CHUNK) of a strand's table in both passes.
 constexpr uint32_t OT_BUCKETS = 4096;
-#ifndef CRP_OT_CHUNK
-#define CRP_OT_CHUNK 16384
-#endif
-constexpr uint32_t OT_CHUNK = CRP_OT_CHUNK;
+constexpr uint32_t OT_CHUNK = 16384;
 
 template <bool MINUS>
 __device__ __forceinline__ uint32_t seed_of_windows(uint32_t h, uint32_t w, uint32_t u, uint32_t a, uint64_t p,
@@ -129,6 +126,44 @@ __global__ __launch_bounds__(BLOCK) void ot_seed_kernel(Planes pl, const uint32_
         const uint64_t q = MINUS ? p + 3 : p - CRP_OT_SEED_LEN;
         const uint32_t code = seed_of_windows<MINUS>(window12(pl.plane[0], q), window12(pl.plane[1], q), window12(pl.plane[2], q),
                                                      window12(pl.plane[3], q), p, own, n_own);
+        seeds[t] = code;
+        if (code < OT_SEEDS) atomicAdd(&cnt[code >> 12], 1u);
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < OT_BUCKETS; b += BLOCK)
+        if (cnt[b]) atomicAdd(&bucket_total[b], cnt[b]);
+}
+
+// The same step when the scan itself delivered the seeds (crp_scan_score with CRP_SCAN_SEEDS, l = 20): the emit kernel
+// wrote one RAW word per hit -- low code bits of the 12 seed characters in bits 11..0, high code bits in bits 23..12,
+// already oriented, SEED_RAW_NONE where the 12 characters are not all bases -- because it has every hit's window in
+// registers anyway.  This pass only interleaves the two halves (Morton code: character k at bits 2k, 2k+1), applies
+// the ownership ranges and counts the buckets: 4 B in, 4 B out per hit (+ 4 B of position with ownership ranges),
+// no second visit to the planes (ot_seed_kernel: four divergent loads per hit).
+__global__ __launch_bounds__(BLOCK) void ot_seed_from_raw_kernel(const uint32_t *__restrict__ raw, const uint32_t *__restrict__ pos,
+                                                                  uint64_t n, const uint64_t *__restrict__ own, uint32_t n_own,
+                                                                  uint32_t *__restrict__ seeds, uint32_t *__restrict__ bucket_total)
+{
+    __shared__ uint32_t cnt[OT_BUCKETS];
+    for (uint32_t b = threadIdx.x; b < OT_BUCKETS; b += BLOCK) cnt[b] = 0;
+    __syncthreads();
+    const uint64_t lo = (uint64_t)blockIdx.x * OT_CHUNK, hi = lo + OT_CHUNK < n ? lo + OT_CHUNK : n;
+    for (uint64_t t = lo + threadIdx.x; t < hi; t += BLOCK) {
+        const uint32_t r = raw[t];
+        uint32_t code = OT_NOT_A_SITE;
+        if (r != SEED_RAW_NONE) {
+            code = (spread12(r >> 12) << 1) | spread12(r & 0xfffu);
+            if (n_own) {  // the range with the largest begin <= p
+                const uint64_t p = pos[t];
+                uint32_t a = 0, b = n_own;
+                while (a < b) {
+                    const uint32_t mid = (a + b) >> 1;
+                    if (own[2 * mid] <= p) a = mid + 1;
+                    else b = mid;
+                }
+                if (!(a > 0 && p < own[2 * (a - 1) + 1])) code = OT_NOT_OWNED;
+            }
+        }
         seeds[t] = code;
         if (code < OT_SEEDS) atomicAdd(&cnt[code >> 12], 1u);
     }
@@ -320,9 +355,6 @@ __global__ __launch_bounds__(1024) void ot_ball_kernel(const uint32_t *__restric
     }
 }
 
-#ifndef CRP_OT_LOOKUP_ILP
-#define CRP_OT_LOOKUP_ILP 1
-#endif
 // ILP independent gathers in flight per lane.  Measured: 1, 2, 4, 8 all run at the same rate,
 // and a table cut down to 4 MB (L2-resident) is only 2x faster -- the gather is bound by the ~6 cycles the vector
 // memory path spends per divergent lane, neither by latency nor by HBM bandwidth.  (Non-temporal loads: 1.44 ms
@@ -330,7 +362,7 @@ __global__ __launch_bounds__(1024) void ot_ball_kernel(const uint32_t *__restric
 __global__ __launch_bounds__(BLOCK) void ot_lookup_kernel(const uint32_t *__restrict__ seeds, uint64_t n,
                                                            const uint4 *__restrict__ ball, uint4 *__restrict__ out)
 {
-    constexpr int ILP = CRP_OT_LOOKUP_ILP;
+    constexpr int ILP = 1;
     const uint64_t span = (uint64_t)gridDim.x * BLOCK;
     for (uint64_t t0 = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; t0 < n; t0 += span * ILP) {
         uint32_t s[ILP];
@@ -344,11 +376,7 @@ __global__ __launch_bounds__(BLOCK) void ot_lookup_kernel(const uint32_t *__rest
         for (int k = 0; k < ILP; ++k) {
             v[k] = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
             if (s[k] < OT_SEEDS) {
-#ifdef CRP_EXPERIMENT_OT_LOOKUP_MASK  // measurement only (wrong counts): how the gather's rate depends on the table's span
-                v[k] = ball[s[k] & CRP_EXPERIMENT_OT_LOOKUP_MASK];
-#else
                 v[k] = ball[s[k]];
-#endif
                 v[k].x -= 1;  // the hit itself is one of the sites at distance 0
             }
         }
@@ -433,7 +461,10 @@ int crp_offtarget_add(crp_arena *a, int guide_len, const uint64_t *own_ranges, u
             if (!n) continue;
             const uint32_t chunks = (uint32_t)((n + crp::OT_CHUNK - 1) / crp::OT_CHUNK);
             CRP_HIP(ctx, hipMemsetAsync(d_total, 0, crp::OT_BUCKETS * sizeof(uint32_t), ctx->stream));
-            if (s == 0)
+            if (a->have_raw && guide_len == 20)  // the scan wrote the seed words (CRP_SCAN_SEEDS)
+                hipLaunchKernelGGL(crp::ot_seed_from_raw_kernel, dim3(chunks), dim3(crp::BLOCK), 0, ctx->stream, a->d_ot_raw[s],
+                                   a->d_pos[s], n, a->d_ot_own, (uint32_t)n_ranges, a->d_ot_seed[s], d_total);
+            else if (s == 0)
                 hipLaunchKernelGGL(crp::ot_seed_kernel<false>, dim3(chunks), dim3(crp::BLOCK), 0, ctx->stream, pl, a->d_pos[0], n,
                                    a->d_ot_own, (uint32_t)n_ranges, a->d_ot_seed[0], d_total);
             else

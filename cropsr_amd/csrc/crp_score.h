@@ -32,7 +32,7 @@ static constexpr double CRP_WS_LIT[CRP_WS_COUNT] = CRP_WS_TABLE;
 // Chain-prefix tables of the PAM-variant scorer (gen_score_terms.py, "table form"): the value of a
 // chain after its first k terms, for every pattern of the k gate bits.  Staged into LDS by the
 // emit kernel; `off` is a byte offset inside the chain's table.
-__device__ const double CRP_SCORE_TAB[CRP_SCORE_TAB_N] = CRP_SCORE_TAB_DATA;
+// (the table's data, CRP_SCORE_TAB_DATA, is part of the image crp_kernels.hip stages: TabsImage)
 __device__ __forceinline__ double crp_tab_at(const double *tab, uint32_t base_bytes, uint32_t off_bytes)
 {
     return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(tab) + base_bytes + off_bytes);

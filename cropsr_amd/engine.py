@@ -97,10 +97,13 @@ class Arena:
                   "crp_arena_stats")
         return dict(n_contigs=a.value, n_chars=b.value, n_words=c.value)
 
-    def scan_score_device(self, guide_len=20, want_pre=False):
-        """Run the kernels; tables stay in HBM.  Returns (n_plus, n_minus)."""
+    def scan_score_device(self, guide_len=20, want_pre=False, want_seeds=False):
+        """Run the kernels; tables stay in HBM.  Returns (n_plus, n_minus).  want_seeds: the scan also writes the
+        seed words the off-target step works on (CRP_SCAN_SEEDS; offtarget_add then skips its own pass over the
+        planes)."""
         npl, nmi = ctypes.c_uint64(), ctypes.c_uint64()
-        nat.check(nat.lib().crp_scan_score(self._h, guide_len, int(bool(want_pre)),
+        flags = (nat.SCAN_PRE if want_pre else 0) | (nat.SCAN_SEEDS if want_seeds else 0)
+        nat.check(nat.lib().crp_scan_score(self._h, guide_len, flags,
                                            ctypes.byref(npl), ctypes.byref(nmi)),
                   "crp_scan_score", self._engine._ctx)
         return npl.value, nmi.value
@@ -478,16 +481,18 @@ class Genome:
                 self._where[k] = (a, j)
         self.n_contigs = len(bufs)
 
-    def scan_score(self, guide_len=20, want_pre=False, offtarget=False):
+    def scan_score(self, guide_len=20, want_pre=False, offtarget=False, seeds_from_scan=True):
         """Seam 1 + 2 for every contig.  offtarget=True also runs the genome-wide seed scan over all
-        arenas (single process: no reduce) and attaches (n, 4) counts to every contig's hits."""
+        arenas (single process: no reduce) and attaches (n, 4) counts to every contig's hits;
+        seeds_from_scan=False makes the off-target step derive its seeds from the planes itself (the
+        path guide lengths other than 20 always take) instead of receiving them from the scan."""
         if not offtarget:
             return GenomeHits(self, [a.scan_score(guide_len, want_pre) for a in self.arenas])
         eng = self._engine
         eng.offtarget_reset()
         counts, per_arena = [], []
         for a in self.arenas:
-            n = a.scan_score_device(guide_len, want_pre)
+            n = a.scan_score_device(guide_len, want_pre, want_seeds=seeds_from_scan)
             a.offtarget_add(guide_len)
             counts.append(n)
         eng.offtarget_solve()

@@ -23,7 +23,7 @@ state but the append-only list), so the path shards by contig:
     and the histograms are summed over the ranks (RCCL all-reduce, crp_offtarget_reduce).
 
 A backend (cli.EngineBackend, or the oracle in the tests) provides
-scan_resident(texts, guide_len) -> Resident:
+scan_resident(texts, guide_len, offtarget=False) -> Resident   (offtarget: the seed scan will follow):
     .layout                          [(arena index, arena offset, length)] per text
     .offtarget(group, own_by_arena)  seed scan over all ranks' sites; own_by_arena: per arena the
                                      [begin, end) arena positions whose hits this rank owns
@@ -173,7 +173,7 @@ def sharded_scan(backend, strings, guide_len, group, dst=0, max_piece=None, offt
     res, err = None, None
     try:
         views = [piece_view(strings[pieces[q][0]], pieces[q][1], pieces[q][2]) for q in mine]
-        res = backend.scan_resident([v for v, _ in views], guide_len)
+        res = backend.scan_resident([v for v, _ in views], guide_len, offtarget=offtarget)
     except Exception as e:  # reported to every rank below
         err = "%s: %s" % (type(e).__name__, e)
     group.check(err)

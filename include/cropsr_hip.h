@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define CRP_ABI_VERSION 2
+#define CRP_ABI_VERSION 3
 
 typedef enum crp_status {
     CRP_OK = 0,
@@ -118,9 +118,15 @@ int crp_arena_stats(const crp_arena *arena, uint64_t *n_contigs, uint64_t *n_cha
  * 30 characters (guide_len == 20: complete windows; > 20: only windows the end of
  * the string cuts to 30; < 20: none -- the others get -1 like CROPSR.py:466-468), leave
  * the tables in HBM.  Tables are ascending in arena position per strand, i.e.
- * per contig in the reference's own order.  want_pre != 0 also keeps the
+ * per contig in the reference's own order.  flags: CRP_SCAN_PRE also keeps the
  * pre-sigmoid sum (CROPSR.py:312). */
-int crp_scan_score(crp_arena *arena, int guide_len, int want_pre,
+#define CRP_SCAN_PRE 1    /* (flags == 1 is what callers of ABI version 2 passed as `want_pre`) */
+/* CRP_SCAN_SEEDS: the scan also writes, per kept hit, the 12 characters of `sequence` next to the PAM that the
+ * off-target seed scan (below) works on -- the emit kernel holds every hit's window in registers anyway.
+ * crp_offtarget_add then takes them from there instead of reading the planes a second time.  Honoured for
+ * guide_len == 20; for other lengths the flag is ignored and crp_offtarget_add derives the seeds itself. */
+#define CRP_SCAN_SEEDS 2
+int crp_scan_score(crp_arena *arena, int guide_len, int flags,
                    uint64_t *n_plus, uint64_t *n_minus);
 /* Copy the tables of the last crp_scan_score to host arrays sized n_plus /
  * n_minus.  Any pointer may be NULL to skip that column. */

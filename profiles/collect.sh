@@ -8,7 +8,7 @@
 #   3. --pmc WRITE_SIZE            : HBM write traffic  (separate pass)
 #   4. --pmc SQ_* (two passes)     : where the emit kernel's wave time goes
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 RAW=gpurun_out/prof_$TAG

@@ -159,7 +159,7 @@ class OracleBackend:
                 h["ot_plus"], h["ot_minus"] = ot["ot_plus"], ot["ot_minus"]
         return out
 
-    def scan_resident(self, texts, l):
+    def scan_resident(self, texts, l, offtarget=False):
         return OracleResident(self.orc, texts, l)
 
     def rescore(self, rows_u8, order):

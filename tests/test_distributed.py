@@ -95,7 +95,7 @@ def _failing_worker(rank, world, port, out_dir):
     from oracle import oracle
 
     class Broken(OracleBackend):
-        def scan_resident(self, texts, l):
+        def scan_resident(self, texts, l, offtarget=False):
             if group.rank == 1:
                 raise ValueError("this rank's share does not fit")
             return OracleBackend.scan_resident(self, texts, l)

@@ -182,16 +182,29 @@ gpu = pytest.mark.gpu
 
 
 @pytest.fixture(scope="module")
-def engine():
+def _engine():
     from cropsr_amd import Engine
     eng = Engine(0)
     yield eng
     eng.close()
 
 
+SEEDS_FROM_SCAN = True
+
+
+@pytest.fixture(params=["seeds_from_scan", "seeds_from_planes"])
+def engine(_engine, request):
+    """Every off-target GPU test runs both ways: the scan hands over the seed words (CRP_SCAN_SEEDS: the emit kernel
+    writes them from the windows it holds anyway, l = 20), or the off-target step reads the planes itself."""
+    global SEEDS_FROM_SCAN
+    SEEDS_FROM_SCAN = request.param == "seeds_from_scan"
+    yield _engine
+    SEEDS_FROM_SCAN = True
+
+
 def gpu_offtarget(engine, contigs, l=20, max_words=None):
     genome = engine.genome(contigs, max_words=max_words)
-    hits = genome.scan_score(l, offtarget=True)
+    hits = genome.scan_score(l, offtarget=True, seeds_from_scan=SEEDS_FROM_SCAN)
     seeds = []
     for a, h in zip(genome.arenas, hits.per_arena):
         seeds.append(a.offtarget_seeds(h.n_plus, h.n_minus))
@@ -239,7 +252,7 @@ def test_gpu_counts_vs_all_pairs_on_a_megabase(engine, oracle):
     a = np.frombuffer(b"ACGTACGTACGTacgtacgtNNRYGGCC", dtype=np.uint8)
     contigs = [b"'" + rng.choice(a, n).tobytes() + b"')," for n in (700000, 350000, 90000)]
     genome = engine.genome(contigs)
-    hits = genome.scan_score(20, offtarget=True)
+    hits = genome.scan_score(20, offtarget=True, seeds_from_scan=SEEDS_FROM_SCAN)
     hist = engine.offtarget_hist()
     want = oracle.offtarget_genome(contigs, 20)
     codes = np.concatenate([np.concatenate([w["seed_plus"], w["seed_minus"]]) for w in want])
@@ -302,7 +315,7 @@ def test_gpu_genome_wide_over_several_arenas_and_ownership(engine, oracle):
             assert (one[k][key] == many[k][key]).all()
     # ownership: only the first half of contig 0 counts
     arena = engine.arena(contigs[:1])
-    n = arena.scan_score_device(20)
+    n = arena.scan_score_device(20, want_seeds=SEEDS_FROM_SCAN)
     off = int(arena.offsets[0])
     engine.offtarget_reset()
     sites = arena.offtarget_add(20, [(off, off + 30000)])
