@@ -268,11 +268,33 @@ def _distributed():
 _ACTIVE_GROUP = None  # the group main() aborts when this rank fails outside an agreed error (Group.check)
 
 
-def check_guide_length(l):
-    """The engine scans guide lengths 1..50 (the reference takes any integer; lengths outside that
-    range give it no rows, or Python-slice artefacts).  Checked before ANY side effect, on every rank."""
-    if not 1 <= l <= 50:
-        sys.exit("cropsr_amd: -l/--length must be between 1 and 50 (got %d)" % l)
+NATIVE_GUIDE_LENGTHS = (1, 50)  # what the kernels' window logic and the native row formatter are built for
+
+
+def device_guide_length(l):
+    """The guide length the engine scans with for the reference's `-l l` (any integer, CROPSR.py:38-40).  Inside
+    0..50 it is l itself; outside, the nearest end of that range, whose kept hits are a SUPERSET of the reference's
+    (the keep-filters of CROPSR.py:419 / :430 only get stricter as |l| grows) -- refilter_hits() then applies
+    the literal filter.  No row is scored at those lengths (long_sequence has l + 10 characters, or is cut by the end
+    of the string to more than 30 for l > 35): what remains of the reference's work there is the filter."""
+    return min(max(int(l), 0), NATIVE_GUIDE_LENGTHS[1])
+
+
+def refilter_hits(hits, n, l):
+    """CROPSR.py:419 and :430, all four clauses each, on the hit tables of one contig string of n characters (match
+    indices i of (?=.GG), j of (?=CC.)) -- for guide lengths the engine scanned with a clamped length
+    (device_guide_length).  Every surviving row is unscored (-1), like the reference writes it."""
+    out = dict(hits)
+    for strand in ("plus", "minus"):
+        p = np.asarray(hits["pos_" + strand]).astype(np.int64)
+        a, b = (p - l, p) if strand == "plus" else (p + 3, p + 3 + l)  # pam_location (:418 / :429)
+        keep = (a >= 5) & (a + 5 <= n + 10) & (b >= 5) & (b <= n + 10)
+        for key in ("pos_", "score_", "pre_", "ot_"):
+            col = hits.get(key + strand)
+            if col is not None:
+                out[key + strand] = np.asarray(col)[keep]
+        out["score_" + strand] = np.full(int(keep.sum()), -1.0)
+    return out
 
 
 def run(args, backend=None, out=sys.stdout, group=None):
@@ -288,8 +310,10 @@ def run(args, backend=None, out=sys.stdout, group=None):
     begin = time.time()
     if not args.cas9:
         sys.exit("Please select at least one CRISPR system: Cas9")  # CROPSR.py:335-336
-    check_guide_length(args.l)
     offtarget = bool(getattr(args, "offtarget", False))
+    l_dev = device_guide_length(args.l)
+    if offtarget and l_dev != args.l:  # (checked before any side effect, on every rank)
+        sys.exit("cropsr_amd: --offtarget needs a guide length between 0 and %d (got %d)" % (NATIVE_GUIDE_LENGTHS[1], args.l))
     finalize = getattr(args, "score_finalize", "gpu")
     stages = {}  # --bench-json
     own_group = group is None
@@ -320,7 +344,7 @@ def run(args, backend=None, out=sys.stdout, group=None):
             group.check(err)
             if hasattr(backend, "connect"):
                 backend.connect()
-            parallel.sharded_scan(backend, strings, args.l, group, max_piece=max_piece, offtarget=offtarget)
+            parallel.sharded_scan(backend, strings, l_dev, group, max_piece=max_piece, offtarget=offtarget)
         finally:
             if own_backend and backend is not None:
                 backend.close()
@@ -379,7 +403,7 @@ def run(args, backend=None, out=sys.stdout, group=None):
     if group is None:
         if own_backend:
             backend = make_backend()
-        all_hits = backend.scan(strings, args.l, offtarget=offtarget) if offtarget else backend.scan(strings, args.l)
+        all_hits = backend.scan(strings, l_dev, offtarget=offtarget) if offtarget else backend.scan(strings, l_dev)
     else:  # contigs (cut where longer than a rank's share) over all GPUs, tables gathered here
         from . import parallel
         err = None
@@ -391,9 +415,11 @@ def run(args, backend=None, out=sys.stdout, group=None):
         group.check(err)
         if hasattr(backend, "connect"):
             backend.connect()
-        all_hits = parallel.sharded_scan(backend, strings, args.l, group, max_piece=max_piece, offtarget=offtarget)
+        all_hits = parallel.sharded_scan(backend, strings, l_dev, group, max_piece=max_piece, offtarget=offtarget)
         if hasattr(backend, "finalize_gathered"):
             all_hits = backend.finalize_gathered(all_hits)
+    if l_dev != args.l:  # a length outside the engine's range: the literal keep-filter, on the host
+        all_hits = [refilter_hits(h, len(s), args.l) for h, s in zip(all_hits, strings)]
     world = 1 if group is None else group.world
     if own_group and group is not None:
         # the exchange is over: the other ranks leave now (Group.close is a barrier) instead of waiting, watched by
@@ -407,7 +433,8 @@ def run(args, backend=None, out=sys.stdout, group=None):
         from . import annotate
         annot = annotate.Annotation(args.g, args.p)
 
-    native = getattr(args, "csv_writer", "native") == "native"
+    # (the native formatter's row buffers are sized for guide lengths 1..50; other lengths take the csv module)
+    native = getattr(args, "csv_writer", "native") == "native" and NATIVE_GUIDE_LENGTHS[0] <= args.l <= NATIVE_GUIDE_LENGTHS[1]
     once = getattr(args, "each_contig_once", False)
     dataset = rows.NativeDataset() if native else rows.Dataset()  # Complete_dataset, CROPSR.py:407
     ids = None

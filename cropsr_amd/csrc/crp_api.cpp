@@ -59,7 +59,7 @@ const char *crp_strerror(int status)
         case CRP_ERR_NOMEM: return "out of memory";
         case CRP_ERR_STATE: return "call out of order";
         case CRP_ERR_CAPACITY: return "arena capacity exceeded";
-        case CRP_ERR_UNSUPPORTED: return "unsupported parameter";
+        case CRP_ERR_UNSUPPORTED: return "unsupported parameter (guide length outside 0..50)";
         case CRP_ERR_IO: return "write to the output descriptor failed";
         case CRP_ERR_COMM: return "RCCL error";
         case CRP_ERR_PEER: return "abandoned on every rank: another rank reported an error before the exchange";
@@ -517,7 +517,7 @@ int crp_scan_score(crp_arena *a, int guide_len, int flags, uint64_t *n_plus, uin
     crp::Range roctx_range("crp: scan + score");
     if (!a || (flags & ~(CRP_SCAN_PRE | CRP_SCAN_SEEDS))) return CRP_ERR_INVALID;
     if (!a->sealed) return CRP_ERR_STATE;
-    if (guide_len < 1 || guide_len > 50) return CRP_ERR_UNSUPPORTED;
+    if (guide_len < 0 || guide_len > 50) return CRP_ERR_UNSUPPORTED;
     crp_ctx *ctx = a->ctx;
     CRP_HIP(ctx, hipSetDevice(ctx->device));
     a->have_hits = false;

@@ -48,7 +48,7 @@ typedef enum crp_status {
     CRP_ERR_NOMEM = -4,       /* host or device allocation failed */
     CRP_ERR_STATE = -5,       /* call out of order (e.g. scan before seal) */
     CRP_ERR_CAPACITY = -6,    /* arena capacity exceeded */
-    CRP_ERR_UNSUPPORTED = -7, /* e.g. guide length outside [1, 50] */
+    CRP_ERR_UNSUPPORTED = -7, /* e.g. guide length outside [0, 50] */
     CRP_ERR_IO = -8,          /* write(2) on the caller's descriptor failed; errno is left set */
     CRP_ERR_COMM = -9,        /* an RCCL call failed or librccl.so could not be loaded; see crp_last_error */
     CRP_ERR_PEER = -10        /* a collective call was abandoned ON EVERY RANK because another rank reported an error
@@ -114,7 +114,9 @@ int crp_arena_stats(const crp_arena *arena, uint64_t *n_contigs, uint64_t *n_cha
 
 /* ---- seam 1 + 2 over a whole arena -------------------------------------- */
 /* Scan both strands of every contig, keep what CROPSR.py:419/:430 keep for
- * guide length `guide_len`, score every kept hit whose long_sequence has exactly
+ * guide length `guide_len` (0..50; the reference takes any integer: for lengths outside that range scan with the
+ * nearer end of it -- a superset of the reference's hits, none of them scored at those lengths -- and apply
+ * CROPSR.py:419/:430 to the positions on the host, as cropsr_amd/cli.py refilter_hits does), score every kept hit whose long_sequence has exactly
  * 30 characters (guide_len == 20: complete windows; > 20: only windows the end of
  * the string cuts to 30; < 20: none -- the others get -1 like CROPSR.py:466-468), leave
  * the tables in HBM.  Tables are ascending in arena position per strand, i.e.

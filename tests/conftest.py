@@ -49,7 +49,10 @@ def sample_fasta_text():
 
 PROBES = ["multi", "twoline", "spaces", "edges", "mixed", "rightend", "tiny", "dupname", "crlf"]
 # probes the real reference was also run on with a non-default guide length: (probe, -l value)
-LENGTH_CASES = [("mixed", 23), ("rightend", 17), ("multi", 25), ("tiny", 21), ("edges", 24)]
+LENGTH_CASES = [("mixed", 23), ("rightend", 17), ("multi", 25), ("tiny", 21), ("edges", 24),
+                # beyond the engine's native 1..50 (the reference takes any integer, CROPSR.py:38-40), and the range's ends
+                ("mixed", 0), ("multi", -3), ("tiny", -12), ("multi", 51), ("rightend", 64), ("mixed", 100),
+                ("rightend", 35), ("rightend", 36), ("mixed", 50), ("tiny", 1)]
 
 
 VERBOSE_CASES = ["multi", "mixed"]

@@ -93,7 +93,8 @@ def main():
     degenerate = ["", "\n", ">", ">\n", ">x", ">x\n", "ACGT", "ACGTGGCCAGGTTCCAGGACGT\n", ">a\n>b\n", ">a\n\n"]
     for it in range(a.n):
         fa = degenerate[it] if it < len(degenerate) else random_fasta(rnd)
-        extra = rnd.choice([(), (), (), ("-l", "17"), ("-l", "23"), ("-l", "30"), ("-v",), ("-v", "-l", "21")])
+        extra = rnd.choice([(), (), (), ("-l", "17"), ("-l", "23"), ("-l", "30"), ("-v",), ("-v", "-l", "21"),
+                            ("-l", "0"), ("-l", "-7"), ("-l", "35"), ("-l", "51"), ("-l", "77"), ("-v", "-l", "-30")])
         try:
             want = mg.run_reference(fa, mg.MINI_GFF, env_kind, scratch, extra=extra)
         except RuntimeError as e:

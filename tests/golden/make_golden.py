@@ -155,7 +155,12 @@ def build_probes():
 
 # probes re-run with a non-default guide length (-l): l > 20 scores only windows the end of the
 # contig string cuts to 30 characters, l < 20 scores nothing (CROPSR.py:458,466)
-LENGTH_CASES = [("mixed", 23), ("rightend", 17), ("multi", 25), ("tiny", 21), ("edges", 24)]
+LENGTH_CASES = [("mixed", 23), ("rightend", 17), ("multi", 25), ("tiny", 21), ("edges", 24),
+                # what the reference accepts beyond the engine's native range 1..50 (CROPSR.py:38-40 takes any integer):
+                # every row unscored; for l <= 0 the two clauses of :419 / :430 that are otherwise always true decide
+                ("mixed", 0), ("multi", -3), ("tiny", -12), ("multi", 51), ("rightend", 64), ("mixed", 100),
+                # and the ends of the range in which the end of the string can still cut a window to 30 (l <= 35)
+                ("rightend", 35), ("rightend", 36), ("mixed", 50), ("tiny", 1)]
 
 
 # probes re-run with -v: the banner, the per-contig site counts and the progress lines on stdout

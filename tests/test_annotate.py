@@ -1,7 +1,8 @@
 """--annotate: the opt-in GFF / Phytozome join.  No reference oracle exists (the
 reference drops the parsed GFF, CROPSR.py:375, and writes '' into `features`, :466-468): the product's
 sweep + binary search is checked against the brute-force restatement in oracle/annotate_oracle.py, and
-the default CSV is asserted untouched.  CPU only (the join is host code)."""
+the default CSV is asserted untouched.  The join itself is host code; the `-m gpu` tests at the end run it on
+hit tables that come out of the HIP engine."""
 import csv
 import gzip
 import io
@@ -169,3 +170,51 @@ def test_random_interval_sets_against_brute_force():
                 assert got == ";".join(want), (trial, k, cut, got, want)
         finally:
             os.unlink(path)
+
+
+# ------------------------------------------------------------------------------- GPU
+@pytest.mark.gpu
+def test_gpu_annotate_sample_genome(manifest, tmp_path, monkeypatch, sample_gff):
+    """The reference's sample pair through the PRODUCT path -- EngineBackend, hit tables from libcropsr_hip.so -- with
+    --annotate: the `features` column equals the brute-force join (oracle/annotate_oracle.py) for all 17 314 rows and every
+    other byte is the reference's; the same run without the flag is md5_libm, the reference's own bytes
+    (CROPSR.py:77-95 parses the GFF, :375 drops it, :466-468 write '')."""
+    import hashlib
+    from oracle import annotate_oracle
+    fa = golden_fasta_path("sample", tmp_path)
+    got, _ = run_cli(tmp_path, monkeypatch, fa, None, manifest["seed"], extra=("-g", sample_gff, "--annotate"))
+    ref = read_golden_csv("sample")
+    a = list(csv.reader(io.StringIO(got.decode("latin-1"), newline="")))
+    b = list(csv.reader(io.StringIO(ref.decode("latin-1"), newline="")))
+    assert len(a) == len(b) == 17315 and a[0] == b[0]
+    want = annotate_oracle.features_of_rows(b[1:], lambda chrom: chrom.strip("(',"), 1, sample_gff)
+    for ra, rb, w in zip(a[1:], b[1:], want):
+        assert ra[:10] == rb[:10] and ra[11:] == rb[11:] and ra[10] == w
+    assert sum(bool(w) for w in want) > 8000
+    d = tmp_path / "plain"
+    d.mkdir()
+    plain, _ = run_cli(d, monkeypatch, fa, None, manifest["seed"], extra=("-g", sample_gff))
+    assert plain == ref and hashlib.md5(plain).hexdigest() == manifest["cases"]["sample"]["md5_libm"]
+
+
+@pytest.mark.gpu
+def test_gpu_annotate_with_offtarget_two_processes_equal_one(manifest, tmp_path, sample_gff):
+    """`--annotate --offtarget` as two processes (contigs cut into 20 kb pieces dealt to two ranks that share the one
+    GPU here, host transport) writes the bytes of the one-process run: the join sees the same stitched tables."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    fa = golden_fasta_path("sample", tmp_path)
+    common = ["-f", fa, "-g", sample_gff, "--cas9", "--seed", str(manifest["seed"]), "--device", "0", "--annotate", "--offtarget"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "CROPSR_LAUNCHED")}
+    env["PYTHONPATH"] = ROOT
+    one, two = tmp_path / "one.csv", tmp_path / "two.csv"
+    p = subprocess.run([sys.executable, "-m", "cropsr_amd", "-o", str(one)] + common, capture_output=True, text=True,
+                       timeout=600, cwd=str(tmp_path), env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    q = subprocess.run([sys.executable, "-m", "cropsr_amd", "--gpus", "2", "-o", str(two)] + common, capture_output=True, text=True,
+                       timeout=600, cwd=str(tmp_path), env=dict(env, CROPSR_GATHER="host", CROPSR_DIST_MAX_PIECE="20000"))
+    assert q.returncode == 0, q.stderr[-2000:]
+    assert one.read_bytes() == two.read_bytes()
+    rows = list(csv.reader(io.StringIO(one.read_bytes().decode("latin-1"), newline="")))
+    assert len(rows) == 17315 and len(rows[0]) == 16 and sum(bool(r[10]) for r in rows[1:] if len(r) == 16) > 8000

@@ -122,8 +122,9 @@ def test_exp_table_path_needs_no_small_argument_case(oracle):
 
 @pytest.mark.parametrize("name,guide_len", LENGTH_CASES)
 def test_cli_reproduces_reference_csv_other_guide_lengths(name, guide_len, oracle, manifest, tmp_path, monkeypatch):
-    """-l 17 ... 25: the oracle's keep-filter / window rules for l != 20 and the host's row
-    assembly against the real reference's CSV bytes and stdout."""
+    """-l 17 ... 25 -- and 1, 35 / 36, 50, and beyond the engine's range 0, -3, -12, 51, 64, 100: the oracle's
+    keep-filter / window rules for l != 20, the host's literal refilter for clamped scans and the row assembly
+    against the real reference's CSV bytes and stdout."""
     got, stdout = run_cli(tmp_path, monkeypatch, golden_fasta_path(name, tmp_path), oracle_scan_provider(oracle),
                           manifest["seed"], extra=("-l", str(guide_len)))
     case = manifest["cases"]["%s.l%d" % (name, guide_len)]
@@ -134,6 +135,27 @@ def test_cli_reproduces_reference_csv_other_guide_lengths(name, guide_len, oracl
     body = list(csv.reader(io.StringIO(got.decode(), newline="")))[1:]
     scored = sum(1 for r in body if len(r) == 12)
     assert len(body) == case["rows"] and (scored == 0 if guide_len < 20 else scored < len(body))
+
+
+@pytest.mark.parametrize("l", [-40, -12, -3, -1, 0, 51, 58, 59, 64, 100, 200])
+def test_guide_lengths_beyond_the_engines_range_are_the_clamped_scan_refiltered(oracle, l):
+    """The reference takes any integer -l (CROPSR.py:38-40).  The engine scans lengths 0..50; outside, cli.py scans with
+    the nearer end of that range and applies the literal keep-filter (CROPSR.py:419 / :430, all four clauses) on the
+    host.  That this is the reference's hit set is checked here against the oracle's LITERAL scan at the true length,
+    on contigs whose ends, N runs and decorations exercise every clause; no row is scored at those lengths."""
+    from cropsr_amd import cli
+    rng = np.random.default_rng(abs(l) + 7)
+    for n in (0, 3, 9, 40, 75, 130, 700, 5000):
+        body = rng.choice(np.frombuffer(b"ACGTGGCCacgtN", dtype=np.uint8), n).tobytes()
+        for s in (body, b"'" + body + b"'),", b"GG" + body + b"CC", b"CC" + body + b"GG"):
+            want_plus, want_minus = oracle.scan(s, l)
+            l_dev = cli.device_guide_length(l)
+            assert l_dev in (0, 50)
+            got = cli.refilter_hits(oracle.scan_score(s, l_dev), len(s), l)
+            assert (got["pos_plus"] == want_plus).all() and (got["pos_minus"] == want_minus).all(), (l, n)
+            lit = oracle.scan_score(s, l)
+            assert (lit["score_plus"] == -1).all() and (lit["score_minus"] == -1).all()
+            assert (got["score_plus"] == -1).all() and got["score_plus"].size == want_plus.size
 
 
 @pytest.mark.parametrize("name", VERBOSE_CASES)
