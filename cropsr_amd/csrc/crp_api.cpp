@@ -9,6 +9,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <sys/mman.h>
+
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -26,13 +28,125 @@ namespace {
 // arena positions (and therefore per-strand hit counts) stay below 2^31: the chained-scan
 // descriptors carry two 31-bit counts in one 64-bit word
 constexpr uint64_t kMaxArenaWords = (1ull << 31) / 64 - 2 * crp::ARENA_ALIGN_WORDS;
-constexpr uint64_t kUploadChunk = 64ull << 20;  // characters per H2D + pack round (multiple of 4096)
+constexpr uint64_t kUploadChunk = crp::STAGE_CHUNK;  // characters per H2D + pack round (multiple of 4096) = one pinned buffer
 
 inline uint64_t round_up(uint64_t x, uint64_t m) { return (x + m - 1) / m * m; }
 
 }  // namespace
 
 namespace crp {
+
+// populate: every thread first asks the kernel for its slice's pages in ONE call (MADV_POPULATE_WRITE, Linux 5.14+;
+// ignored where unknown) instead of taking a page fault per 4 KiB inside memcpy.  On plain malloc'ed memory that is
+// 56 GB/s with four threads against 6-14 GB/s by faults (profiles/microbench/pcie_copy.hip); numpy's large arrays,
+// however, are already advised for huge pages, and for them the plain copy measured faster (fetch of the bench
+// workload's tables: 0.044 s against 0.055 s) -- so the table fetches do not use it.
+void parallel_copy(void *dst, const void *src, size_t n, int threads, bool populate)
+{
+    constexpr size_t MIN_PER_THREAD = 2ull << 20;
+    const int t = (int)std::max<size_t>(1, std::min<size_t>((size_t)threads, n / MIN_PER_THREAD));
+    const size_t per = t <= 1 ? n : ((n + t - 1) / t + 4095) & ~(size_t)4095;
+    auto piece = [=](size_t a, size_t b) {
+        uint8_t *d = static_cast<uint8_t *>(dst) + a;
+        if (populate) {
+            const uintptr_t p0 = (reinterpret_cast<uintptr_t>(d) + 4095) & ~(uintptr_t)4095;
+            const uintptr_t p1 = (reinterpret_cast<uintptr_t>(d) + (b - a)) & ~(uintptr_t)4095;
+            if (p1 > p0) (void)madvise(reinterpret_cast<void *>(p0), p1 - p0, 23 /* MADV_POPULATE_WRITE */);
+        }
+        std::memcpy(d, static_cast<const uint8_t *>(src) + a, b - a);
+    };
+    if (t <= 1) {
+        piece(0, n);
+        return;
+    }
+    std::vector<std::thread> pool;
+    for (int k = 1; k < t; ++k) {
+        const size_t a = std::min(n, per * k), b = std::min(n, a + per);
+        if (a < b) pool.emplace_back(piece, a, b);
+    }
+    piece(0, std::min(n, per));
+    for (auto &th : pool) th.join();
+}
+
+int staging_ready(crp_ctx *ctx)
+{
+    if (ctx->pin[0]) return CRP_OK;
+    for (int b = 0; b < 2; ++b) {
+        CRP_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->pin[b]), STAGE_CHUNK, hipHostMallocDefault));
+        CRP_HIP(ctx, hipEventCreateWithFlags(&ctx->pin_done[b], hipEventDisableTiming));
+        ctx->pin_busy[b] = false;
+    }
+    return CRP_OK;
+}
+
+static int pin_wait(crp_ctx *ctx, int b)
+{
+    if (ctx->pin_busy[b]) {
+        CRP_HIP(ctx, hipEventSynchronize(ctx->pin_done[b]));
+        ctx->pin_busy[b] = false;
+    }
+    return CRP_OK;
+}
+
+int staged_h2d(crp_ctx *ctx, void *d_dst, const void *src, size_t n)
+{
+    if (n < STAGE_CHUNK / 4) {  // small: the runtime's own path (which returns once `src` has been read)
+        if (n) CRP_HIP(ctx, hipMemcpyAsync(d_dst, src, n, hipMemcpyHostToDevice, ctx->stream));
+        return CRP_OK;
+    }
+    int rc = staging_ready(ctx);
+    if (rc != CRP_OK) return rc;
+    int b = 0;
+    for (size_t off = 0; off < n; off += STAGE_CHUNK, b ^= 1) {
+        const size_t len = std::min(STAGE_CHUNK, n - off);
+        rc = pin_wait(ctx, b);  // the copy that last read this buffer has left
+        if (rc != CRP_OK) return rc;
+        parallel_copy(ctx->pin[b], static_cast<const uint8_t *>(src) + off, len, ctx->copy_threads, false);
+        CRP_HIP(ctx, hipMemcpyAsync(static_cast<uint8_t *>(d_dst) + off, ctx->pin[b], len, hipMemcpyHostToDevice, ctx->stream));
+        CRP_HIP(ctx, hipEventRecord(ctx->pin_done[b], ctx->stream));
+        ctx->pin_busy[b] = true;
+    }
+    return CRP_OK;
+}
+
+int staged_d2h(crp_ctx *ctx, void *dst, const void *d_src, size_t n)
+{
+    if (n < STAGE_CHUNK / 4) {
+        if (n) {
+            CRP_HIP(ctx, hipMemcpyAsync(dst, d_src, n, hipMemcpyDeviceToHost, ctx->stream));
+            CRP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        }
+        return CRP_OK;
+    }
+    int rc = staging_ready(ctx);
+    if (rc != CRP_OK) return rc;
+    for (int b = 0; b < 2; ++b) {
+        rc = pin_wait(ctx, b);
+        if (rc != CRP_OK) return rc;
+    }
+    // chunk k is copied out of its pinned buffer by the host threads (which also take the first-touch page faults of a
+    // fresh destination, in parallel) while chunk k + 1 crosses the link into the other one
+    size_t prev_off = 0, prev_len = 0;
+    int b = 0, prev_b = 0;
+    for (size_t off = 0; off < n; off += STAGE_CHUNK, b ^= 1) {
+        const size_t len = std::min(STAGE_CHUNK, n - off);
+        CRP_HIP(ctx, hipMemcpyAsync(ctx->pin[b], static_cast<const uint8_t *>(d_src) + off, len, hipMemcpyDeviceToHost, ctx->stream));
+        CRP_HIP(ctx, hipEventRecord(ctx->pin_done[b], ctx->stream));
+        if (prev_len) {
+            CRP_HIP(ctx, hipEventSynchronize(ctx->pin_done[prev_b]));
+            parallel_copy(static_cast<uint8_t *>(dst) + prev_off, ctx->pin[prev_b], prev_len, ctx->copy_threads, false);
+        }
+        prev_off = off;
+        prev_len = len;
+        prev_b = b;
+    }
+    if (prev_len) {
+        CRP_HIP(ctx, hipEventSynchronize(ctx->pin_done[prev_b]));
+        parallel_copy(static_cast<uint8_t *>(dst) + prev_off, ctx->pin[prev_b], prev_len, ctx->copy_threads, false);
+    }
+    return CRP_OK;
+}
+
 int grow(crp_ctx *ctx, void **p, uint64_t *cap, uint64_t need, size_t elem)
 {
     if (*cap >= need && *p) return CRP_OK;
@@ -102,6 +216,11 @@ int crp_init(int device_id, crp_ctx **out)
         return CRP_ERR_NOMEM;
     }
     if (const char *e = std::getenv("CRP_TEST_MUTE_TILE")) ctx->mute_tile = (uint32_t)std::strtoul(e, nullptr, 10);
+    {
+        const unsigned hw = std::thread::hardware_concurrency();
+        ctx->copy_threads = (int)std::max(1u, std::min(8u, hw ? hw / 2 : 4u));
+        if (const char *e = std::getenv("CRP_COPY_THREADS")) ctx->copy_threads = std::max(1, std::min(64, std::atoi(e)));
+    }
     *out = ctx;
     return CRP_OK;
 }
@@ -119,6 +238,10 @@ int crp_destroy(crp_ctx *ctx)
     (void)hipFree(ctx->d_rscore);
     (void)hipFree(ctx->d_scalar);
     if (ctx->h_scalar) (void)hipHostFree(ctx->h_scalar);
+    for (int b = 0; b < 2; ++b) {
+        if (ctx->pin[b]) (void)hipHostFree(ctx->pin[b]);
+        if (ctx->pin_done[b]) (void)hipEventDestroy(ctx->pin_done[b]);
+    }
     (void)hipFree(ctx->d_ot_hist);
     (void)hipFree(ctx->d_ot_ball);
     (void)hipFree(ctx->d_ot_part);
@@ -267,27 +390,38 @@ int crp_arena_add_contig_ascii(crp_arena *a, const uint8_t *text, uint64_t len, 
     if (rc != CRP_OK) return rc;
     CRP_HIP(ctx, hipSetDevice(ctx->device));
     const uint64_t n_words = crp_arena_words_for(len);
-    const uint64_t want = std::min<uint64_t>(kUploadChunk, round_up(std::max<uint64_t>(len, 1), 4096));
-    if (ctx->d_text_cap < want) {
-        CRP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        (void)hipFree(ctx->d_text);
-        ctx->d_text = nullptr;
-        ctx->d_text_cap = 0;
-        CRP_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_text), want));
-        ctx->d_text_cap = want;
+    if (!ctx->d_text) {
+        CRP_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_text), kUploadChunk));
+        ctx->d_text_cap = kUploadChunk;
     }
-    // Upload and pack in rounds of kUploadChunk characters (word-aligned cuts).
+    rc = crp::staging_ready(ctx);
+    if (rc != CRP_OK) return rc;
+    // Upload and pack in rounds of kUploadChunk characters (word-aligned cuts), every round through one of the two
+    // pinned buffers: the host threads copy round k + 1 out of the caller's pages while round k crosses the link and
+    // is packed.  Copies and pack kernels are ordered on the stream, so ONE device text buffer serves all rounds and
+    // all contigs, and nothing here waits for the GPU except for a pinned buffer that is still on the link: the call
+    // returns when `text` has been read (crp_arena_seal waits for the uploads).  A small contig costs a memcpy and
+    // two asynchronous calls, not a stream synchronisation.
     uint64_t c0 = 0;
     do {
         const uint64_t c1 = std::min<uint64_t>(len, c0 + kUploadChunk);
         const bool last = c1 == len;
         const uint64_t w0 = c0 / 64, w1 = last ? n_words : c1 / 64;
-        if (c1 > c0) CRP_HIP(ctx, hipMemcpyAsync(ctx->d_text, text + c0, c1 - c0, hipMemcpyHostToDevice, ctx->stream));
+        if (c1 > c0) {
+            const int b = ctx->pin_next;
+            ctx->pin_next ^= 1;
+            if (ctx->pin_busy[b]) {
+                CRP_HIP(ctx, hipEventSynchronize(ctx->pin_done[b]));
+                ctx->pin_busy[b] = false;
+            }
+            crp::parallel_copy(ctx->pin[b], text + c0, c1 - c0, ctx->copy_threads, false);
+            CRP_HIP(ctx, hipMemcpyAsync(ctx->d_text, ctx->pin[b], c1 - c0, hipMemcpyHostToDevice, ctx->stream));
+            CRP_HIP(ctx, hipEventRecord(ctx->pin_done[b], ctx->stream));
+            ctx->pin_busy[b] = true;
+        }
         CRP_HIP(ctx, crp::launch_pack(ctx->stream, ctx->d_text, c1 - c0, w1 - w0, a->d_plane[0] + w_first + w0,
                                       a->d_plane[1] + w_first + w0, a->d_plane[2] + w_first + w0,
                                       a->d_plane[3] + w_first + w0));
-        // the staging buffer is reused by the next round
-        CRP_HIP(ctx, hipStreamSynchronize(ctx->stream));
         c0 = c1;
     } while (c0 < len);
     a->used_words += n_words;
@@ -311,9 +445,10 @@ int crp_arena_add_contig_packed(crp_arena *a, const uint64_t *hi, const uint64_t
     const uint64_t body = (len + 63) / 64;
     const uint64_t *src[4] = {hi, lo, up, ac};
     if (body)
-        for (int p = 0; p < 4; ++p)
-            CRP_HIP(ctx, hipMemcpyAsync(a->d_plane[p] + w_first, src[p], body * sizeof(uint64_t),
-                                        hipMemcpyHostToDevice, ctx->stream));
+        for (int p = 0; p < 4; ++p) {
+            rc = crp::staged_h2d(ctx, a->d_plane[p] + w_first, src[p], body * sizeof(uint64_t));
+            if (rc != CRP_OK) return rc;
+        }
     CRP_HIP(ctx, hipStreamSynchronize(ctx->stream));  // caller may free its planes on return
     // the separator word after the body is still void from crp_arena_create
     a->used_words += crp_arena_words_for(len);
@@ -570,12 +705,15 @@ int crp_fetch_hits(crp_arena *a, uint32_t *pos_plus, double *pre_plus, double *s
     uint32_t *hp[2] = {pos_plus, pos_minus};
     double *hs[2] = {score_plus, score_minus};
     double *hr[2] = {pre_plus, pre_minus};
+    CRP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     for (int s = 0; s < 2; ++s) {
         const uint64_t n = a->n_hits[s];
         if (!n) continue;
-        if (hp[s]) CRP_HIP(ctx, hipMemcpyAsync(hp[s], a->d_pos[s], n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-        if (hs[s]) CRP_HIP(ctx, hipMemcpyAsync(hs[s], a->d_score[s], n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-        if (hr[s]) CRP_HIP(ctx, hipMemcpyAsync(hr[s], a->d_pre[s], n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        int rc = CRP_OK;
+        if (hp[s]) rc = crp::staged_d2h(ctx, hp[s], a->d_pos[s], n * sizeof(uint32_t));
+        if (rc == CRP_OK && hs[s]) rc = crp::staged_d2h(ctx, hs[s], a->d_score[s], n * sizeof(double));
+        if (rc == CRP_OK && hr[s]) rc = crp::staged_d2h(ctx, hr[s], a->d_pre[s], n * sizeof(double));
+        if (rc != CRP_OK) return rc;
     }
     CRP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return CRP_OK;

@@ -386,9 +386,11 @@ int crp_gathered_fetch(crp_ctx *ctx, int rank, uint32_t *pos_plus, double *score
             ds = c->d_gscore[s] + c->goff[s][(size_t)rank];
             if (c->gflags & CRP_GATHER_OFFTARGET) dt = c->d_got[s] + c->goff[s][(size_t)rank];
         }
-        if (ho[s]) CRP_HIP(ctx, hipMemcpyAsync(ho[s], dt, n * sizeof(uint4), hipMemcpyDeviceToHost, ctx->stream));
-        if (hp[s]) CRP_HIP(ctx, hipMemcpyAsync(hp[s], dp, n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-        if (hs[s]) CRP_HIP(ctx, hipMemcpyAsync(hs[s], ds, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        int rc = CRP_OK;
+        if (ho[s]) rc = crp::staged_d2h(ctx, ho[s], dt, n * sizeof(uint4));
+        if (rc == CRP_OK && hp[s]) rc = crp::staged_d2h(ctx, hp[s], dp, n * sizeof(uint32_t));
+        if (rc == CRP_OK && hs[s]) rc = crp::staged_d2h(ctx, hs[s], ds, n * sizeof(double));
+        if (rc != CRP_OK) return rc;
     }
     CRP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return CRP_OK;

@@ -32,6 +32,13 @@ struct crp_ctx {
     uint64_t chain_timeouts = 0;    // single-launch scans that were repeated with three launches
     uint32_t chain_timeout_ticks = 2000000;  // CRP_OPT_CHAIN_TIMEOUT_US in ticks of the 100 MHz real-time counter
     uint32_t mute_tile = 0xffffffffu;  // test hook (environment CRP_TEST_MUTE_TILE): see crp_kernels.h
+    // host <-> device staging for large transfers from / to pageable caller memory (crp_api.cpp: staged_h2d / staged_d2h):
+    // two pinned buffers, filled / drained by a few host threads while the other one is on the link
+    uint8_t *pin[2] = {nullptr, nullptr};
+    hipEvent_t pin_done[2] = {nullptr, nullptr};
+    bool pin_busy[2] = {false, false};
+    int pin_next = 0;  // the buffer the next upload round takes
+    int copy_threads = 8;  // environment CRP_COPY_THREADS
     // measurement
     int profiling = 0;  // 0 off, 1 emit kernel only, 2 all kernels
     hipEvent_t ev[2 * CRP_K_KINDS] = {};  // start/stop pair per kernel kind
@@ -119,6 +126,19 @@ inline void prof_collect(crp_ctx *ctx, int kind)
         ctx->launches[kind] += 1;
     }
 }
+
+// Large copies between pageable host memory and the device, pipelined through the context's two pinned buffers: a few
+// host threads move chunk k + 1 between the caller's pages and a pinned buffer while chunk k crosses the link (the
+// runtime's own pageable path does this with one thread: ~17 GB/s up, ~10 GB/s down into untouched pages on the
+// MI355X boxes).  Small copies go straight through hipMemcpyAsync.  Both are synchronous for the caller's memory:
+// on return of staged_h2d `src` may be reused (the device copy is ordered on the stream); staged_d2h returns with
+// `dst` filled.  `after_chunk`, if given, is called after chunk k's copy has been queued (e.g. to launch a kernel
+// that consumes it from a reused device buffer) with (offset, length).
+constexpr size_t STAGE_CHUNK = 32ull << 20;
+int staged_h2d(crp_ctx *ctx, void *d_dst, const void *src, size_t n);
+int staged_d2h(crp_ctx *ctx, void *dst, const void *d_src, size_t n);
+int staging_ready(crp_ctx *ctx);
+void parallel_copy(void *dst, const void *src, size_t n, int threads, bool populate);
 
 // grow-only device buffer: *p holds at least `need` elements of `elem` bytes afterwards
 int grow(crp_ctx *ctx, void **p, uint64_t *cap, uint64_t need, size_t elem);

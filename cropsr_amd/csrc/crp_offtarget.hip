@@ -561,11 +561,13 @@ int crp_offtarget_counts(crp_arena *a, uint32_t *counts_plus, uint32_t *counts_m
     CRP_HIP(ctx, hipGetLastError());
     crp::prof_end(ctx, CRP_K_OT_LOOKUP);
     uint32_t *host[2] = {counts_plus, counts_minus};
-    for (int s = 0; s < 2; ++s)
-        if (host[s] && a->n_hits[s])
-            CRP_HIP(ctx, hipMemcpyAsync(host[s], a->d_ot_cnt[s], a->n_hits[s] * sizeof(uint4), hipMemcpyDeviceToHost, ctx->stream));
     CRP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     crp::prof_collect(ctx, CRP_K_OT_LOOKUP);
+    for (int s = 0; s < 2; ++s)
+        if (host[s] && a->n_hits[s]) {
+            const int rc = crp::staged_d2h(ctx, host[s], a->d_ot_cnt[s], a->n_hits[s] * sizeof(uint4));
+            if (rc != CRP_OK) return rc;
+        }
     return CRP_OK;
 }
 
@@ -576,10 +578,12 @@ int crp_offtarget_seeds(crp_arena *a, uint32_t *seeds_plus, uint32_t *seeds_minu
     if (!a->have_hits || a->ot_epoch != ctx->ot_epoch || a->ot_epoch == 0) return CRP_ERR_STATE;
     CRP_HIP(ctx, hipSetDevice(ctx->device));
     uint32_t *host[2] = {seeds_plus, seeds_minus};
-    for (int s = 0; s < 2; ++s)
-        if (host[s] && a->n_hits[s])
-            CRP_HIP(ctx, hipMemcpyAsync(host[s], a->d_ot_seed[s], a->n_hits[s] * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     CRP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int s = 0; s < 2; ++s)
+        if (host[s] && a->n_hits[s]) {
+            const int rc = crp::staged_d2h(ctx, host[s], a->d_ot_seed[s], a->n_hits[s] * sizeof(uint32_t));
+            if (rc != CRP_OK) return rc;
+        }
     return CRP_OK;
 }
 

@@ -231,7 +231,7 @@ def test_every_position_a_hit_multi_round(engine, oracle):
     assert n > 100000
 
 
-@pytest.mark.parametrize("l", [1, 2, 7, 8, 9, 19, 21, 30, 50])
+@pytest.mark.parametrize("l", [0, 1, 2, 7, 8, 9, 19, 21, 30, 35, 36, 50])
 def test_guide_lengths_vs_oracle(engine, oracle, l):
     """-l != 20: the keep-filter moves and long_sequence is l+10 characters, so rows
     are unscored (-1, CROPSR.py:466-468) -- except, for l > 20, a window that the end
@@ -257,12 +257,12 @@ def test_unsupported_and_misordered_calls(engine):
     from cropsr_amd import CropsrHipError
     from cropsr_amd import _native as nat
     arena = engine.arena([b"ACGTGGCCACGT" * 10])
-    for l in (0, 51, -3):
+    for l in (51, -1, -3):  # (0 is the bare PAM filter the host uses for -l <= 0; cli.device_guide_length)
         with pytest.raises(CropsrHipError) as e:
             arena.scan_score(l)
         assert e.value.status == -7  # CRP_ERR_UNSUPPORTED
     with pytest.raises(CropsrHipError) as e:
-        arena.fetch(1, 1)  # nothing scanned yet
+        arena.fetch(1, 1)  # nothing scanned yet (a refused scan leaves no tables)
     assert e.value.status == -5  # CRP_ERR_STATE
     arena.close()
     L = nat.lib()
