@@ -304,11 +304,11 @@ int crp_offtarget_seeds(crp_arena *arena, uint32_t *seeds_plus, uint32_t *seeds_
 /* ---- options -------------------------------------------------------------- */
 /* CRP_OPT_TWO_PASS (value 0/1, default 0): with 0 crp_scan_score is ONE kernel launch; the
  * table offsets come from a chained scan across workgroups inside it (decoupled look-back
- * over per-tile descriptors; every wait is bounded).  With 1 it runs the count /
+ * over per-tile descriptors; every wait is bounded in wall time).  With 1 it runs the count /
  * tile-scan / emit+score launch sequence (one more pass over the packed planes).  Results
- * are identical; the single launch is ~10 % faster on MI355X.  Should a
- * look-back ever time out, the scan is repeated with the three-launch sequence and the
- * context stays in that mode. */
+ * are identical; the single launch is ~20 % faster per scan on MI355X.
+ * A scan in which a look-back ran out of its allowance is repeated with the three-launch
+ * sequence (see CRP_OPT_CHAIN_TIMEOUT_US); the setting itself is not changed by that. */
 #define CRP_OPT_TWO_PASS 1
 /* CRP_OPT_CHAIN_TIMEOUT_US (default 20000): how long a workgroup of the single-launch scan waits for
  * a predecessor's counts before it gives up (wall time, read from the GPU's 100 MHz real-time
