@@ -312,8 +312,8 @@ def run(args, backend=None, out=sys.stdout, group=None):
         sys.exit("Please select at least one CRISPR system: Cas9")  # CROPSR.py:335-336
     offtarget = bool(getattr(args, "offtarget", False))
     l_dev = device_guide_length(args.l)
-    if offtarget and l_dev != args.l:  # (checked before any side effect, on every rank)
-        sys.exit("cropsr_amd: --offtarget needs a guide length between 0 and %d (got %d)" % (NATIVE_GUIDE_LENGTHS[1], args.l))
+    if offtarget and not NATIVE_GUIDE_LENGTHS[0] <= args.l <= NATIVE_GUIDE_LENGTHS[1]:  # (before any side effect, on every rank)
+        sys.exit("cropsr_amd: --offtarget needs a guide length between %d and %d (got %d)" % (NATIVE_GUIDE_LENGTHS + (args.l,)))
     finalize = getattr(args, "score_finalize", "gpu")
     stages = {}  # --bench-json
     own_group = group is None
