@@ -229,6 +229,18 @@ def _cli_worker(rank, world, port, probe, max_piece, out_dir, extra):
     group.close()
 
 
+@pytest.mark.parametrize("probe,l,world,max_piece", [("mixed", 100, 2, 150), ("multi", -3, 3, 60), ("rightend", 35, 2, 40)])
+def test_cli_multi_process_other_guide_lengths(probe, l, world, max_piece, manifest, tmp_path):
+    """-l beyond the engine's range through the sharded flow: every rank scans its pieces with the clamped length, the
+    literal keep-filter runs on rank 0 on the STITCHED per-contig tables (whole-contig coordinates and lengths), and the
+    bytes are the real reference's for that -l."""
+    from conftest import read_golden_csv
+    assert _spawn(_cli_worker, world, probe, max_piece, str(tmp_path), ("-l", str(l))) == [0] * world
+    with open(tmp_path / "rank0" / "out.csv", "rb") as f:
+        assert f.read() == read_golden_csv(probe, l)
+    assert (tmp_path / "rank0" / "stdout.txt").read_text() == manifest["cases"]["%s.l%d" % (probe, l)]["stdout"]
+
+
 @pytest.mark.parametrize("probe,world,max_piece", [("multi", 2, 0), ("mixed", 3, 100), ("tiny", 2, 40)])
 def test_cli_multi_process_equals_reference(probe, world, max_piece, manifest, tmp_path):
     """python -m cropsr_amd launched as `world` processes (what torch.distributed.run does): contigs
@@ -337,8 +349,17 @@ def test_rendezvous_refuses_strangers(tmp_path):
     s = socket.create_connection((info["host"], info["port"]))
     blob = pickle.dumps({"rank": 1, "world": 2, "token": "0" * 32})
     s.sendall(struct.pack("<Q", len(blob)) + blob)
-    _time.sleep(0.2)
-    assert 0 not in groups  # still waiting for the real rank 1
+    # hellos whose fields have the wrong TYPES -- without the token (a rank of 'x' used to raise TypeError out
+    # of the accept loop and kill rank 0's rendezvous) and with it: judged, dropped, nothing raised
+    for hello in ({"world": 2, "rank": "x"}, {"world": 2, "rank": [1]}, {"world": "2", "rank": 1, "token": info["token"]},
+                  {"world": 2, "rank": True, "token": info["token"]}, {"world": 2, "rank": 1.0, "token": info["token"]},
+                  {"world": 2, "rank": 1, "token": None}, ["rank", 1], None, {"world": 2, "rank": 7, "token": info["token"]}):
+        c = socket.create_connection((info["host"], info["port"]))
+        blob = pickle.dumps(hello)
+        c.sendall(struct.pack("<Q", len(blob)) + blob)
+        c.close()
+    _time.sleep(0.3)
+    assert t.is_alive() and 0 not in groups  # still waiting for the real rank 1
     groups[1] = rz.Group(1, 2, 1, None, path)
     t.join(10)
     assert 0 in groups
