@@ -32,6 +32,7 @@ SIGNATURES = {
     "crp_arena_create": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, voidpp]),
     "crp_arena_destroy": (ctypes.c_int, [ctypes.c_void_p]),
     "crp_arena_add_contig_ascii": (ctypes.c_int, [ctypes.c_void_p, u8p, ctypes.c_uint64, u64p]),
+    "crp_arena_add_contigs_ascii": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), u64p, ctypes.c_uint64, u64p]),
     "crp_arena_add_contig_packed": (ctypes.c_int, [ctypes.c_void_p, u64p, u64p, u64p, u64p,
                                                    ctypes.c_uint64, u64p]),
     "crp_arena_seal": (ctypes.c_int, [ctypes.c_void_p]),

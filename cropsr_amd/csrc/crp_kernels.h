@@ -58,6 +58,16 @@ hipError_t launch_count_scored(hipStream_t s, const double *score, uint64_t n, u
 hipError_t launch_score30(hipStream_t s, const uint8_t *rows, uint64_t n, int order, double *pre, double *score);
 hipError_t launch_pack(hipStream_t s, const uint8_t *text, uint64_t len, uint64_t n_words, uint64_t *hi,
                        uint64_t *lo, uint64_t *up, uint64_t *ac);
+// one wave's work in pack_groups_kernel: <= 64 words of one contig of a batch
+struct PackGroup {
+    uint32_t src;       // byte offset of the group's first character in the device text buffer (multiple of 16)
+    uint32_t n_chars;   // real characters of the group (<= 4096); the rest of its words is void
+    uint64_t dst_word;  // first plane word it fills
+    uint32_t n_words;   // <= 64
+    uint32_t pad;
+};
+hipError_t launch_pack_groups(hipStream_t s, const uint8_t *text, const PackGroup *groups, uint32_t n_groups, uint64_t *hi,
+                              uint64_t *lo, uint64_t *up, uint64_t *ac);
 uint8_t host_classify_char(uint32_t ch);
 
 // Raw seed word the emit kernel writes per hit when HitTables::seed_* are set (guide lengths >= 20):

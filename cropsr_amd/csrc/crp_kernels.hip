@@ -994,6 +994,52 @@ __global__ __launch_bounds__(BLOCK) void pack_kernel(const uint8_t *__restrict__
     }
 }
 
+// The same packing for a BATCH of small contigs that were copied to the device back to back (crp_arena_add_contigs_ascii):
+// one wave per group of <= 64 words of ONE contig; `groups` says where the group's characters start in `text`, how many
+// of them are real (the rest of its words is void: the contig's tail and its separator word) and which words it fills.
+__global__ __launch_bounds__(BLOCK) void pack_groups_kernel(const uint8_t *__restrict__ text, const PackGroup *__restrict__ groups,
+                                                             uint32_t n_groups, uint64_t *__restrict__ hi, uint64_t *__restrict__ lo,
+                                                             uint64_t *__restrict__ up, uint64_t *__restrict__ ac)
+{
+    __shared__ uint8_t lut[256];
+    __shared__ __attribute__((aligned(16))) uint8_t buf[BLOCK / 64][4096];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    lut[tid] = classify_char(tid);
+    const uint32_t n_iters = (n_groups + BLOCK / 64 - 1) / (BLOCK / 64);
+    for (uint32_t it = blockIdx.x; it < n_iters; it += gridDim.x) {
+        const uint32_t g = it * (BLOCK / 64) + wave;
+        __syncthreads();  // lut ready / previous iteration's reads done
+        PackGroup pg{0, 0, 0, 0, 0};
+        if (g < n_groups) {
+            pg = groups[g];
+            // (reads up to 4096 bytes from the group's start: inside the device text buffer by construction, what lies
+            // behind the group's own characters is masked below)
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                *reinterpret_cast<uint4 *>(&buf[wave][k * 1024 + lane * 16]) =
+                    *reinterpret_cast<const uint4 *>(text + pg.src + (uint32_t)k * 1024 + (uint32_t)lane * 16);
+        }
+        __syncthreads();
+        if (g < n_groups) {
+            uint64_t w_hi = 0, w_lo = 0, w_up = 0, w_ac = 0;
+            for (uint32_t t = 0; t < pg.n_words; ++t) {
+                const uint32_t idx = t * 64 + lane;
+                const uint32_t nib = idx < pg.n_chars ? lut[buf[wave][idx]] : 0x3u;  // void past the end
+                const uint64_t b0 = __ballot(nib & 1), b1 = __ballot(nib & 2);
+                const uint64_t b2 = __ballot(nib & 4), b3 = __ballot(nib & 8);
+                if ((uint32_t)lane == t) { w_hi = b0; w_lo = b1; w_up = b2; w_ac = b3; }
+            }
+            if ((uint32_t)lane < pg.n_words) {
+                const uint64_t w = pg.dst_word + lane;
+                hi[w] = w_hi;
+                lo[w] = w_lo;
+                up[w] = w_up;
+                ac[w] = w_ac;
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------ launch wrappers
 hipError_t launch_count(hipStream_t s, const Planes &pl, uint64_t n_words_padded, int l, uint2 *tile_cnt,
                         uint32_t n_tiles)
@@ -1071,6 +1117,15 @@ hipError_t launch_score30(hipStream_t s, const uint8_t *rows, uint64_t n, int or
     const uint64_t blocks = (n + BLOCK - 1) / BLOCK;
     const uint32_t grid = (uint32_t)(blocks < 8192 ? blocks : 8192);
     hipLaunchKernelGGL(score30_kernel, dim3(grid), dim3(BLOCK), 0, s, rows, n, pre, score);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_groups(hipStream_t s, const uint8_t *text, const PackGroup *groups, uint32_t n_groups, uint64_t *hi,
+                              uint64_t *lo, uint64_t *up, uint64_t *ac)
+{
+    if (n_groups == 0) return hipSuccess;
+    const uint32_t iters = (n_groups + BLOCK / 64 - 1) / (BLOCK / 64);
+    hipLaunchKernelGGL(pack_groups_kernel, dim3(iters < 4096 ? iters : 4096), dim3(BLOCK), 0, s, text, groups, n_groups, hi, lo, up, ac);
     return hipGetLastError();
 }
 

@@ -28,6 +28,19 @@ def _as_u8(s):
     return np.frombuffer(s, dtype=np.uint8)
 
 
+def _add_contigs(handle, bufs, ctx):
+    """crp_arena_add_contigs_ascii for a list of uint8 arrays: small contigs share one copy and one pack launch."""
+    n = len(bufs)
+    offs = np.zeros(n, dtype=np.uint64)
+    if n:
+        ptrs = (ctypes.c_void_p * n)(*[b.ctypes.data if b.size else None for b in bufs])
+        lens = np.array([b.size for b in bufs], dtype=np.uint64)
+        nat.check(nat.lib().crp_arena_add_contigs_ascii(handle, ptrs, lens.ctypes.data_as(nat.u64p), n,
+                                                        offs.ctypes.data_as(nat.u64p)),
+                  "crp_arena_add_contigs_ascii", ctx)
+    return offs
+
+
 class Hits:
     """Hit tables of one Arena.scan_score() call (host copies).
 
@@ -238,18 +251,17 @@ class Engine:
         offsets = np.zeros(len(bufs), dtype=np.uint64)
         lengths = np.array([b.size for b in bufs], dtype=np.uint64)
         try:
-            for k, b in enumerate(bufs):
-                off = ctypes.c_uint64()
-                if pack == "device":
-                    st = L.crp_arena_add_contig_ascii(h, b.ctypes.data_as(nat.u8p), b.size, ctypes.byref(off))
-                elif pack == "host":
+            if pack == "device":
+                offsets = _add_contigs(h, bufs, self._ctx)  # one call: small contigs travel and are packed in batches
+            elif pack == "host":
+                for k, b in enumerate(bufs):
+                    off = ctypes.c_uint64()
                     planes = pack_ascii(b, pack_threads)
-                    st = L.crp_arena_add_contig_packed(h, *[p.ctypes.data_as(nat.u64p) for p in planes],
-                                                       b.size, ctypes.byref(off))
-                else:
-                    raise ValueError("pack must be 'device' or 'host'")
-                nat.check(st, "crp_arena_add_contig", self._ctx)
-                offsets[k] = off.value
+                    nat.check(L.crp_arena_add_contig_packed(h, *[p.ctypes.data_as(nat.u64p) for p in planes],
+                                                            b.size, ctypes.byref(off)), "crp_arena_add_contig", self._ctx)
+                    offsets[k] = off.value
+            else:
+                raise ValueError("pack must be 'device' or 'host'")
             nat.check(L.crp_arena_seal(h), "crp_arena_seal", self._ctx)
         except Exception:
             L.crp_arena_destroy(h)
@@ -419,6 +431,14 @@ class Engine:
 
 
 class ArenaBuilder:
+    """Incremental upload: announce the contig lengths, then add() the strings in that order.  Small contigs are held
+    back (by reference) and handed to the library in batches -- one host-to-device copy and one pack launch per batch
+    instead of one each per contig; a large contig flushes what is pending and goes at once, so at most one large
+    string is alive here at a time."""
+
+    SMALL = 8 << 20       # the library's own threshold (a quarter of its staging buffer)
+    FLUSH_BYTES = 24 << 20
+
     def __init__(self, engine, lengths):
         L = nat.lib()
         self._engine = engine
@@ -428,22 +448,28 @@ class ArenaBuilder:
         nat.check(L.crp_arena_create(engine._ctx, L.crp_arena_words_total(total), ctypes.byref(self._h)),
                   "crp_arena_create", engine._ctx)
         self._offsets = []
+        self._pending, self._pending_bytes, self._n_added = [], 0, 0
+
+    def _flush(self):
+        if self._pending:
+            self._offsets.extend(int(o) for o in _add_contigs(self._h, self._pending, self._engine._ctx))
+            self._pending, self._pending_bytes = [], 0
 
     def add(self, contig):
         b = _as_u8(contig)
-        k = len(self._offsets)
+        k = self._n_added
         if k >= len(self._lengths) or b.size != self._lengths[k]:
             raise ValueError("contig %d: length differs from the one announced" % k)
-        off = ctypes.c_uint64()
-        nat.check(nat.lib().crp_arena_add_contig_ascii(self._h, b.ctypes.data_as(nat.u8p), b.size,
-                                                       ctypes.byref(off)),
-                  "crp_arena_add_contig_ascii", self._engine._ctx)
-        self._offsets.append(off.value)
-        return off.value
+        self._n_added += 1
+        self._pending.append(b)
+        self._pending_bytes += b.size
+        if b.size >= self.SMALL or self._pending_bytes >= self.FLUSH_BYTES:
+            self._flush()
 
     def seal(self):
-        if len(self._offsets) != len(self._lengths):
+        if self._n_added != len(self._lengths):
             raise ValueError("not every announced contig was added")
+        self._flush()
         nat.check(nat.lib().crp_arena_seal(self._h), "crp_arena_seal", self._engine._ctx)
         a = Arena(self._engine, self._h, np.array(self._offsets, dtype=np.uint64),
                   np.array(self._lengths, dtype=np.uint64))

@@ -103,6 +103,12 @@ int crp_arena_destroy(crp_arena *arena);
  * P belongs to the contig with the largest offset <= P, at index P - offset. */
 int crp_arena_add_contig_ascii(crp_arena *arena, const uint8_t *text, uint64_t len,
                                uint64_t *arena_offset);
+/* n contigs in one call, in order (arena_offsets: n values, may be NULL).  Same result as n calls of
+ * crp_arena_add_contig_ascii; small contigs (an assembly's scaffolds) share one host-to-device copy and one pack
+ * launch per ~31 MiB instead of paying a copy, a launch and an event each.  On an error the contigs before the failing
+ * one have been added. */
+int crp_arena_add_contigs_ascii(crp_arena *arena, const uint8_t *const *texts, const uint64_t *lens, uint64_t n,
+                                uint64_t *arena_offsets);
 /* Same, from planes packed on the host with crp_pack_ascii. */
 int crp_arena_add_contig_packed(crp_arena *arena, const uint64_t *hi, const uint64_t *lo,
                                 const uint64_t *up, const uint64_t *ac, uint64_t len,

@@ -509,6 +509,38 @@ def test_baseline_config_workloads_whole_genome_digest(_engine, oracle, config):
           % (config, len(want), n_hits, hashlib.sha256("".join(got).encode()).hexdigest()))
 
 
+def test_many_small_contigs_between_large_ones(engine, oracle):
+    """crp_arena_add_contigs_ascii: thousands of small contigs (empty ones, lengths around the 64-word group and the
+    16-byte alignment of the batch buffer) share copies and pack launches, large ones (>= 8 MiB) stream through the
+    single-contig path in between; the order, the arena offsets and every hit table are what one contig at a time gives
+    -- checked against the oracle contig by contig, through Engine.arena and through the buffering ArenaBuilder."""
+    rng = np.random.default_rng(4242)
+    a = np.frombuffer(b"ACGTacgtNGGCC", dtype=np.uint8)
+    sizes = [0, 1, 15, 16, 17, 63, 64, 65, 4095, 4096, 4097, 8191, 8192, 70000] + rng.integers(0, 9000, 2500).tolist()
+    contigs = [rng.choice(a, int(n)).tobytes() for n in sizes]
+    big = np.frombuffer(b"'", dtype=np.uint8).tolist() + rng.choice(a, (9 << 20) + 123).tolist()
+    big = bytes(big) + b"'),"
+    contigs = contigs[:700] + [big] + contigs[700:1500] + [big[: 8 << 20]] + contigs[1500:]
+    want_big = oracle.scan_score(big, 20)
+    for how in ("arena", "builder"):
+        if how == "arena":
+            arena = engine.arena(contigs)
+        else:
+            b = engine.arena_builder([len(c) for c in contigs])
+            for c in contigs:
+                b.add(c)
+            arena = b.seal()
+        assert arena.stats()["n_contigs"] == len(contigs)
+        assert (np.diff(arena.offsets.astype(np.int64)) > 0).all() and (arena.offsets % 64 == 0).all()
+        hits = arena.scan_score(20, want_pre=True)
+        for k in list(range(0, len(contigs), 37)) + [700, 1501]:
+            want = want_big if k == 700 else oracle.scan_score(contigs[k], 20)
+            assert_hits_equal(hits.contig(k), want, ctx=(how, k))
+        total = sum(oracle.scan(c, 20)[0].size + oracle.scan(c, 20)[1].size for c in contigs)
+        assert hits.n_plus + hits.n_minus == total
+        arena.close()
+
+
 def test_empty_and_degenerate_arenas(engine, oracle):
     """No contig at all, only empty contigs, contigs shorter than any window, a contig of
     characters that are no bases: the oracle's (mostly empty) tables, no error, in both scan modes."""
