@@ -287,6 +287,30 @@ def test_deterministic_and_repeatable(engine):
     arena.close()
 
 
+def test_fetch_into_reused_arrays(engine, oracle):
+    """Arena.fetch(out=...) fills the arrays of a previous fetch again (a caller that keeps its host buffers does not pay
+    the first touch of fresh pages): same values, same storage where it is large enough, fresh arrays where it is not."""
+    rng = np.random.default_rng(8)
+    a = np.frombuffer(b"ACGTacgtNGGCC", dtype=np.uint8)
+    big, small = rng.choice(a, 60000).tobytes(), rng.choice(a, 9000).tobytes()
+    ar_big, ar_small = engine.arena([big]), engine.arena([small])
+    nb, ns = ar_big.scan_score_device(20, want_pre=True), ar_small.scan_score_device(20, want_pre=True)
+    first = ar_big.fetch(*nb, want_pre=True)
+    keep = [c.copy() for c in first]
+    again = ar_small.fetch(*ns, want_pre=True, out=first)          # smaller tables: views of the same storage
+    assert all(np.shares_memory(x, y) for x, y in zip(again, first))
+    want = oracle.scan_score(small, 20)
+    off = int(ar_small.offsets[0])
+    assert (again[0] - off == want["pos_plus"]).all() and (bits(again[2]) == bits(want["score_plus"])).all()
+    assert (again[3] - off == want["pos_minus"]).all() and (bits(again[4]) == bits(want["pre_minus"])).all()
+    back = ar_big.fetch(*nb, want_pre=True, out=again)              # larger tables than the views: fresh arrays
+    assert all((bits(x) == bits(y)).all() for x, y in zip(back, keep))
+    no_pre = ar_big.fetch(*nb, out=back)
+    assert no_pre[1] is None and no_pre[4] is None and np.shares_memory(no_pre[0], back[0])
+    ar_big.close()
+    ar_small.close()
+
+
 def test_single_pass_equals_two_pass(engine):
     """crp_scan_score's one-kernel mode (chained scan across workgroups) and the
     count / scan / emit sequence must produce identical tables; poly-G forces the
