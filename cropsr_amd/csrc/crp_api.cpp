@@ -18,6 +18,7 @@
 #include <new>
 #include <string>
 #include <thread>
+#include <utility>
 #include <vector>
 
 #include "crp_internal.h"
@@ -45,7 +46,6 @@ void parallel_copy(void *dst, const void *src, size_t n, int threads, bool popul
 {
     constexpr size_t MIN_PER_THREAD = 2ull << 20;
     const int t = (int)std::max<size_t>(1, std::min<size_t>((size_t)threads, n / MIN_PER_THREAD));
-    const size_t per = t <= 1 ? n : ((n + t - 1) / t + 4095) & ~(size_t)4095;
     auto piece = [=](size_t a, size_t b) {
         uint8_t *d = static_cast<uint8_t *>(dst) + a;
         if (populate) {
@@ -59,13 +59,29 @@ void parallel_copy(void *dst, const void *src, size_t n, int threads, bool popul
         piece(0, n);
         return;
     }
-    std::vector<std::thread> pool;
-    for (int k = 1; k < t; ++k) {
-        const size_t a = std::min(n, per * k), b = std::min(n, a + per);
-        if (a < b) pool.emplace_back(piece, a, b);
+    // (nothing may throw across the C ABI: no allocation here, and a thread that cannot be started is replaced by
+    // doing its slice on this one)
+    constexpr int MAX_THREADS = 64;
+    std::thread pool[MAX_THREADS];
+    size_t todo[MAX_THREADS][2];
+    int n_todo = 0;
+    const int tt = std::min(t, MAX_THREADS);
+    const size_t per_t = ((n + tt - 1) / tt + 4095) & ~(size_t)4095;
+    for (int k = 1; k < tt; ++k) {
+        const size_t a = std::min(n, per_t * k), b = std::min(n, a + per_t);
+        if (a >= b) continue;
+        try {
+            pool[k] = std::thread(piece, a, b);
+        } catch (...) {
+            todo[n_todo][0] = a;
+            todo[n_todo][1] = b;
+            ++n_todo;
+        }
     }
-    piece(0, std::min(n, per));
-    for (auto &th : pool) th.join();
+    piece(0, std::min(n, per_t));
+    for (int k = 0; k < n_todo; ++k) piece(todo[k][0], todo[k][1]);
+    for (int k = 1; k < tt; ++k)
+        if (pool[k].joinable()) pool[k].join();
 }
 
 int staging_ready(crp_ctx *ctx)
@@ -459,6 +475,11 @@ int crp_arena_add_contigs_ascii(crp_arena *a, const uint8_t *const *texts, const
     for (uint64_t i = 0; i < n; ++i)
         if (lens[i] && !texts[i]) return CRP_ERR_INVALID;
     std::vector<crp::PackGroup> groups;
+    try {
+        groups.reserve(kMaxGroups);  // the only allocation of this call: nothing below can throw
+    } catch (...) {
+        return CRP_ERR_NOMEM;
+    }
     uint64_t i = 0;
     while (i < n) {
         if (lens[i] >= kSmall) {
