@@ -325,13 +325,22 @@ int crp_pack_ascii(const uint8_t *text, uint64_t len, uint64_t *hi, uint64_t *lo
         pack_range(text, len, 0, n_words, lut, hi, lo, up, ac);
         return CRP_OK;
     }
-    std::vector<std::thread> pool;
+    // (no allocation, and a thread that cannot be started is replaced by packing its range here: nothing throws)
+    constexpr int MAX_THREADS = 64;
+    n_threads = std::min(n_threads, MAX_THREADS);
+    std::thread pool[MAX_THREADS];
     const uint64_t per = (n_words + n_threads - 1) / n_threads;
     for (int t = 0; t < n_threads; ++t) {
         const uint64_t w0 = std::min<uint64_t>(n_words, per * t), w1 = std::min<uint64_t>(n_words, w0 + per);
-        if (w0 < w1) pool.emplace_back(pack_range, text, len, w0, w1, lut, hi, lo, up, ac);
+        if (w0 >= w1) continue;
+        try {
+            pool[t] = std::thread(pack_range, text, len, w0, w1, lut, hi, lo, up, ac);
+        } catch (...) {
+            pack_range(text, len, w0, w1, lut, hi, lo, up, ac);
+        }
     }
-    for (auto &th : pool) th.join();
+    for (int t = 0; t < n_threads; ++t)
+        if (pool[t].joinable()) pool[t].join();
     return CRP_OK;
 }
 
