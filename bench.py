@@ -222,7 +222,9 @@ def main():
         t_upload += time.perf_counter() - t_up
         my_bases += genomes[g].specs[k].length
         del s
-    arena = builder.seal()
+    t_up = time.perf_counter()
+    arena = builder.seal()  # (flushes the small contigs the builder still holds, waits for the uploads)
+    t_upload += time.perf_counter() - t_up
     t_gen = time.perf_counter() - t_gen
 
     def gatherv(n_plus, n_minus):
