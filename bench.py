@@ -67,6 +67,9 @@ def parse_args():
     ap.add_argument("--share-gpu0", action="store_true",
                     help="rehearsal only: every rank uses device 0; fences and sums go over the control sockets and "
                          "the gatherv over the host transport (RCCL cannot put two ranks on one GPU)")
+    ap.add_argument("--collective-timeout", type=float, default=300.0,
+                    help="N > 1: rank 0 prints the line with the timed steps' numbers and aborts the run if the final gatherv "
+                         "or the off-target block does not return within this many seconds (0 = wait for ever)")
     ap.add_argument("--launch-timeout", type=float, default=1500.0,
                     help="--gpus N without a launcher: stop the self-started ranks after this many seconds")
     ap.add_argument("--offtarget-steps", type=int, default=5,
@@ -313,10 +316,125 @@ def main():
                    "bases": int(my_bases), "kept_hits": int(n_plus + n_minus), "gRNAs_scored": int(scored)}
     per_rank = group.all_gather(mine_report) if group else [mine_report]
 
+    # ---- everything the line needs that the collectives below cannot change, taken NOW: if the exchange (or the
+    # off-target block's all-reduce) never returns on this node, rank 0's watchdog still prints the scan's numbers
+    info = eng.device_info() if rank == 0 else None
+    build_id = nat.lib().crp_build_id().decode()
+    n_chars = arena.stats()["n_chars"]
+
+    def build_line(gather_info, ot):
+        hits = n_plus + n_minus
+        algo_bytes = (n_chars + 3) // 4 + 2 * ((n_chars + 7) // 8) + 12 * hits  # SURVEY.md 8d, rank 0's launch
+        emit = prof["emit_score"]
+        emit_ms = emit["ms"] / max(1, emit["launches"])
+        achieved = algo_bytes / (emit_ms * 1e-3) / 1e9
+        path_ms = sum(prof[k]["ms"] / max(1, prof[k]["launches"]) for k in ("count", "tile_scan", "emit_score"))
+        facts, facts_src = load_profile_facts(build_id, genomes[0].name)
+        three_launches = bool(args.two_pass or state["two_pass_active"])
+        roof = {"bound": "hbm",
+                "kernel": "emit_kernel (scan+compact+score)" if three_launches else
+                          "emit_kernel, single launch (masks + chained tile offsets + compact + score)",
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": facts.get("hbm_bytes_per_launch") if facts else None, "traffic_source": facts_src,
+                "algorithmic_bytes_per_launch": int(algo_bytes),
+                "kernel_ms": emit_ms, "all_kernels_ms": path_ms,
+                "count_kernel_ms": prof["count"]["ms"] / max(1, prof["count"]["launches"]),
+                "tile_scan_ms": prof["tile_scan"]["ms"] / max(1, prof["tile_scan"]["launches"])}
+        if facts and facts.get("valu_insts_per_launch") and facts.get("kernel_cycles_per_launch"):
+            # the second, honest ceiling: the kernel is VALU-issue bound (one wave64 VALU instruction
+            # holds its SIMD for 4 cycles on average here): issue slots used / issue slots there were
+            roof["valu_issue_frac"] = facts["valu_insts_per_launch"] * 4.0 / N_SIMD / facts["kernel_cycles_per_launch"]
+            roof["valu_insts_per_launch"] = facts["valu_insts_per_launch"]
+        line = {
+            "metric": "gRNAs scored/sec", "value": scored_all * args.steps / dt, "unit": "gRNAs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "untimed_steps_before": n_warm,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": genomes[0].name, "genomes": world, "contigs_per_genome": len(genomes[0].specs),
+                       "bases_total": int(bases_all), "kept_hits_total": int(hits_all),
+                       "guide_len": 20,
+                       "launches_per_step": 3 if three_launches else 1,
+                       # single-launch scans that timed out in a look-back and were repeated as three launches
+                       "chain_timeouts": state["chain_timeouts"],
+                       "parallelism": ("contigs by LPT over %d ranks" % world) +
+                       ("" if not want_gather else (" + %s gatherv to rank 0 " % ("RCCL (in-library)" if use_rccl else "host-socket") +
+                                                    ("every step" if args.gather_every_step else "once, after the steps"))),
+                       "device": info["name"].strip(), "library_build": build_id},
+            "bases_per_s": bases_all * args.steps / dt,
+            "per_rank": per_rank,
+            "roofline": roof,
+            "setup_s": {"generate_pack_upload": t_gen},
+            # host-buffer boundary: characters H2D + pack, one scan, tables D2H (never `value`)
+            "pcie_inclusive": {"upload_pack_s": t_upload, "fetch_tables_s": t_fetch,
+                               # the same fetch into the SAME host arrays (pages already touched): the link's rate
+                               "fetch_tables_into_reused_arrays_s": t_fetch_again,
+                               "gRNAs_per_s": scored / (t_upload + dt / args.steps + t_fetch)},
+        }
+        if rccl_error:
+            line["rccl_error"] = rccl_error
+        if ot is not None:
+            if facts and "roofline" in ot:
+                # counter traffic exists for the ball passes only (streaming reads, where the gfx950 FETCH_SIZE correction
+                # is calibrated); the look-up's gathers and the partition's scatters are not calibrated: whole step = null
+                ot["roofline"]["stage_traffic"] = {"ball_passes": facts.get("offtarget_ball_hbm_bytes_per_step")}
+                ot["roofline"]["traffic_source"] = facts_src
+            line["offtarget"] = ot
+        if gather_info is not None:
+            line["gatherv_ok"] = "s" in gather_info
+            if "s" in gather_info:
+                moved = 12.0 * (hits_all - hits)  # bytes that crossed xGMI to rank 0
+                gather_info.update({"bytes_to_root": int(moved), "GB_per_s_into_root": moved / gather_info["s"] / 1e9})
+                # the WHOLE job of the path at N ranks = one scan on every rank + the one exchange: this, not
+                # `value` (whose timed steps hold no collective and therefore grow ~N-fold by construction),
+                # is the number to build a scaling curve from
+                line["value_with_final_gatherv"] = scored_all / (dt / args.steps + gather_info["s"])
+                line["ms_scan_plus_gatherv"] = (dt / args.steps + gather_info["s"]) * 1e3
+            line["gatherv"] = gather_info
+        return line
+
+    # Rank 0's watchdog over the collectives that follow (RCCL has no time-out of its own): if one of them does not return
+    # within --collective-timeout seconds, the line is printed with what the timed steps measured and the run is taken
+    # down through the abort channel (non-zero exit on every rank) -- an unattended first multi-GPU run leaves data behind
+    # even if the node's RCCL cannot complete a point-to-point exchange.
+    import threading
+    watch = {"stage": None, "timer": None, "lock": threading.Lock(), "fired": False}
+
+    def _timed_out():
+        with watch["lock"]:  # the collective may return at the very moment the timer fires: one of the two prints
+            if watch["timer"] is None:
+                return
+            watch["fired"] = True
+        stage = watch["stage"]
+        why = "%s did not return within %.0f s" % (stage, args.collective_timeout)
+        gi = {"error": why} if stage == "final gatherv" else gather_info
+        oi = {"error": why} if stage != "final gatherv" else None
+        try:
+            print(json.dumps(build_line(gi, oi)), flush=True)
+        finally:
+            group.abort("bench: " + why)
+
+    def guard(stage):
+        if rank == 0 and world > 1 and args.collective_timeout > 0:
+            watch["stage"] = stage
+            watch["timer"] = threading.Timer(args.collective_timeout, _timed_out)
+            watch["timer"].daemon = True
+            watch["timer"].start()
+
+    def unguard():
+        with watch["lock"]:
+            if watch["timer"] is not None:
+                watch["timer"].cancel()
+                watch["timer"] = None
+        if watch["fired"]:  # the watchdog is printing the line and taking the run down: stay out of its way
+            threading.Event().wait()
+
     # the final exchange, once, timed on its own (barrier + sync on both sides, max over ranks)
     gather_info = None
     if want_gather and not args.gather_every_step:
+        guard("final gatherv")
         try:
+            if os.environ.get("CROPSR_BENCH_TEST_STALL") == "%d:gatherv" % rank:  # tests: this rank never reaches the exchange
+                time.sleep(3600)
             gatherv(n_plus, n_minus)  # warm-up: RCCL sets up its point-to-point channels
             fence()
             tg = time.perf_counter()
@@ -326,12 +444,14 @@ def main():
             gather_info = {"s": tg}  # rank 0 finishes last: it waits for every receive
         except Exception as e:  # the bench line is printed even if the exchange fails on this node
             gather_info = {"error": repr(e)[:300]}
+        unguard()
 
     # ---- the opt-in off-target seed scan of cfg 5 on the same resident genome and hit tables
     ot = None
     if args.offtarget_steps > 0 and rccl_error and world > 1:
         ot = {"skipped": "the site histogram is summed over the ranks by an RCCL all-reduce, and RCCL is unavailable here"}
     elif args.offtarget_steps > 0 and not (gather_info and "error" in gather_info):
+        guard("off-target block (site-histogram all-reduce)")
         try:
             # The scan hands the seed words over (CRP_SCAN_SEEDS: the emit kernel writes them from the windows it
             # holds anyway); what that costs the scan is measured here and reported beside the step.
@@ -405,78 +525,10 @@ def main():
                   "parity": "unpinned: the reference has no off-target step (oracle: oracle/crp_oracle.c all-pairs)"}
         except Exception as e:
             ot = {"error": repr(e)[:300]}
+        unguard()
 
     if rank == 0:
-        info = eng.device_info()
-        build_id = nat.lib().crp_build_id().decode()
-        n_chars = arena.stats()["n_chars"]
-        hits = n_plus + n_minus
-        algo_bytes = (n_chars + 3) // 4 + 2 * ((n_chars + 7) // 8) + 12 * hits  # SURVEY.md 8d, rank 0's launch
-        emit = prof["emit_score"]
-        emit_ms = emit["ms"] / max(1, emit["launches"])
-        achieved = algo_bytes / (emit_ms * 1e-3) / 1e9
-        path_ms = sum(prof[k]["ms"] / max(1, prof[k]["launches"]) for k in ("count", "tile_scan", "emit_score"))
-        facts, facts_src = load_profile_facts(build_id, genomes[0].name)
-        three_launches = bool(args.two_pass or state["two_pass_active"])
-        roof = {"bound": "hbm",
-                "kernel": "emit_kernel (scan+compact+score)" if three_launches else
-                          "emit_kernel, single launch (masks + chained tile offsets + compact + score)",
-                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": facts.get("hbm_bytes_per_launch") if facts else None, "traffic_source": facts_src,
-                "algorithmic_bytes_per_launch": int(algo_bytes),
-                "kernel_ms": emit_ms, "all_kernels_ms": path_ms,
-                "count_kernel_ms": prof["count"]["ms"] / max(1, prof["count"]["launches"]),
-                "tile_scan_ms": prof["tile_scan"]["ms"] / max(1, prof["tile_scan"]["launches"])}
-        if facts and facts.get("valu_insts_per_launch") and facts.get("kernel_cycles_per_launch"):
-            # the second, honest ceiling: the kernel is VALU-issue bound (one wave64 VALU instruction
-            # holds its SIMD for 4 cycles on average here): issue slots used / issue slots there were
-            roof["valu_issue_frac"] = facts["valu_insts_per_launch"] * 4.0 / N_SIMD / facts["kernel_cycles_per_launch"]
-            roof["valu_insts_per_launch"] = facts["valu_insts_per_launch"]
-        line = {
-            "metric": "gRNAs scored/sec", "value": scored_all * args.steps / dt, "unit": "gRNAs/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "untimed_steps_before": n_warm,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": genomes[0].name, "genomes": world, "contigs_per_genome": len(genomes[0].specs),
-                       "bases_total": int(bases_all), "kept_hits_total": int(hits_all),
-                       "guide_len": 20,
-                       "launches_per_step": 3 if three_launches else 1,
-                       # single-launch scans that timed out in a look-back and were repeated as three launches
-                       "chain_timeouts": state["chain_timeouts"],
-                       "parallelism": ("contigs by LPT over %d ranks" % world) +
-                       ("" if not want_gather else (" + %s gatherv to rank 0 " % ("RCCL (in-library)" if use_rccl else "host-socket") +
-                                                    ("every step" if args.gather_every_step else "once, after the steps"))),
-                       "device": info["name"].strip(), "library_build": build_id},
-            "bases_per_s": bases_all * args.steps / dt,
-            "per_rank": per_rank,
-            "roofline": roof,
-            "setup_s": {"generate_pack_upload": t_gen},
-            # host-buffer boundary: characters H2D + pack, one scan, tables D2H (never `value`)
-            "pcie_inclusive": {"upload_pack_s": t_upload, "fetch_tables_s": t_fetch,
-                               # the same fetch into the SAME host arrays (pages already touched): the link's rate
-                               "fetch_tables_into_reused_arrays_s": t_fetch_again,
-                               "gRNAs_per_s": scored / (t_upload + dt / args.steps + t_fetch)},
-        }
-        if rccl_error:
-            line["rccl_error"] = rccl_error
-        if ot is not None:
-            if facts and "roofline" in ot:
-                # counter traffic exists for the ball passes only (streaming reads, where the gfx950 FETCH_SIZE correction
-                # is calibrated); the look-up's gathers and the partition's scatters are not calibrated: whole step = null
-                ot["roofline"]["stage_traffic"] = {"ball_passes": facts.get("offtarget_ball_hbm_bytes_per_step")}
-                ot["roofline"]["traffic_source"] = facts_src
-            line["offtarget"] = ot
-        if gather_info is not None:
-            line["gatherv_ok"] = "s" in gather_info
-            if "s" in gather_info:
-                moved = 12.0 * (hits_all - hits)  # bytes that crossed xGMI to rank 0
-                gather_info.update({"bytes_to_root": int(moved), "GB_per_s_into_root": moved / gather_info["s"] / 1e9})
-                # the WHOLE job of the path at N ranks = one scan on every rank + the one exchange: this, not
-                # `value` (whose timed steps hold no collective and therefore grow ~N-fold by construction),
-                # is the number to build a scaling curve from
-                line["value_with_final_gatherv"] = scored_all / (dt / args.steps + gather_info["s"])
-                line["ms_scan_plus_gatherv"] = (dt / args.steps + gather_info["s"]) * 1e3
-            line["gatherv"] = gather_info
+        line = build_line(gather_info, ot)
         if world == 1 and args.cpu_sample_bases > 0:
             from oracle import oracle as _o
             _o.lib()

@@ -841,6 +841,30 @@ def test_bench_starts_its_own_ranks():
     assert sum(r["kept_hits"] for r in ranks) == d["config"]["kept_hits_total"]
 
 
+def test_bench_prints_its_line_when_the_exchange_never_returns():
+    """A final gatherv that hangs (here: rank 1 never reaches it, test hook CROPSR_BENCH_TEST_STALL) must not cost the
+    run its scan measurement: after --collective-timeout rank 0 prints the ONE line with the timed steps' numbers and
+    `gatherv_ok: false`, takes every rank down and the status is non-zero."""
+    import json
+    import subprocess
+    import sys
+    import time
+    from conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "CROPSR_LAUNCHED")}
+    env["CROPSR_BENCH_TEST_STALL"] = "1:gatherv"
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu0", "--scale", "0.02",
+                        "--steps", "3", "--warmup", "1", "--offtarget-steps", "0", "--collective-timeout", "5"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert p.returncode != 0 and time.time() - t0 < 600
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, (p.stdout[-2000:], p.stderr[-2000:])
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["gatherv_ok"] is False and "did not return" in d["gatherv"]["error"]
+    assert d["value"] > 0 and d["roofline"]["kernel_ms"] > 0 and len(d["per_rank"]) == 2
+    assert "value_with_final_gatherv" not in d
+
+
 def test_cli_starts_its_own_ranks(manifest, tmp_path):
     """`python -m cropsr_amd --gpus 2 ...` without a launcher writes the reference's bytes (both ranks on the one GPU
     here, host transport)."""
