@@ -9,15 +9,22 @@
 
 namespace crp {
 
-constexpr int BLOCK = 256;       // threads per workgroup (4 wavefronts of 64), every kernel of this file
+constexpr int BLOCK = 256;       // threads per workgroup (4 wavefronts of 64) of the streaming kernels (pack, score30, ...)
+// The two kernels that work tile by tile (count, emit) run EIGHT wavefronts per workgroup on a tile of 1 024 words:
+// 52.1 KB of LDS per workgroup = three per CU = six waves per SIMD (the emit kernel is held to 80 VGPRs for that),
+// where 256 threads on 512 words (31.6 KB: the scorer's 9.7 KB of tables do not shrink with the tile) stop at five.
+// Measured -4.4 % on the emit kernel (profiles/EXPERIMENTS.md, round 3).  1 024 words is also the largest tile whose
+// positions fit the 16-bit entries of the hit list.
+constexpr int TILE_BLOCK = 512;
 constexpr int TILE_WPT = 2;      // 64-position words per thread in the emit pass
-constexpr int TILE_WORDS = BLOCK * TILE_WPT;  // one workgroup = one tile of 512 words = 32 768 positions
+constexpr int TILE_WORDS = TILE_BLOCK * TILE_WPT;  // one workgroup = one tile of 1 024 words = 65 536 positions
 constexpr int ARENA_ALIGN_WORDS = 1024;       // arena planes are padded to this many words
-// LDS hit-list entries per round.  2 688: the most that leaves the workgroup (31.6 KB of LDS) at five per CU with
-// some margin (2 944 no longer fits five).  A tile with more kept hits than the list holds takes a second round; on
-// the bench genome (1 520 hits per tile on average, soft-masked runs of ~2 kb) 2 048 entries left about one tile in
-// six in that state (0.468 -> 0.457 ms).
-constexpr int LIST_CAP = 2688;
+static_assert(ARENA_ALIGN_WORDS % TILE_WORDS == 0 && TILE_WORDS * 64 <= 65536, "tile geometry");
+// LDS hit-list entries per round.  5 376 (= 2 x 2 688, the value tuned for the 512-word tile: 2 048 there left about one
+// tile in six of the bench genome -- 1 520 hits per 512 words on average, soft-masked runs of ~2 kb -- with a second
+// round, 0.468 -> 0.457 ms): with it the workgroup takes 53 392 B of LDS, and 512 B more would no longer fit three
+// per CU.  A tile with more kept hits than the list holds takes a second round.
+constexpr int LIST_CAP = 5376;
 #ifndef CRP_NT_STORES
 #define CRP_NT_STORES 1  // hit-table stores with the non-temporal hint: -1.5 % at steady clocks
 #endif

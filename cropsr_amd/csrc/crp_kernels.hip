@@ -16,7 +16,7 @@
 // (i-l >= 5, j+3 >= 5, j+3+l <= len+10, j+2 < len, complete 30-window) becomes a
 // test of a void bit at a fixed distance, and no kernel needs a contig table.
 //
-// Work decomposition: one 256-thread workgroup per tile of 512 words.  PAM
+// Work decomposition: one 512-thread workgroup (eight wavefronts) per tile of 1 024 words.  PAM
 // masks are 64-wide bit-parallel per lane; kept hits are ranked with popcounts and
 // a block scan, compacted to an LDS list, and then scored one hit per lane so the
 // f64 work is balanced and the table stores are coalesced.  Output order is
@@ -73,7 +73,7 @@ __device__ __forceinline__ uint64_t wave_inclusive_scan(uint64_t v)
 }
 
 // Block-wide exclusive scan of a packed (plus | minus << 32) count.
-// `wave_tot` is LDS scratch of BLOCK/64 entries.  Returns the exclusive prefix,
+// `wave_tot` is LDS scratch of TILE_BLOCK/64 entries.  Returns the exclusive prefix,
 // sets `total` to the block total.
 // The per-lane counts are small (<= 128 per strand), so both fit one 32-bit
 // word as 16-bit fields and the wave scan is six DPP adds (row_shr 1,2,4,8 inside
@@ -107,7 +107,7 @@ __device__ __forceinline__ uint64_t block_exclusive_scan(uint64_t v, uint64_t *w
     __syncthreads();
     uint64_t base = 0, tot = 0;
 #pragma unroll
-    for (int w = 0; w < BLOCK / 64; ++w) {
+    for (int w = 0; w < TILE_BLOCK / 64; ++w) {
         const uint64_t t = wave_tot[w];
         if (w < wave) base += t;
         tot += t;
@@ -121,7 +121,7 @@ __device__ __forceinline__ uint64_t block_exclusive_scan(uint64_t v, uint64_t *w
 // covers 128 consecutive words (two per lane, one 16-byte load per plane and lane
 // = 64 bytes in flight per lane); the words a lane does not own come from its
 // neighbours by wave shuffles of the DERIVED G / C / void masks, and only lanes 0
-// and 63 touch memory for the words just outside the wave.  A workgroup of four
+// and 63 touch memory for the words just outside the wave.  A workgroup of eight
 // waves produces the counts of one emit tile.
 __device__ __forceinline__ void derive(uint64_t hi, uint64_t lo, uint64_t up, uint64_t ac, uint64_t &g,
                                        uint64_t &c, uint64_t &v)
@@ -148,13 +148,13 @@ __device__ __forceinline__ void masks_of(uint64_t g_c, uint64_t g_n, uint64_t c_
 // LFIX > 0: guide length known at compile time (20, the reference's default), so
 // every funnel shift has a constant amount and becomes one v_alignbit_b32 per half.
 template <int LFIX>
-__global__ __launch_bounds__(BLOCK) void count_kernel(Planes pl, uint64_t n_words_padded, int l_arg,
+__global__ __launch_bounds__(TILE_BLOCK) void count_kernel(Planes pl, uint64_t n_words_padded, int l_arg,
                                                        uint2 *__restrict__ tile_cnt)
 {
     const int l = LFIX > 0 ? LFIX : l_arg;
-    static_assert(BLOCK == 256 && TILE_WORDS == 512, "count pass geometry: one workgroup = one emit tile, 128 words per wave");
+    static_assert(TILE_WORDS == 2 * TILE_BLOCK, "count pass geometry: one workgroup = one emit tile, 128 words per wave");
     const uint32_t tile = blockIdx.x;
-    __shared__ uint64_t wave_tot[BLOCK / 64];
+    __shared__ uint64_t wave_tot[TILE_BLOCK / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint64_t c = 0;
     const uint64_t w0 = (uint64_t)tile * TILE_WORDS + (uint64_t)wave * 128;  // first word of this wave
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(BLOCK) void count_kernel(Planes pl, uint64_t n_word
     if (threadIdx.x == 0 && (uint64_t)tile * TILE_WORDS < n_words_padded) {
         uint64_t t = 0;
 #pragma unroll
-        for (int w = 0; w < BLOCK / 64; ++w) t += wave_tot[w];
+        for (int w = 0; w < TILE_BLOCK / 64; ++w) t += wave_tot[w];
         tile_cnt[tile] = make_uint2((uint32_t)t, (uint32_t)(t >> 32));
     }
 }
@@ -582,7 +582,7 @@ __device__ __forceinline__ void emit_rounds(uint64_t (*sh)[TILE_WORDS + 2], uint
 // CHAINED = false: third pass of the count / scan / emit sequence (offsets from tile_off).
 // PRE: the pre-sigmoid column is written too.  SEEDS: so is the off-target scan's raw seed word.
 template <bool CHAINED, int LFIX, bool PRE, bool SEEDS>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8))) void emit_kernel(
+__global__ __launch_bounds__(TILE_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8))) void emit_kernel(
     Planes pl, uint64_t n_words_padded, int l_arg, const uint2 *__restrict__ tile_off, uint64_t *chain,
     uint64_t *__restrict__ chain_next, HitTables out, uint32_t mute_tile, uint32_t timeout_ticks)
 {
@@ -593,7 +593,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8))) v
     __shared__ uint64_t tabs[256 + CRP_SCORE_TAB_N];
     uint64_t *const exp_tab = tabs;
     double *const score_tab = reinterpret_cast<double *>(tabs + 256);
-    __shared__ uint64_t wave_tot[BLOCK / 64];
+    __shared__ uint64_t wave_tot[TILE_BLOCK / 64];
     __shared__ uint64_t s_excl;
     __shared__ uint32_t s_flag;
     __shared__ uint16_t list[LIST_CAP];
@@ -687,9 +687,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8))) v
     // follows the hit-list build; staging them only now keeps them out of the way of the counts that later tiles wait
     // for (-3.5 %).  (Staging by LDS-DMA, or requesting the words earlier and writing them here, both measured
     // slower: profiles/EXPERIMENTS.md.)
-    for (int k = tid; k < 256; k += BLOCK) exp_tab[k] = CRP_TABS.exp_tab[k];
+    for (int k = tid; k < 256; k += TILE_BLOCK) exp_tab[k] = CRP_TABS.exp_tab[k];
     if (LFIX == 20)
-        for (int k = tid; k < CRP_SCORE_TAB_N; k += BLOCK) score_tab[k] = CRP_TABS.score_tab[k];
+        for (int k = tid; k < CRP_SCORE_TAB_N; k += TILE_BLOCK) score_tab[k] = CRP_TABS.score_tab[k];
     emit_rounds<LFIX == 20, CHAINED, PRE, SEEDS>(sh, list, exp_tab, score_tab, mp, mm, ex, n_plus, n_minus, l, (uint32_t)(t0 * 64),
                                                  off_plus, off_minus, out, ch);
 }
@@ -840,17 +840,17 @@ __device__ __forceinline__ void emit_rounds(uint64_t (*sh)[TILE_WORDS + 2], uint
             before_first_store(any);
             if (any) {
                 store(first);
-                for (k += BLOCK; k < n_round; k += BLOCK) store(score(fetch(k)));
+                for (k += TILE_BLOCK; k < n_round; k += TILE_BLOCK) store(score(fetch(k)));
             }
         };
         if (!CHAINED) {
             run_rows(tid, [](bool) {});
         } else {
             // Single pass.  The workgroup's slot (LDS, wave slots) is held until its LAST wave is done, and wave 0
-            // also resolves the tile's prefix.  So wave 0 takes the chunks of 64 rows nobody would miss: waves 1, 2,
-            // 3 own chunks 0, 1, 2 (mod 4) and wave 0 chunk 3 -- when the row count is not a multiple of 256 it is
+            // also resolves the tile's prefix.  So wave 0 takes the chunks of 64 rows nobody would miss: waves 1 ... 7
+            // own chunks 0 ... 6 (mod 8) and wave 0 chunk 7 -- when the row count is not a multiple of 512 it is
             // wave 0 that has one chunk less, not one more.
-            const uint32_t k0 = (uint32_t)(tid & 63) | ((((uint32_t)tid >> 6) + (BLOCK / 64 - 1)) % (BLOCK / 64)) << 6;
+            const uint32_t k0 = (uint32_t)(tid & 63) | ((((uint32_t)tid >> 6) + (TILE_BLOCK / 64 - 1)) % (TILE_BLOCK / 64)) << 6;
             // the whole look-back BEFORE wave 0 scores anything (nothing of the scorer is live then)
             if (lo_rank == 0 && tid < 64) chain_resolve(ch);
             // The other waves score their first rows meanwhile and need the offsets only to STORE them: by then
@@ -1046,9 +1046,9 @@ hipError_t launch_count(hipStream_t s, const Planes &pl, uint64_t n_words_padded
 {
     if (n_tiles == 0) return hipSuccess;
     if (l == 20)
-        hipLaunchKernelGGL(count_kernel<20>, dim3(n_tiles), dim3(BLOCK), 0, s, pl, n_words_padded, l, tile_cnt);
+        hipLaunchKernelGGL(count_kernel<20>, dim3(n_tiles), dim3(TILE_BLOCK), 0, s, pl, n_words_padded, l, tile_cnt);
     else
-        hipLaunchKernelGGL(count_kernel<0>, dim3(n_tiles), dim3(BLOCK), 0, s, pl, n_words_padded, l, tile_cnt);
+        hipLaunchKernelGGL(count_kernel<0>, dim3(n_tiles), dim3(TILE_BLOCK), 0, s, pl, n_words_padded, l, tile_cnt);
     return hipGetLastError();
 }
 
@@ -1073,7 +1073,7 @@ static hipError_t launch_emit_variant(hipStream_t s, const Planes &pl, uint64_t 
     const bool pre = out.pre_plus != nullptr, seeds = out.seed_plus != nullptr;
     if (seeds && l != 20) return hipErrorInvalidValue;
 #define CRP_LAUNCH(LFIX, PRE, SEEDS)                                                                                      \
-    hipLaunchKernelGGL((emit_kernel<CHAINED, LFIX, PRE, SEEDS>), dim3(n_tiles), dim3(BLOCK), 0, s, pl, n_words_padded, l, \
+    hipLaunchKernelGGL((emit_kernel<CHAINED, LFIX, PRE, SEEDS>), dim3(n_tiles), dim3(TILE_BLOCK), 0, s, pl, n_words_padded, l, \
                        tile_off, chain, chain_next, out, mute_tile, timeout_ticks)
     if (l == 20) {
         if (seeds) {
