@@ -11,8 +11,8 @@ namespace crp {
 
 constexpr int BLOCK = 256;       // threads per workgroup (4 wavefronts of 64) of the streaming kernels (pack, score30, ...)
 // The two kernels that work tile by tile (count, emit) run EIGHT wavefronts per workgroup on a tile of 1 024 words:
-// 52.1 KB of LDS per workgroup = three per CU = six waves per SIMD (the emit kernel is held to 80 VGPRs for that),
-// where 256 threads on 512 words (31.6 KB: the scorer's 9.7 KB of tables do not shrink with the tile) stop at five.
+// 52.5 KB of LDS per workgroup = three per CU = six waves per SIMD (the emit kernel is held to 80 VGPRs for that),
+// where 256 threads on 512 words (31.6 KB: the scorer's tables do not shrink with the tile) stop at five.
 // Measured -4.4 % on the emit kernel (profiles/EXPERIMENTS.md, round 3).  1 024 words is also the largest tile whose
 // positions fit the 16-bit entries of the hit list.
 constexpr int TILE_BLOCK = 512;
@@ -20,11 +20,14 @@ constexpr int TILE_WPT = 2;      // 64-position words per thread in the emit pas
 constexpr int TILE_WORDS = TILE_BLOCK * TILE_WPT;  // one workgroup = one tile of 1 024 words = 65 536 positions
 constexpr int ARENA_ALIGN_WORDS = 1024;       // arena planes are padded to this many words
 static_assert(ARENA_ALIGN_WORDS % TILE_WORDS == 0 && TILE_WORDS * 64 <= 65536, "tile geometry");
-// LDS hit-list entries per round.  5 376 (= 2 x 2 688, the value tuned for the 512-word tile: 2 048 there left about one
-// tile in six of the bench genome -- 1 520 hits per 512 words on average, soft-masked runs of ~2 kb -- with a second
-// round, 0.468 -> 0.457 ms): with it the workgroup takes 53 392 B of LDS, and 512 B more would no longer fit three
-// per CU.  A tile with more kept hits than the list holds takes a second round.
-constexpr int LIST_CAP = 5376;
+// LDS hit-list entries per round.  The workgroup's LDS (planes 32.8 KB, scorer tables 10.8 KB, this list) must stay within
+// 53 760 B = 42 allocation units of 1 280 B: one unit more and only two workgroups fit a CU (measured: 0.42 -> 0.52 ms).
+// What the planes leave is split between the scorer's chain tables and the list: 5 016 entries with the tables of
+// gen_score_terms.py (4 504 entries and one more table bit measured the same; 5 376 with one table bit less +1.5 %).
+// The bench genome has ~3 040 kept hits per tile on average (soft-masked runs of ~2 kb); a tile with more kept hits
+// than the list holds takes a second round (one per strand when each strand fits).
+constexpr int LIST_CAP = 5016;
+constexpr int TILE_LDS_LIMIT = 53760;  // checked in emit_kernel
 #ifndef CRP_NT_STORES
 #define CRP_NT_STORES 1  // hit-table stores with the non-temporal hint: -1.5 % at steady clocks
 #endif

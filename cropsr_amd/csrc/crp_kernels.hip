@@ -597,6 +597,8 @@ __global__ __launch_bounds__(TILE_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8
     __shared__ uint64_t s_excl;
     __shared__ uint32_t s_flag;
     __shared__ uint16_t list[LIST_CAP];
+    static_assert(sizeof(sh) + sizeof(tabs) + sizeof(wave_tot) + sizeof(s_excl) + 8 + sizeof(list) <= TILE_LDS_LIMIT,
+                  "three workgroups per CU: see LIST_CAP");
 
     const int tid = threadIdx.x;
     const uint32_t tile = blockIdx.x;  // dispatch order = index order: every tile this one waits for has started

@@ -83,7 +83,9 @@ def scaled(w, bit):
 # bits are gathered into a table index with one multiplication: for the right constant the top k
 # bits of (bits * MAGIC) are different for every one of the 2^k patterns (any one-to-one mapping
 # will do, the table is laid out to match).  Terms past the first k of a chain stay gated FMAs.
-TABLE_BITS = {"fA": 8, "fT": 8, "fG": 7, "fC": 7, "sG": 7, "sC": 7, "sA": 6, "sT": 0}  # sT: 4 terms, 25 positions apart
+# (sT: its three live terms as an 8-entry table; sG: 8 of its 14 terms.  Measured with the 1 024-word tile, where the LDS
+# left over by three workgroups per CU is split between these tables and the hit list: profiles/EXPERIMENTS.md, round 3)
+TABLE_BITS = {"fA": 8, "fT": 8, "fG": 7, "fC": 7, "sG": 8, "sC": 7, "sA": 6, "sT": 3}
 # experiments: CRP_TABLE_BITS="fA=7,fT=7" trades table size (LDS) against gated FMAs
 for _kv in os.environ.get("CRP_TABLE_BITS", "").split(","):
     if "=" in _kv:

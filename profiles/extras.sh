@@ -1,0 +1,36 @@
+#!/bin/bash
+# The files of profiles/rNN/ that profiles/collect.sh does not write, for the SAME library build:
+#   bash profiles/extras.sh r03 [soak]     (GPU box, repo root; `soak` adds the 1 200-trial fuzz, ~6 minutes)
+# Everything lands under gpurun_out/profiles_<tag>/; copy it into profiles/<tag>/ beside collect.sh's files.
+set -e
+TAG=${1:-r03}
+cd "${GRAFT_REPO_ROOT:-.}"
+export TMPDIR=/tmp
+RAW=gpurun_out/prof_$TAG
+OUT=gpurun_out/profiles_$TAG
+mkdir -p "$RAW" "$OUT"
+
+# the bench with no flags (CPU baseline legs included) and with the driver's flags, plain and under the kernel trace
+python3 bench.py > $OUT/bench_default_run.json 2> $RAW/default.err
+python3 bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver_flags_run.json 2> $RAW/driver.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/driver_trace -- python3 bench.py --gpus 1 --steps 20 --warmup 5 \
+    > $OUT/bench_driver_flags_under_trace.json 2> $RAW/driver_trace.err
+cp $RAW/driver_trace/*/*_kernel_stats.csv $OUT/kernel_stats_driver_flags.csv
+# the smaller configs of BASELINE.json (parity cases, not the headline)
+python3 bench.py --workload tair10 --cpu-sample-bases 0 > $OUT/bench_tair10_like.json 2> $RAW/tair10.err
+python3 bench.py --workload ecoli --cpu-sample-bases 0 > $OUT/bench_ecoli_like.json 2> $RAW/ecoli.err
+# N = 2 started by the program itself, both ranks on this one GPU (host transport for fences and the final gatherv)
+python3 bench.py --gpus 2 --share-gpu0 --scale 0.25 --steps 10 --warmup 3 --cpu-sample-bases 0 \
+    > $OUT/bench_2ranks_self_launched_one_gpu.json 2> $RAW/2ranks.err
+# the whole CLI end to end (FASTA in, CSV out)
+python3 tools/e2e_cli.py switchgrass > $OUT/e2e_cli_switchgrass_first_process_on_the_box.json 2> $RAW/e2e0.err
+python3 tools/e2e_cli.py switchgrass > $OUT/e2e_cli_switchgrass.json 2> $RAW/e2e1.err
+python3 tools/e2e_cli.py switchgrass --cli-flag=--offtarget > $OUT/e2e_cli_switchgrass_offtarget.json 2> $RAW/e2e2.err
+python3 tools/e2e_cli.py switchgrass --cli-flag=--score-finalize --cli-flag=host > $OUT/e2e_cli_switchgrass_finalize_host.json 2> $RAW/e2e3.err
+python3 tools/e2e_cli.py tair10 --reference-behaviour > $OUT/e2e_cli_tair10_reference_behaviour.json 2> $RAW/e2e4.err
+{ for p in 1 4; do python3 tools/e2e_cli.py tair10 --procs $p --md5 --cli-flag=--offtarget; done; } > $OUT/multi_process_cli_md5.txt 2> $RAW/md5.err
+if [ "$2" = soak ]; then
+  CROPSR_FUZZ_TRIALS=1200 python3 -m pytest -q tests/test_gpu_parity.py::test_randomised_arenas_vs_oracle \
+      tests/test_offtarget.py::test_gpu_randomised_genomes_vs_oracle > $OUT/fuzz_soak_1200_trials.log 2>&1
+fi
+ls -la $OUT
