@@ -199,7 +199,8 @@ def main():
             # collective, so the measurement goes on with the control sockets as fence and host transport for the
             # final exchange; the line says so (`rccl_error`, `parallelism`) and stderr says it loudly.
             rccl_error = str(e)[:500]
-            nat.lib().crp_comm_destroy(eng._ctx)
+            if not eng.comm_stuck:  # (a bootstrap that never returned still holds the context on its helper thread)
+                nat.lib().crp_comm_destroy(eng._ctx)
             use_rccl = False
             sys.stderr.write("[bench rank %d] RCCL communicator unavailable, falling back to the host transport "
                              "for fences and the final gatherv: %s\n" % (rank, rccl_error))
@@ -546,6 +547,8 @@ def main():
     eng.close()
     if group:
         group.close()
+    from cropsr_amd import engine as _engine
+    _engine.leave_if_comm_stuck(0)  # (a communicator bootstrap that never returned left a thread inside RCCL)
 
 
 if __name__ == "__main__":

@@ -205,7 +205,16 @@ class EngineBackend:
     def connect(self):
         """Collective over the group: create the RCCL communicator (transport "rccl")."""
         if self.group is not None and self.transport == "rccl":
-            self.engine.comm_init(self.group)
+            from .rendezvous import RankError
+            try:
+                self.engine.comm_init(self.group)
+            except RankError as e:
+                # every rank has this error (comm_init agrees on it): the job of the run is the CSV, and the tables can
+                # travel over the control sockets instead
+                import sys
+                if self.group.rank == 0:
+                    sys.stderr.write("cropsr_amd: no RCCL communicator (%s); the final exchange uses the host transport\n" % e)
+                self.transport = "host"
 
     def _finalize(self, hits):
         """--score-finalize=host: CROPSR.py:313 on this host's numpy, from the GPU's pre-sigmoid sum."""
@@ -502,6 +511,9 @@ def main(argv=None):
                                     args.gpus))
     try:
         run(args)
+        eng_mod = sys.modules.get(__package__ + ".engine")  # (only a run that opened the GPU has imported it)
+        if eng_mod is not None:
+            eng_mod.leave_if_comm_stuck(0)
     except Exception as e:
         from . import rendezvous
         if isinstance(e, rendezvous.RankError):  # agreed on by every rank: all leave the same way, together

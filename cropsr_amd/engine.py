@@ -196,6 +196,19 @@ class Arena:
 # before module globals are torn down and before the HIP runtime's own static destructors, so no
 # __del__ ever calls into a runtime that is already gone.
 _LIVE_ENGINES = weakref.WeakSet()
+_COMM_STUCK = False  # some Engine.comm_init of this process left a helper thread behind inside RCCL
+
+
+def leave_if_comm_stuck(status=0):
+    """Call when the program's output is written: if a communicator bootstrap never returned (Engine.comm_init), a
+    thread of this process still sits inside RCCL, and the runtime's tear-down at a normal exit may wait for it --
+    leave through os._exit instead."""
+    if _COMM_STUCK:
+        import os
+        import sys
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(status)
 
 
 @atexit.register
@@ -212,6 +225,7 @@ class Engine:
 
     def __init__(self, device=0):
         self._ctx = None
+        self.comm_stuck = False  # comm_init: a helper thread never came back from RCCL's bootstrap
         L = nat.lib()
         h = ctypes.c_void_p()
         st = L.crp_init(int(device), ctypes.byref(h))
@@ -225,7 +239,8 @@ class Engine:
         if self._ctx:
             for a in list(self._arenas):  # arenas hold device memory of this context
                 a.close()
-            nat.lib().crp_destroy(self._ctx)
+            if not self.comm_stuck:  # (a helper thread may still be inside RCCL with this context: comm_init)
+                nat.lib().crp_destroy(self._ctx)
             self._ctx = None
 
     __del__ = close
@@ -340,10 +355,23 @@ class Engine:
         return out
 
     # ---- multi-GPU: RCCL inside the library (crp_comm.cpp); `group` is a rendezvous.Group
-    def comm_init(self, group):
+    def comm_init(self, group, timeout_s=None):
         """Create the RCCL communicator of this engine: rank 0 draws the unique id, the group's
-        control sockets carry it to the others.  Errors are agreed on before anyone proceeds."""
+        control sockets carry it to the others.  Errors are agreed on before anyone proceeds.
+
+        ncclCommInitRank has no time-out of its own; a bootstrap that never completes on some node must not
+        take the run with it (the scan needs no collective, the exchange has a host transport).  The call is
+        therefore made on a helper thread and given `timeout_s` seconds (CROPSR_COMM_INIT_TIMEOUT_S, default
+        180): a rank whose call has not returned by then reports that as its error, group.check makes it
+        every rank's error, and the callers fall back to the host transport.  The helper thread stays behind
+        inside RCCL: `comm_stuck` is then set, close() leaves the context alone, and the program should leave
+        through os._exit once its output is written (bench.py and the CLI do)."""
+        import os
+        import threading
+        global _COMM_STUCK
         L = nat.lib()
+        if timeout_s is None:
+            timeout_s = float(os.environ.get("CROPSR_COMM_INIT_TIMEOUT_S", "180"))
         ident, err = None, None
         if group.rank == 0:
             buf = (ctypes.c_uint8 * nat.COMM_ID_BYTES)()
@@ -357,11 +385,30 @@ class Engine:
         group.check(err)
         ident = group.bcast(ident)
         buf = (ctypes.c_uint8 * nat.COMM_ID_BYTES).from_buffer_copy(ident)
-        st = L.crp_comm_init(self._ctx, buf, group.rank, group.world)
+        done = {}
+
+        def init():
+            if os.environ.get("CROPSR_TEST_COMM_INIT_STALL") == str(group.rank):  # tests: this rank's bootstrap hangs
+                threading.Event().wait()
+            done["st"] = L.crp_comm_init(self._ctx, buf, group.rank, group.world)
+
+        worker = threading.Thread(target=init, name="crp_comm_init", daemon=True)
+        worker.start()
+        worker.join(timeout_s if timeout_s > 0 else None)
         err = None
-        if st != nat.CRP_OK:
-            err = "crp_comm_init: %s [%s]" % (L.crp_strerror(st).decode(), L.crp_last_error(self._ctx).decode())
-        group.check(err)
+        if worker.is_alive():
+            self.comm_stuck = _COMM_STUCK = True
+            err = "crp_comm_init did not return within %.0f s (RCCL bootstrap)" % timeout_s
+        elif done["st"] != nat.CRP_OK:
+            err = "crp_comm_init: %s [%s]" % (L.crp_strerror(done["st"]).decode(), L.crp_last_error(self._ctx).decode())
+        try:
+            group.check(err)
+        except Exception:
+            # a peer's bootstrap hung: this rank's communicator (if it got one) has no usable peers, and destroying it
+            # may wait for them -- treat the context like a stuck one
+            if err is None:
+                self.comm_stuck = _COMM_STUCK = True
+            raise
 
     def comm_barrier(self):
         nat.check(nat.lib().crp_comm_barrier(self._ctx), "crp_comm_barrier", self._ctx)

@@ -301,19 +301,25 @@ class Group:
 
     # ------------------------------------------------------------- collectives
     def all_gather(self, obj):
-        """[obj of rank 0, obj of rank 1, ...] on every rank."""
+        """[obj of rank 0, obj of rank 1, ...] on every rank.  A peer that is gone ends this rank the way the abort
+        channel would (status 3, "another rank died"): an exception out of here would race the watcher thread for the
+        exit status, and the launcher takes the status of the rank at fault, not of the ranks that noticed."""
         if self.world == 1:
             return [obj]
-        if self.rank == 0:
-            objs = [obj] + [None] * (self.world - 1)
-            for r, s in self._peers.items():
-                objs[r] = _loads(_recv_msg(s))
-            blob = pickle.dumps(objs)
-            for s in self._peers.values():
-                _send_msg(s, blob)
-            return objs
-        _send_msg(self._hub, pickle.dumps(obj))
-        return _loads(_recv_msg(self._hub))
+        r = 0
+        try:
+            if self.rank == 0:
+                objs = [obj] + [None] * (self.world - 1)
+                for r, s in self._peers.items():
+                    objs[r] = _loads(_recv_msg(s))
+                blob = pickle.dumps(objs)
+                for r, s in self._peers.items():
+                    _send_msg(s, blob)
+                return objs
+            _send_msg(self._hub, pickle.dumps(obj))
+            return _loads(_recv_msg(self._hub))
+        except OSError as e:
+            self._die("lost the control connection to rank %d in a collective (%s)" % (r, e))
 
     def bcast(self, obj, src=0):
         return self.all_gather(obj if self.rank == src else None)[src]
@@ -342,12 +348,18 @@ class Group:
         if dst != 0 or self.rank == 0:
             raise ValueError("arrays travel to rank 0 only")
         a = np.ascontiguousarray(arr)
-        _send_msg(self._hub, pickle.dumps((a.dtype.str, a.shape)))
-        _send_msg(self._hub, memoryview(a).cast("B") if a.size else b"")
+        try:
+            _send_msg(self._hub, pickle.dumps((a.dtype.str, a.shape)))
+            _send_msg(self._hub, memoryview(a).cast("B") if a.size else b"")
+        except OSError as e:
+            self._die("lost the control connection to rank 0 while sending a table (%s)" % e)
 
     def recv_array(self, src):
         """rank 0: the array rank `src` sent."""
         s = self._peers[src]
-        dtype, shape = _loads(_recv_msg(s))
-        raw = _recv_msg(s)
+        try:
+            dtype, shape = _loads(_recv_msg(s))
+            raw = _recv_msg(s)
+        except OSError as e:
+            self._die("lost the control connection to rank %d while receiving a table (%s)" % (src, e))
         return np.frombuffer(raw, dtype=np.dtype(dtype)).reshape(shape)

@@ -871,6 +871,28 @@ def test_bench_prints_its_line_when_the_exchange_never_returns():
     assert "value_with_final_gatherv" not in d
 
 
+def test_bench_goes_on_when_the_rccl_bootstrap_never_returns():
+    """ncclCommInitRank has no time-out: a bootstrap that hangs (here: rank 1 never calls it, test hook
+    CROPSR_TEST_COMM_INIT_STALL, so rank 0 waits for a peer that does not come) must not take the measurement with it.
+    After CROPSR_COMM_INIT_TIMEOUT_S every rank agrees on the error, the bench goes on over the host transport, says so in
+    the line (`rccl_error`) and leaves with status 0 through os._exit (a thread is still inside RCCL)."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "CROPSR_LAUNCHED")}
+    env.update(CROPSR_BENCH_FORCE_RCCL="1", CROPSR_TEST_COMM_INIT_STALL="1", CROPSR_COMM_INIT_TIMEOUT_S="5")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu0", "--scale", "0.02",
+                        "--steps", "3", "--warmup", "1", "--offtarget-steps", "0"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, (p.stdout[-2000:], p.stderr[-2000:])
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and "did not return" in d["rccl_error"] and d["gatherv_ok"] is True and d["value"] > 0
+    assert "host-socket" in d["config"]["parallelism"]
+
+
 def test_cli_starts_its_own_ranks(manifest, tmp_path):
     """`python -m cropsr_amd --gpus 2 ...` without a launcher writes the reference's bytes (both ranks on the one GPU
     here, host transport)."""
