@@ -171,8 +171,6 @@ def main():
         sys.stdout.flush()
         sys.exit(launch.spawn_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus,
                                     timeout_s=args.launch_timeout))
-    import numpy as np
-
     from cropsr_amd import Engine, parallel, rendezvous
     from cropsr_amd import _native as nat
 

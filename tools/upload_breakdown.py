@@ -1,6 +1,5 @@
 import sys, time
 sys.path.insert(0, '.')
-import numpy as np
 import bench_workload as bw
 from cropsr_amd import Engine
 eng = Engine(0)
