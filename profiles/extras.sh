@@ -30,7 +30,7 @@ python3 tools/e2e_cli.py switchgrass --cli-flag=--score-finalize --cli-flag=host
 python3 tools/e2e_cli.py tair10 --reference-behaviour > $OUT/e2e_cli_tair10_reference_behaviour.json 2> $RAW/e2e4.err
 { for p in 1 4; do python3 tools/e2e_cli.py tair10 --procs $p --md5 --cli-flag=--offtarget; done; } > $OUT/multi_process_cli_md5.txt 2> $RAW/md5.err
 if [ "$2" = soak ]; then
-  CROPSR_FUZZ_TRIALS=1200 python3 -m pytest -q tests/test_gpu_parity.py::test_randomised_arenas_vs_oracle \
+  CROPSR_FUZZ_TRIALS=1200 CROPSR_FUZZ_PROGRESS=$RAW/fuzz_progress.txt python3 -m pytest -q tests/test_gpu_parity.py::test_randomised_arenas_vs_oracle \
       tests/test_offtarget.py::test_gpu_randomised_genomes_vs_oracle > $OUT/fuzz_soak_1200_trials.log 2>&1
 fi
 ls -la $OUT

@@ -187,3 +187,18 @@ def run_cli(tmp_path, monkeypatch, fasta_path, backend, seed, extra=()):
     cli.run(args, backend=backend, out=buf)
     with open(out_csv, "rb") as f:
         return f.read(), buf.getvalue()
+
+
+def fuzz_settings(default_trials, base_seed):
+    """(trials, seed, tick) of a seeded fuzz test.  CROPSR_FUZZ_TRIALS: more trials for a soak on the GPU box;
+    CROPSR_FUZZ_SEED: an offset to the test's seed (a second soak covers new ground); CROPSR_FUZZ_PROGRESS: a file
+    that gets a line every 100 trials (a long soak must keep writing, or the GPU pool takes it for hung)."""
+    trials = int(os.environ.get("CROPSR_FUZZ_TRIALS", str(default_trials)))
+    seed = base_seed + int(os.environ.get("CROPSR_FUZZ_SEED", "0"))
+    path = os.environ.get("CROPSR_FUZZ_PROGRESS")
+
+    def tick(name, trial):
+        if path and trial % 100 == 99:
+            with open(path, "a") as f:
+                f.write("%s: %d trials\n" % (name, trial + 1))
+    return trials, seed, tick

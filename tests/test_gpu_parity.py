@@ -955,13 +955,16 @@ def test_gather_failure_is_agreed_on_before_the_exchange(tmp_path, mode, want):
 def test_randomised_arenas_vs_oracle(engine, oracle):
     """Seeded fuzz: arenas with random contig counts, lengths clustered around word (64) and
     tile (16384) boundaries, random alphabets / decoration / guide lengths / packers."""
-    rng = np.random.default_rng(20261003)
+    from conftest import fuzz_settings
+    trials, seed, tick = fuzz_settings(60, 20261003)
+    rng = np.random.default_rng(seed)
     alphabets = [b"ACGT", b"ACGTacgtN", b"GGCC", b"ACGTUZuzN')],", b"GGGGGGCCCCCCAT"]
     # contig lengths around word (64), wave (128 words), half-tile and tile (1 024 words = 65 536 positions) borders
     anchors = [0, 1, 30, 63, 64, 65, 8191, 8192, 8193, 16383, 16384, 16385, 2 * 16384 - 1, 2 * 16384, 2 * 16384 + 1, 3 * 16384 + 7,
                4 * 16384 - 1, 4 * 16384, 4 * 16384 + 65, 8 * 16384 - 1, 8 * 16384, 8 * 16384 + 1]
     total_hits = 0
-    for trial in range(int(os.environ.get("CROPSR_FUZZ_TRIALS", "60"))):  # (more for a long soak on the GPU box)
+    for trial in range(trials):
+        tick("arenas", trial)
         contigs = []
         for _ in range(int(rng.integers(1, 9))):
             n = max(0, int(anchors[rng.integers(len(anchors))] + rng.integers(-40, 41)))
@@ -973,6 +976,29 @@ def test_randomised_arenas_vs_oracle(engine, oracle):
         l = 20 if rng.random() < 0.7 else int(rng.integers(1, 51))
         total_hits += check_contigs(engine, oracle, contigs, l, "device" if trial % 2 else "host")
     assert total_hits > 50000
+
+
+def test_results_do_not_depend_on_where_a_contig_lies_in_the_arena(engine, oracle):
+    """Shift invariance: one 300 kb contig (soft-masked stretches, N runs, PAM-rich stretches) behind filler contigs of
+    0 ... 140 words, so that its words fall on every kind of lane / wave (128 words) / tile (1 024 words) border in turn.
+    Its tables must be bit-identical wherever it lies, and equal to the oracle's."""
+    rng = np.random.default_rng(77)
+    a = np.frombuffer(b"ACGT", dtype=np.uint8)
+    body = rng.choice(a, 300_000)
+    body[40_000:48_000] |= 0x20           # a soft-masked run
+    body[90_000:90_700] = ord("N")
+    body[131_000:131_400] = ord("G")       # every position a '+' hit
+    body[131_400:131_800] = ord("C")
+    body[65_536 - 40:65_536 + 40] = np.frombuffer(b"GGCC" * 20, dtype=np.uint8)  # hits across a tile border (at shift 0)
+    main = b"'" + body.tobytes() + b"'),"
+    want = oracle.scan_score(main, 20)
+    shifts = [0, 1, 63, 64, 65, 127, 128, 129, 1023, 1024, 1025, 64 * 127 - 3, 64 * 128, 64 * 140 + 17, 65_536 - 7, 65_536 + 64]
+    for sh in shifts:
+        filler = rng.choice(a, sh).tobytes()
+        arena = engine.arena([filler, main] if sh else [main])
+        got = arena.scan_score(20, want_pre=True).contig(1 if sh else 0)
+        assert_hits_equal(got, want, ctx=("shift", sh))
+        arena.close()
 
 
 def test_chain_timeout_falls_back_to_three_launches(oracle, monkeypatch):

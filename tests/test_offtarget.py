@@ -267,10 +267,13 @@ def test_gpu_counts_vs_all_pairs_on_a_megabase(engine, oracle):
 def test_gpu_randomised_genomes_vs_oracle(engine, oracle):
     """Seeded fuzz: random contig counts and lengths (around word and tile borders), alphabets, guide lengths and
     arena splits; seeds, histogram and all four counts against the oracle's enumeration method."""
-    rng = np.random.default_rng(424242)
+    from conftest import fuzz_settings
+    trials, seed, tick = fuzz_settings(25, 424242)
+    rng = np.random.default_rng(seed)
     alphabets = [b"ACGT", b"ACGTacgtN", b"GGCC", b"ACGTUZuzN')],", b"GGGGGGCCCCCCAT", b"ACGTACGTACGTN"]
     anchors = [0, 1, 30, 63, 64, 65, 16383, 16384, 16385, 2 * 16384 + 1, 40000]
-    for trial in range(int(os.environ.get("CROPSR_FUZZ_TRIALS", "25"))):
+    for trial in range(trials):
+        tick("off-target genomes", trial)
         contigs = []
         for _ in range(int(rng.integers(1, 7))):
             n = max(0, int(anchors[rng.integers(len(anchors))] + rng.integers(-40, 41)))
