@@ -306,6 +306,29 @@ def refilter_hits(hits, n, l):
     return out
 
 
+class _Early:
+    """fn() on a helper thread; get() joins and returns its result or raises what it raised."""
+
+    def __init__(self, fn):
+        import threading
+        self._out = []
+        self._thread = threading.Thread(target=self._run, args=(fn,), name="cropsr-open-gpu")
+        self._thread.start()
+
+    def _run(self, fn):
+        try:
+            self._out.append((fn(), None))
+        except BaseException as e:  # handed to the caller of get()
+            self._out.append((None, e))
+
+    def get(self):
+        self._thread.join()
+        value, error = self._out[0]
+        if error is not None:
+            raise error
+        return value
+
+
 def run(args, backend=None, out=sys.stdout, group=None):
     """main() of the reference (CROPSR.py:333-486) with the hot path swapped out.
 
@@ -336,6 +359,10 @@ def run(args, backend=None, out=sys.stdout, group=None):
             device = group.local_rank if group is not None else 0
         return EngineBackend(device, group, finalize)
 
+    # Opening the GPU (HIP start-up, code object, two pinned staging buffers: ~0.3 s) starts NOW on a helper thread and
+    # is collected where the backend is first needed: it overlaps reading and parsing the FASTA.
+    early = _Early(make_backend) if backend is None else None
+
     if group is not None and group.rank != 0:
         # Ranks other than 0 of a multi-GPU run: read the same FASTA, scan their share of the contigs,
         # hand the tables to rank 0 -- which alone prints, draws ids and writes files -- and leave.
@@ -346,7 +373,7 @@ def run(args, backend=None, out=sys.stdout, group=None):
         try:
             strings = [v for _, v in fasta.table_from_bytes(fasta.read_text_bytes(args.f))]
             if own_backend:
-                backend = make_backend()
+                backend = early.get()
         except Exception as e:
             err = "%s: %s" % (type(e).__name__, e)
         try:
@@ -384,10 +411,10 @@ def run(args, backend=None, out=sys.stdout, group=None):
     data = fasta.read_text_bytes(args.f)
     if verbose:
         print(f"Genome file {args.f} successfully imported", file=out)
-        if 2 * data.count(b">") != data.count(b"\n") + 1:
+        if 2 * fasta.count_byte(data, b">") != fasta.count_byte(data, b"\n") + 1:
             print("formatting genome", file=out)
             print(f"Genome file {args.f} successfully formatted", file=out)
-    formatted = 2 * data.count(b">") != data.count(b"\n") + 1 if getattr(args, "annotate", False) else None
+    formatted = (2 * fasta.count_byte(data, b">") != fasta.count_byte(data, b"\n") + 1) if getattr(args, "annotate", False) else None
     table = fasta.table_from_bytes(data)  # == fasta.contig_table(text).items(), without printing the genome
     del data
     stages["read_fasta_s"] = time.perf_counter() - t_stage
@@ -411,14 +438,14 @@ def run(args, backend=None, out=sys.stdout, group=None):
     t_stage = time.perf_counter()
     if group is None:
         if own_backend:
-            backend = make_backend()
+            backend = early.get()
         all_hits = backend.scan(strings, l_dev, offtarget=offtarget) if offtarget else backend.scan(strings, l_dev)
     else:  # contigs (cut where longer than a rank's share) over all GPUs, tables gathered here
         from . import parallel
         err = None
         try:
             if own_backend:
-                backend = make_backend()
+                backend = early.get()
         except Exception as e:
             err = "%s: %s" % (type(e).__name__, e)
         group.check(err)

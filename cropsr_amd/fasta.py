@@ -159,14 +159,61 @@ def table_from_bytes(data, n_threads=None):
     return _merge(pairs)
 
 
-def read_text_bytes(path):
+PARALLEL_READ_MIN = 64 << 20
+READ_PIECE = 16 << 20
+
+
+def read_text_bytes(path, n_threads=None):
     """The file's bytes as Python's text mode would hand them over (CROPSR.py:58 opens
-    with 'r': universal newlines turn \r\n and \r into \n)."""
-    with open(path, "rb") as f:
-        data = f.read()
-    if b"\r" in data:
-        data = data.replace(b"\r\n", b"\n").replace(b"\r", b"\n")
-    return data
+    with 'r': universal newlines turn \r\n and \r into \n).
+
+    Returns a bytes-like object (bytes, or a uint8 numpy array for a large file: count_byte() and
+    table_from_bytes() take both).  A large file is read by several threads into ONE fresh buffer
+    (os.preadv releases the GIL): what a single read() of a 1 GB genome spends its time on is the
+    page faults of a destination nobody has touched, and those parallelise (6 -> 13 GB/s on the
+    MI355X boxes)."""
+    import os
+    size = os.path.getsize(path)
+    if size < PARALLEL_READ_MIN or not hasattr(os, "preadv"):
+        with open(path, "rb") as f:
+            data = f.read()
+        if b"\r" in data:
+            data = data.replace(b"\r\n", b"\n").replace(b"\r", b"\n")
+        return data
+    from concurrent.futures import ThreadPoolExecutor
+
+    import numpy as np
+
+    from .rows import default_threads
+    buf = np.empty(size, dtype=np.uint8)
+    view = memoryview(buf)
+    piece = READ_PIECE
+    fd = os.open(path, os.O_RDONLY)
+    try:
+        def read_piece(a):
+            b, got = min(size, a + piece), a
+            while got < b:
+                k = os.preadv(fd, [view[got:b]], got)
+                if k <= 0:
+                    raise EOFError("%s: shorter than its size says" % path)
+                got += k
+            return bool((buf[a:b] == 0x0D).any())
+        with ThreadPoolExecutor(min(n_threads or default_threads(), 16)) as pool:
+            has_cr = any(list(pool.map(read_piece, range(0, size, piece))))
+    finally:
+        os.close(fd)
+    if has_cr:
+        return buf.tobytes().replace(b"\r\n", b"\n").replace(b"\r", b"\n")
+    return buf
+
+
+def count_byte(data, ch):
+    """data.count(ch) for what read_text_bytes returns (ch: a one-byte bytes object)."""
+    if isinstance(data, (bytes, bytearray)):
+        return data.count(ch)
+    import numpy as np
+    c, step = ch[0], 64 << 20
+    return int(sum(np.count_nonzero(data[a:a + step] == c) for a in range(0, len(data), step)))
 
 
 def load_bytes(path):

@@ -404,3 +404,26 @@ def test_score_finalize_host_on_probes(name, oracle, manifest, tmp_path, monkeyp
             assert ulp <= 2
         else:
             assert ra == rb
+
+
+def test_parallel_fasta_read_equals_the_plain_read(tmp_path, monkeypatch):
+    """fasta.read_text_bytes on a "large" file (several threads, os.preadv into one buffer) hands over the same bytes as
+    the single read -- also with \\r\\n / \\r line ends, and also when a piece border falls inside a \\r\\n pair --, and
+    table_from_bytes / count_byte take what it returns."""
+    from cropsr_amd import fasta
+    rng = np.random.default_rng(3)
+    body = b"".join(b">c%d some text\n" % k + rng.choice(np.frombuffer(b"ACGTacgtN", dtype=np.uint8), 5000).tobytes() + b"\n"
+                    for k in range(40))
+    for name, data in (("unix.fa", body), ("dos.fa", body.replace(b"\n", b"\r\n")), ("mac.fa", body.replace(b"\n", b"\r"))):
+        path = tmp_path / name
+        path.write_bytes(data)
+        plain = fasta.read_text_bytes(str(path))
+        assert isinstance(plain, bytes) and plain == body
+        monkeypatch.setattr(fasta, "PARALLEL_READ_MIN", 1000)
+        monkeypatch.setattr(fasta, "READ_PIECE", 4097)  # many pieces; borders inside \r\n pairs
+        got = fasta.read_text_bytes(str(path), n_threads=4)
+        monkeypatch.undo()
+        assert bytes(got) == body, name
+        assert fasta.count_byte(got, b">") == body.count(b">") and fasta.count_byte(got, b"\n") == body.count(b"\n")
+        assert [(k, bytes(v)) for k, v in fasta.table_from_bytes(got)] == \
+            [(k, bytes(v)) for k, v in fasta.table_from_bytes(body)]
