@@ -50,6 +50,9 @@ def main():
                          "device 0, tables over the host transport: a rehearsal of the multi-GPU mode on a one-GPU box)")
     ap.add_argument("--out", default=None)
     ap.add_argument("--md5", action="store_true", help="print the CSV's md5 (to compare runs with different --procs)")
+    ap.add_argument("--ablate-ids", action="store_true",
+                    help="timing only (the CSV's id column is wrong): ids cost nothing -- how much of the CSV stage is the "
+                         "one sequential MT19937 stream the reference's ids come from")
     ap.add_argument("--cli-flag", action="append", default=[], metavar="FLAG",
                     help="extra flag for the CLI, e.g. --cli-flag=--offtarget (repeatable)")
     a = ap.parse_args()
@@ -87,6 +90,10 @@ def main():
         os.remove(fa)
         return
     from cropsr_amd import cli
+    if a.ablate_ids:
+        import numpy as np
+        from cropsr_amd import rows as _rows
+        _rows.draw_ids = lambda size, piece=1 << 20, reverse=False: np.full((size, 7), 65, dtype=np.uint8)
     stages_json = os.path.join(tmp, "stages.json")
     args = cli.build_parser().parse_args(argv + ["--bench-json", stages_json])
     os.chdir(tmp)
