@@ -1,3 +1,5 @@
+"""What the CLI's "upload + scan + fetch" stage is made of on the bench genome: library load, Engine() (HIP start-up,
+pinned staging buffers), upload, scan + fetch, slicing per contig.  GPU box, repo root: python tools/cli_stage_breakdown.py"""
 import sys, time
 sys.path.insert(0, '.')
 t0=time.perf_counter()
