@@ -18,7 +18,9 @@ tables to rank 0 (crp_gather_hits) -- runs once after the timed steps and is rep
 ranks / (one step + the one exchange): the number a scaling curve should be built from, since `value`'s
 steps hold no collective; `per_rank` lists every rank's kernel time and share).
 --gather-every-step puts it inside every step instead.  A failed exchange still prints the line
-(`gatherv_ok: false`) and then exits non-zero.  If the RCCL communicator cannot be CREATED (every rank
+(`gatherv_ok: false`) and then exits non-zero; one that never RETURNS is ended by rank 0's watchdog after
+--collective-timeout seconds, the line printed with the scan's numbers first.  If the RCCL communicator cannot be CREATED
+(or its bootstrap does not return within CROPSR_COMM_INIT_TIMEOUT_S; every rank
 learns that together, before any collective), the measurement still runs -- the scan needs no
 collective -- with the control sockets as fence and the host transport for the final exchange; the
 line then carries `rccl_error` and names the transport in `config.parallelism`, and stderr says so.
