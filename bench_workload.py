@@ -152,3 +152,77 @@ def tair10_like():
     lens = [30_427_671, 19_698_289, 23_459_830, 18_585_056, 26_975_502, 366_924, 154_478]
     specs = [ContigSpec("Chr%d" % (i + 1), n, (3, 0, i)) for i, n in enumerate(lens)]
     return Workload("tair10-like-120Mb", specs, gc=0.36, soft_mask=0.0, n_frac=0.002)
+
+
+def synthetic_annotation(wl, gff_path, info_path=None, n_genes=30000, seed=11):
+    """A seeded Phytozome-style GFF3 (+ annotation_info.txt) for a Workload -- the stand-in for the annotation files
+    BASELINE.json configs[2] / [3] name (the real ones are not available offline).  n_genes gene models are dealt to
+    the contigs in proportion to their length (every contig of >= 20 kb gets at least one): gene + mRNA + exon +
+    CDS (+ UTR) rows, 1-based closed coordinates, 1-9 CDS per gene; ~6 % of the genes start inside their predecessor
+    (overlap, often on the other strand), ~2 % lie nested inside it, some CDS rows carry no ID (only Parent).  Two
+    thirds of the genes get a line in the annotation_info file.  Returns the number of gene and CDS rows written."""
+    rng = np.random.default_rng(np.random.SeedSequence([seed, len(wl.specs), n_genes]))
+    lens = np.array([s.length for s in wl.specs], dtype=np.int64)
+    share = np.maximum((lens >= 20000).astype(np.int64), np.floor(n_genes * lens / lens.sum()).astype(np.int64))
+    n_rows = [0, 0]
+    info = None
+    if info_path:
+        info = open(info_path, "w")
+        info.write("#pacId\tlocusName\ttranscriptName\tpeptideName\tPfam\tPanther\tKOG\tKEGG/ec\tKO\tGO\t"
+                   "Best-hit-arabi-name\tarabi-symbol\tarabi-defline\n")
+    deflines = ["protein kinase superfamily protein", "NAC domain containing protein 1", "", "F-box family protein",
+                "Leucine-rich repeat (LRR) family protein", "RING/U-box superfamily protein, putative"]
+    with open(gff_path, "w") as f:
+        f.write("##gff-version 3\n##annot-version synthetic\n")
+        pac = 37000000
+        for ci, (spec, n_here) in enumerate(zip(wl.specs, share.tolist())):
+            if n_here == 0 or spec.length < 2000:
+                continue
+            starts = np.sort(rng.integers(1, max(2, spec.length - 1500), n_here))
+            glen = np.minimum(np.exp(rng.normal(7.8, 0.7, n_here)).astype(np.int64) + 300, 40000)
+            prev = None
+            out = []
+            for g in range(n_here):
+                a, b = int(starts[g]), int(min(spec.length, starts[g] + glen[g]))
+                u = rng.random()
+                if prev is not None and prev[1] - prev[0] > 900:
+                    if u < 0.06:    # starts inside the previous gene
+                        a = int(rng.integers(prev[0] + 1, prev[1]))
+                        b = int(min(spec.length, max(b, a + 400)))
+                    elif u < 0.08:  # nested in the previous gene
+                        a = int(rng.integers(prev[0] + 1, prev[1] - 400))
+                        b = int(rng.integers(a + 200, prev[1]))
+                if b - a < 200:
+                    continue
+                prev = (a, b)
+                strand = "+" if rng.random() < 0.5 else "-"
+                locus = "%s.%03dG%06d" % (wl.name[:5].replace("-", ""), ci + 1, (g + 1) * 100)
+                gid, tid = locus + ".v1.1", locus + ".1.v1.1"
+                pac += 1
+                out.append("%s\tphytozomev12\tgene\t%d\t%d\t.\t%s\t.\tID=%s;Name=%s\n" % (spec.name, a, b, strand, gid, locus))
+                out.append("%s\tphytozomev12\tmRNA\t%d\t%d\t.\t%s\t.\tID=%s;Name=%s.1;pacid=%d;longest=1;Parent=%s\n"
+                           % (spec.name, a, b, strand, tid, locus, pac, gid))
+                n_rows[0] += 1
+                n_ex = int(min(9, 1 + rng.geometric(0.3)))
+                cuts = np.sort(rng.choice(np.arange(a, b + 1), size=min(2 * n_ex, b - a + 1), replace=False))
+                for e in range(len(cuts) // 2):
+                    ea, eb = int(cuts[2 * e]), int(cuts[2 * e + 1])
+                    out.append("%s\tphytozomev12\texon\t%d\t%d\t.\t%s\t.\tID=%s.exon.%d;Parent=%s;pacid=%d\n"
+                               % (spec.name, ea, eb, strand, tid, e + 1, tid, pac))
+                    if e == 0 and eb - ea > 60 and rng.random() < 0.5:
+                        out.append("%s\tphytozomev12\tfive_prime_UTR\t%d\t%d\t.\t%s\t.\tID=%s.five_prime_UTR.1;Parent=%s;pacid=%d\n"
+                                   % (spec.name, ea, ea + 30, strand, tid, tid, pac))
+                        ea += 31
+                    ident = "ID=%s.CDS.%d;" % (tid, e + 1) if rng.random() < 0.97 else ""
+                    out.append("%s\tphytozomev12\tCDS\t%d\t%d\t.\t%s\t%d\t%sParent=%s;pacid=%d\n"
+                               % (spec.name, ea, eb, strand, e % 3, ident, tid, pac))
+                    n_rows[1] += 1
+                if info is not None and rng.random() < 0.67:
+                    at = "AT%dG%05d.1" % (int(rng.integers(1, 6)), int(rng.integers(1000, 80000)))
+                    info.write("%d\t%s\t%s.1\t%s.1.p\tPF%05d\tPTHR%05d\t\t\t\tGO:%07d\t%s\t%s\t%s\n"
+                               % (pac, locus, locus, locus, int(rng.integers(1, 20000)), int(rng.integers(10000, 48000)),
+                                  int(rng.integers(1, 99999)), at, "SYM%d" % g if g % 3 else "", deflines[g % len(deflines)]))
+            f.write("".join(out))
+    if info is not None:
+        info.close()
+    return tuple(n_rows)

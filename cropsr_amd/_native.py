@@ -57,6 +57,16 @@ SIGNATURES = {
     "crp_comm_allreduce_f64": (ctypes.c_int, [ctypes.c_void_p, f64p, ctypes.c_int, ctypes.c_int]),
     "crp_gather_hits": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, u64p]),
     "crp_gathered_fetch": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, u32p, f64p, u32p, u32p, f64p, u32p]),
+    "crp_gathered_fetch_features": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, u32p, u32p]),
+    "crp_annotation_build": (ctypes.c_int, [u8p, ctypes.c_uint64, u8p, ctypes.c_uint64, voidpp]),
+    "crp_annotation_destroy": (ctypes.c_int, [ctypes.c_void_p]),
+    "crp_annotation_stats": (ctypes.c_int, [ctypes.c_void_p, u64p, u64p, u64p, u64p, u64p]),
+    "crp_annotation_strings": (ctypes.c_int, [ctypes.c_void_p, u8p, u64p]),
+    "crp_annotation_seqid": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, voidpp, u64p, voidpp, voidpp, u64p]),
+    "crp_annotation_track": (ctypes.c_int, [ctypes.c_void_p, u64p, ctypes.c_uint64, ctypes.c_int, u32p, u32p, ctypes.c_uint64,
+                                            u64p]),
+    "crp_annotate_set_track": (ctypes.c_int, [ctypes.c_void_p, u32p, u32p, ctypes.c_uint64]),
+    "crp_annotate_lookup": (ctypes.c_int, [ctypes.c_void_p, u32p, u32p]),
     "crp_offtarget_hist_get": (ctypes.c_int, [ctypes.c_void_p, u32p]),
     "crp_offtarget_hist_set": (ctypes.c_int, [ctypes.c_void_p, u32p]),
     "crp_offtarget_reset": (ctypes.c_int, [ctypes.c_void_p]),
@@ -79,15 +89,18 @@ CRP_OK = 0
 ORDER_BODY4, ORDER_TAIL2, ORDER_DOT1 = 0, 1, 2
 OPT_TWO_PASS, OPT_CHAIN_TIMEOUT_US = 1, 2
 Q_CHAIN_TIMEOUTS, Q_TWO_PASS_ACTIVE, Q_COMM_WORLD, Q_COMM_RANK = 1, 2, 3, 4
-KINDS = ("count", "tile_scan", "emit_score", "ot_seed", "ot_ball", "ot_lookup", "gatherv", "ot_reduce")  # CRP_K_*
+KINDS = ("count", "tile_scan", "emit_score", "ot_seed", "ot_ball", "ot_lookup", "gatherv", "ot_reduce",
+         "annotate")  # CRP_K_*
 REDUCE_SUM, REDUCE_MAX = 0, 1
 COMM_ID_BYTES = 128
-GATHER_OFFTARGET, GATHER_PRE = 1, 2
+GATHER_OFFTARGET, GATHER_PRE, GATHER_FEATURES = 1, 2, 4
+NO_FEATURE = 0xFFFFFFFF
 SCAN_PRE, SCAN_SEEDS = 1, 2
 OT_SEEDS = 1 << 24
 OT_NOT_A_SITE, OT_NOT_OWNED = 0xFFFFFFFF, 0xFFFFFFFE
-ABI_VERSION = 3
+ABI_VERSION = 4
 CRP_ERR_NO_DEVICE = -2
+CRP_ERR_CAPACITY = -6
 CRP_ERR_IO = -8
 CRP_ERR_COMM = -9
 CRP_ERR_NOMEM, CRP_ERR_STATE, CRP_ERR_PEER = -4, -5, -10

@@ -4,8 +4,8 @@ The reference parses the GFF into a DataFrame (CROPSR.py:77-95, called at :375),
 writes the constant '' into the `features` column (CROPSR.py:466, :468); `-p` is only echoed in
 the banner (:364).  A real join changes the CSV, so it is OPT-IN here and the default output
 stays byte-identical.  Being absent from the reference, the join has no reference oracle
-("parity unpinned"); its definition is this module's, and tests/test_annotate.py checks it
-against a brute-force restatement.
+("parity unpinned"); its definition is this engine's, and tests/test_annotate.py checks it
+against a brute-force restatement (oracle/annotate_oracle.py).
 
 Definition.  A row of the CSV that has a cut site (the 12-field rows; cutsite = end_pos - 3,
 CROPSR.py:155-158) gets, in `features`, the ';'-joined labels of every GFF row whose type is `gene`
@@ -18,17 +18,24 @@ Coordinates: the reference's positions index the string it scans; in the re-form
 string starts with one decoration character, so genome coordinate (1-based) =
 cutsite - dec + 1 with dec = 1 there and 0 for an unformatted FASTA.
 
-Method: per seqid the feature intervals cut the coordinate axis into elementary intervals with a
-constant label set (a sweep over the 2F interval ends builds one string per distinct set); a hit
-then needs one binary search (numpy searchsorted over the sorted cut points).
+Where the work is done.  This module only moves tables:
+  * crp_annotation_build (csrc/crp_annotation.cpp, host code) reads the two files and, per seqid, cuts the
+    coordinate axis at the interval ends into elementary intervals with a constant label set: one string per
+    DISTINCT set, one id per interval;
+  * crp_annotation_track lays those intervals out in ARENA positions for the texts a rank has loaded (whole contigs,
+    or the pieces of cut contigs in a multi-GPU run);
+  * crp_annotate_set_track / crp_annotate_lookup (csrc/crp_annotate.hip) map every kept hit of the resident hit
+    tables to the id of the interval its cut site falls in -- on the GPU, one streaming pass;
+  * crp_write_rows_ex prints string[id] into the `features` column.
 """
-import re
+import ctypes
 
 import numpy as np
 
-NO_FEATURE = 0xFFFFFFFF
-TYPES = ("gene", "CDS")
-_ATTR = re.compile(r"(?:^|;)\s*(ID|Name|Parent)=([^;]*)")
+from . import _native as nat
+from . import fasta
+
+NO_FEATURE = nat.NO_FEATURE
 
 
 def contig_name(key):
@@ -44,118 +51,117 @@ def contig_name(key):
     return k
 
 
-def parse_gff(path):
-    """[(seqid, type, start, end, attributes)] of the gene / CDS rows, in file order."""
-    out = []
-    with open(path, "r") as f:
-        for line in f:
-            if not line or line[0] == "#":
-                continue
-            cols = line.rstrip("\n").split("\t")
-            if len(cols) < 9 or cols[2] not in TYPES:
-                continue
-            try:
-                start, end = int(cols[3]), int(cols[4])
-            except ValueError:
-                continue
-            out.append((cols[0], cols[2], start, end, cols[8]))
-    return out
+def _text_u8(path):
+    """(uint8 array, length): the file as text mode hands its lines over; an empty file still gets an address."""
+    data = fasta.read_text_bytes(path)
+    n = len(data)
+    if not isinstance(data, np.ndarray):
+        data = np.frombuffer(data or b"\0", dtype=np.uint8)
+    return data, n
 
 
-def parse_annotation_info(path):
-    """Phytozome annotation_info.txt -> {locusName: (best-hit-arabi-name, arabi-defline)}.  Columns are
-    taken by name from a '#pacId ...' header when there is one, else by the usual positions."""
-    names = ["pacId", "locusName", "transcriptName", "peptideName", "Pfam", "Panther", "KOG", "KEGG/ec", "KO", "GO",
-             "Best-hit-arabi-name", "arabi-symbol", "arabi-defline"]
-    info = {}
-    with open(path, "r") as f:
-        for line in f:
-            cols = line.rstrip("\n").split("\t")
-            if line.startswith("#"):
-                head = [c.lstrip("#") for c in cols]
-                if "locusName" in head:
-                    names = head
-                continue
-            if len(cols) < 2:
-                continue
-            rec = dict(zip(names, cols))
-            locus = rec.get("locusName", "")
-            if locus and locus not in info:
-                info[locus] = (rec.get("Best-hit-arabi-name", ""), rec.get("arabi-defline", ""))
-    return info
+class StringTable:
+    """The distinct label-set strings in the form crp_write_rows_ex takes (blob + offsets); table[k] decodes one."""
 
+    def __init__(self, blob, off):
+        self.blob, self.off = blob, off
 
-def label_of(ftype, attributes, info=None):
-    attrs = dict(_ATTR.findall(attributes))
-    ident = attrs.get("ID") or attrs.get("Name") or attrs.get("Parent") or "."
-    label = "%s:%s" % (ftype, ident)
-    if info and ftype == "gene":
-        hit = info.get(attrs.get("Name", "")) or info.get(attrs.get("ID", ""))
-        if hit:
-            label += "".join("|" + x for x in hit if x)
-    return label
+    def __len__(self):
+        return int(self.off.size - 1)
 
-
-class _Track:
-    """One seqid: sorted cut points and the string id of every elementary interval."""
-
-    def __init__(self, feats, strings, string_ids):
-        # feats: [(start, end, order, label)]
-        points = sorted(set([s for s, _, _, _ in feats] + [e + 1 for _, e, _, _ in feats]))
-        self.points = np.asarray(points, dtype=np.int64)
-        by_start = sorted(feats, key=lambda t: t[0])
-        ids = np.full(len(points), NO_FEATURE, dtype=np.uint32)
-        active, nxt = [], 0
-        for i, x in enumerate(points):
-            while nxt < len(by_start) and by_start[nxt][0] <= x:
-                active.append(by_start[nxt])
-                nxt += 1
-            active = [t for t in active if t[1] >= x]
-            if active:
-                labels = []
-                for t in sorted(active, key=lambda t: t[2]):  # GFF file order
-                    if t[3] not in labels:
-                        labels.append(t[3])
-                text = ";".join(labels)
-                k = string_ids.get(text)
-                if k is None:
-                    k = string_ids[text] = len(strings)
-                    strings.append(text)
-                ids[i] = k
-        self.ids = ids
-
-    def lookup(self, x):
-        """string id per coordinate (numpy int64 array)."""
-        i = np.searchsorted(self.points, x, "right") - 1
-        out = np.full(x.shape, NO_FEATURE, dtype=np.uint32)
-        ok = i >= 0
-        out[ok] = self.ids[i[ok]]
-        return out
+    def __getitem__(self, k):
+        return bytes(self.blob[int(self.off[k]):int(self.off[k + 1])]).decode("utf-8", "replace")
 
 
 class Annotation:
-    def __init__(self, gff_path, phytozome_path=None):
-        info = parse_annotation_info(phytozome_path) if phytozome_path else None
-        per_seq = {}
-        for order, (seqid, ftype, start, end, attrs) in enumerate(parse_gff(gff_path)):
-            per_seq.setdefault(seqid, []).append((start, end, order, label_of(ftype, attrs, info)))
-        self.strings, ids = [], {}
-        self.tracks = {seqid: _Track(feats, self.strings, ids) for seqid, feats in per_seq.items()}
+    """The parsed GFF (+ annotation_info): label-set strings and per-seqid elementary intervals (native handle)."""
 
-    def for_contig(self, key, hits, guide_len, dec, contig_len):
-        """(strings, idx): idx[k] = entry of `strings` for row k of the contig (rows in the reference's
-        order: '+' hits, then '-' hits), NO_FEATURE for rows without a feature or without a cut site."""
-        ip = np.asarray(hits["pos_plus"]).astype(np.int64)
-        jm = np.asarray(hits["pos_minus"]).astype(np.int64)
-        l = int(guide_len)
-        # a row has a cut site iff its long_sequence has 30 characters (CROPSR.py:466): Python clamps
-        # the slice at the end of the string
-        full_p = np.minimum(ip + 5, contig_len) - (ip - l - 5) == 30
-        full_m = np.minimum(jm + 3 + l + 5, contig_len) - (jm - 2) == 30
-        cut = np.concatenate([ip - 3, jm])            # end_pos - 3 (CROPSR.py:157): '+' end = i, '-' end = j + 3
-        full = np.concatenate([full_p, full_m])
-        idx = np.full(cut.shape, NO_FEATURE, dtype=np.uint32)
-        track = self.tracks.get(contig_name(key))
-        if track is not None and cut.size:
-            idx[full] = track.lookup(cut[full] - dec + 1)
-        return self.strings, idx
+    def __init__(self, gff_path, phytozome_path=None):
+        L = nat.lib()
+        gff, n_gff = _text_u8(gff_path)
+        info, n_info = _text_u8(phytozome_path) if phytozome_path else (None, 0)
+        self._h = ctypes.c_void_p()
+        nat.check(L.crp_annotation_build(gff.ctypes.data_as(nat.u8p), n_gff, info.ctypes.data_as(nat.u8p) if info is not None else None,
+                                         n_info, ctypes.byref(self._h)), "crp_annotation_build")
+        c = [ctypes.c_uint64() for _ in range(5)]
+        nat.check(L.crp_annotation_stats(self._h, *[ctypes.byref(x) for x in c]), "crp_annotation_stats")
+        n_seq, n_str, n_blob, self.n_genes, self.n_cds = [int(x.value) for x in c]
+        blob = np.zeros(max(1, n_blob), dtype=np.uint8)
+        off = np.zeros(n_str + 1, dtype=np.uint64)
+        nat.check(L.crp_annotation_strings(self._h, blob.ctypes.data_as(nat.u8p), off.ctypes.data_as(nat.u64p)),
+                  "crp_annotation_strings")
+        self.strings = StringTable(blob, off)
+        self.seq_index = {}
+        for k in range(n_seq):
+            name, _, _ = self._seq(k)
+            self.seq_index[name] = k
+        self.n_seqids = n_seq
+
+    def _seq(self, k):
+        name, points, ids = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+        n_name, n = ctypes.c_uint64(), ctypes.c_uint64()
+        nat.check(nat.lib().crp_annotation_seqid(self._h, k, ctypes.byref(name), ctypes.byref(n_name), ctypes.byref(points),
+                                                 ctypes.byref(ids), ctypes.byref(n)), "crp_annotation_seqid")
+        text = ctypes.string_at(name.value, n_name.value).decode("utf-8", "replace") if n_name.value else ""
+        return text, (points.value, ids.value), int(n.value)
+
+    def seq_track(self, name):
+        """(points int64 -- 1-based genome coordinates, ascending --, ids uint32) of one seqid, or None: interval k =
+        [points[k], points[k+1]) carries strings[ids[k]].  Copies (for tests and the oracle's host-side join)."""
+        k = self.seq_index.get(name)
+        if k is None:
+            return None
+        _, (p, i), n = self._seq(k)
+        if n == 0:
+            return np.empty(0, np.int64), np.empty(0, np.uint32)
+        points = np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_int64)), (n,)).copy()
+        ids = np.ctypeslib.as_array(ctypes.cast(i, ctypes.POINTER(ctypes.c_uint32)), (n,)).copy()
+        return points, ids
+
+    def arena_track(self, entries, dec):
+        """(points uint32, ids uint32) for crp_annotate_set_track: entries = [(FASTA name, index of the text's first
+        character inside its contig string, length of the text, arena offset)] in arena order."""
+        e = np.empty((len(entries), 4), dtype=np.uint64)
+        none = np.uint64(0xFFFFFFFFFFFFFFFF)
+        for r, (name, lo, length, off) in enumerate(entries):
+            k = self.seq_index.get(name)
+            e[r] = (none if k is None else k, lo, length, off)
+        n = ctypes.c_uint64()
+        L = nat.lib()
+        st = L.crp_annotation_track(self._h, e.ctypes.data_as(nat.u64p), e.shape[0], int(dec), None, None, 0, ctypes.byref(n))
+        if st not in (nat.CRP_OK, nat.CRP_ERR_CAPACITY):
+            nat.check(st, "crp_annotation_track")
+        points, ids = np.empty(n.value, dtype=np.uint32), np.empty(n.value, dtype=np.uint32)
+        nat.check(L.crp_annotation_track(self._h, e.ctypes.data_as(nat.u64p), e.shape[0], int(dec), points.ctypes.data_as(nat.u32p),
+                                         ids.ctypes.data_as(nat.u32p), n.value, ctypes.byref(n)), "crp_annotation_track")
+        return points, ids
+
+    def close(self):
+        if self._h:
+            nat.lib().crp_annotation_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+
+class Request:
+    """What a backend needs to annotate the texts it scans: the Annotation, the FASTA name of the contig every text
+    comes from, where the text starts inside that contig's string, and `dec`."""
+
+    def __init__(self, annotation, names, dec, starts=None):
+        self.annotation, self.names, self.dec = annotation, list(names), int(dec)
+        self.starts = [0] * len(self.names) if starts is None else [int(s) for s in starts]
+
+    def pieces(self, which, starts):
+        """The same request for texts that are pieces of the contigs: which[k] = contig index of text k."""
+        return Request(self.annotation, [self.names[q] for q in which], self.dec, starts)
+
+    def track(self, layout):
+        """layout: [(text index, arena offset, length)] of ONE arena in arena order -> (points, ids)."""
+        return self.annotation.arena_track([(self.names[t], self.starts[t], ln, off) for t, off, ln in layout], self.dec)
+
+
+def features_of(request, hits):
+    """(string table, idx) for rows.ContigTable / ContigRows from a contig's hit dict that carries the device's
+    feat_plus / feat_minus columns (rows in the reference's order: '+' hits, then '-' hits)."""
+    return request.annotation.strings, np.concatenate([hits["feat_plus"], hits["feat_minus"]]).astype(np.uint32, copy=False)

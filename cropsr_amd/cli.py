@@ -124,6 +124,13 @@ class EngineResident:
             a, j = genome._where[k]
             self.layout.append((a, int(genome.arenas[a].offsets[j]), int(genome.arenas[a].lengths[j])))
         self._ot = False
+        self._annotated = False
+
+    def annotate(self, request):
+        """The annotation join over this rank's resident tables (annotate.Request for ITS texts); the ids stay in HBM
+        and travel with the tables in gather()."""
+        self.genome.annotate(request, self.counts, fetch=False)
+        self._annotated = True
 
     def offtarget(self, group, own_by_arena):
         eng = self.backend.engine
@@ -145,30 +152,32 @@ class EngineResident:
             arena.offtarget_counts(n_plus, n_minus, fetch=False)
         self._ot = True
 
-    def _host_cols(self, arena, n_plus, n_minus, offtarget):
+    def _host_cols(self, arena, n_plus, n_minus, offtarget, features):
         c = arena.fetch(n_plus, n_minus, self.want_pre)
         cols = {"pos_plus": c[0], "score_plus": c[1] if self.want_pre else c[2],
                 "pos_minus": c[3], "score_minus": c[4] if self.want_pre else c[5]}
         if offtarget:
             cols["ot_plus"], cols["ot_minus"] = arena.offtarget_counts(n_plus, n_minus)
+        if features:
+            cols["feat_plus"], cols["feat_minus"] = arena.annotate_lookup(n_plus, n_minus)
         return cols
 
-    def gather(self, group, dst, offtarget):
+    def gather(self, group, dst, offtarget, features=False):
         """[rank][arena] -> column dict on dst.  With want_pre the f64 column carries the pre-sigmoid
         sum (the root finalises the score on its host)."""
         from . import _native as nat
         from . import parallel
         eng = self.backend.engine
         if self.backend.transport != "rccl":
-            mine = [self._host_cols(a, n[0], n[1], offtarget) for a, n in zip(self.genome.arenas, self.counts)]
-            return parallel.gather_host(group, mine, dst, offtarget)
+            mine = [self._host_cols(a, n[0], n[1], offtarget, features) for a, n in zip(self.genome.arenas, self.counts)]
+            return parallel.gather_host(group, mine, dst, offtarget, features)
         n_arenas = group.all_gather(len(self.genome.arenas))
         out = [[] for _ in range(group.world)]
         for rnd in range(max(n_arenas)):
             arena = self.genome.arenas[rnd] if rnd < len(self.genome.arenas) else None
             err, counts = None, None
             try:
-                counts = eng.gather_hits(arena, dst, offtarget, pre=self.want_pre)
+                counts = eng.gather_hits(arena, dst, offtarget, pre=self.want_pre, features=features)
             except nat.CropsrHipError as e:
                 # crp_gather_hits agrees on what can fail on one rank BEFORE the tables move (a rank without tables, a
                 # root that cannot size its receive buffers): every rank is back from the same call, so all of them
@@ -182,7 +191,7 @@ class EngineResident:
             if group.rank == dst:
                 for r in range(group.world):
                     if rnd < n_arenas[r]:
-                        out[r].append(eng.gathered_fetch(r, counts, offtarget))
+                        out[r].append(eng.gathered_fetch(r, counts, offtarget, features))
         return out if group.rank == dst else None
 
     def release(self):
@@ -224,10 +233,12 @@ class EngineBackend:
                 hits["score_" + strand] = host_sigmoid(pre)
         return hits
 
-    def scan(self, contig_strings, guide_len, offtarget=False):
-        """One arena pass on the GPU for all contig strings (seam 1 + 2)."""
+    def scan(self, contig_strings, guide_len, offtarget=False, annotation=None):
+        """One arena pass on the GPU for all contig strings (seam 1 + 2).  annotation (annotate.Request): the hit
+        dicts also carry feat_plus / feat_minus, the label-set id of every row, joined on the GPU while the tables
+        are resident."""
         genome = self.engine.genome(contig_strings)  # as many arenas as the genome needs
-        hits = genome.scan_score(guide_len, want_pre=self.finalize == "host", offtarget=offtarget)
+        hits = genome.scan_score(guide_len, want_pre=self.finalize == "host", offtarget=offtarget, annotation=annotation)
         out = [self._finalize(hits.contig(k)) for k in range(len(contig_strings))]
         genome.close()
         return out
@@ -298,7 +309,7 @@ def refilter_hits(hits, n, l):
         p = np.asarray(hits["pos_" + strand]).astype(np.int64)
         a, b = (p - l, p) if strand == "plus" else (p + 3, p + 3 + l)  # pam_location (:418 / :429)
         keep = (a >= 5) & (a + 5 <= n + 10) & (b >= 5) & (b <= n + 10)
-        for key in ("pos_", "score_", "pre_", "ot_"):
+        for key in ("pos_", "score_", "pre_", "ot_", "feat_"):
             col = hits.get(key + strand)
             if col is not None:
                 out[key + strand] = np.asarray(col)[keep]
@@ -362,6 +373,15 @@ def run(args, backend=None, out=sys.stdout, group=None):
     # Opening the GPU (HIP start-up, code object, two pinned staging buffers: ~0.3 s) starts NOW on a helper thread and
     # is collected where the backend is first needed: it overlaps reading and parsing the FASTA.
     early = _Early(make_backend) if backend is None else None
+    # --annotate: the GFF (+ annotation_info) is parsed natively (crp_annotation_build releases the GIL) beside the FASTA read
+    annotating = bool(getattr(args, "annotate", False))
+    early_annot = _Early(lambda: __import__(__package__ + ".annotate", fromlist=["Annotation"]).Annotation(args.g, args.p)) if annotating else None
+
+    def annotation_request(data, table):
+        """annotate.Request for the contig strings of `table` (every rank builds the same one)."""
+        from . import annotate
+        formatted = 2 * fasta.count_byte(data, b">") != fasta.count_byte(data, b"\n") + 1  # CROPSR.py:61: dec = 1
+        return annotate.Request(early_annot.get(), [annotate.contig_name(k) for k, _ in table], 1 if formatted else 0)
 
     if group is not None and group.rank != 0:
         # Ranks other than 0 of a multi-GPU run: read the same FASTA, scan their share of the contigs,
@@ -369,9 +389,14 @@ def run(args, backend=None, out=sys.stdout, group=None):
         # Whatever fails here is reported to every rank (group.check inside sharded_scan).
         from . import parallel
         own_backend = backend is None
-        err, strings = None, []
+        err, strings, request = None, [], None
         try:
-            strings = [v for _, v in fasta.table_from_bytes(fasta.read_text_bytes(args.f))]
+            data = fasta.read_text_bytes(args.f)
+            table = fasta.table_from_bytes(data)
+            strings = [v for _, v in table]
+            if annotating:
+                request = annotation_request(data, table)
+            del data, table
             if own_backend:
                 backend = early.get()
         except Exception as e:
@@ -380,7 +405,7 @@ def run(args, backend=None, out=sys.stdout, group=None):
             group.check(err)
             if hasattr(backend, "connect"):
                 backend.connect()
-            parallel.sharded_scan(backend, strings, l_dev, group, max_piece=max_piece, offtarget=offtarget)
+            parallel.sharded_scan(backend, strings, l_dev, group, max_piece=max_piece, offtarget=offtarget, annotation=request)
         finally:
             if own_backend and backend is not None:
                 backend.close()
@@ -416,8 +441,13 @@ def run(args, backend=None, out=sys.stdout, group=None):
         if 2 * fasta.count_byte(data, b">") != fasta.count_byte(data, b"\n") + 1:
             print("formatting genome", file=out)
             print(f"Genome file {args.f} successfully formatted", file=out)
-    formatted = (2 * fasta.count_byte(data, b">") != fasta.count_byte(data, b"\n") + 1) if getattr(args, "annotate", False) else None
     table = fasta.table_from_bytes(data)  # == fasta.contig_table(text).items(), without printing the genome
+    request, request_err = None, None
+    if annotating:
+        try:
+            request = annotation_request(data, table)
+        except Exception as e:  # (single process: raised below, after the reference's own GFF import had its say)
+            request_err = e
     del data
     stages["read_fasta_s"] = time.perf_counter() - t_stage
     if verbose:
@@ -441,11 +471,18 @@ def run(args, backend=None, out=sys.stdout, group=None):
     if group is None:
         if own_backend:
             backend = early.get()
-        all_hits = backend.scan(strings, l_dev, offtarget=offtarget) if offtarget else backend.scan(strings, l_dev)
+        if request_err is not None:
+            raise request_err
+        extra = dict(offtarget=True) if offtarget else {}
+        if request is not None:
+            extra["annotation"] = request
+        all_hits = backend.scan(strings, l_dev, **extra)
     else:  # contigs (cut where longer than a rank's share) over all GPUs, tables gathered here
         from . import parallel
         err = None
         try:
+            if request_err is not None:
+                raise request_err
             if own_backend:
                 backend = early.get()
         except Exception as e:
@@ -453,7 +490,7 @@ def run(args, backend=None, out=sys.stdout, group=None):
         group.check(err)
         if hasattr(backend, "connect"):
             backend.connect()
-        all_hits = parallel.sharded_scan(backend, strings, l_dev, group, max_piece=max_piece, offtarget=offtarget)
+        all_hits = parallel.sharded_scan(backend, strings, l_dev, group, max_piece=max_piece, offtarget=offtarget, annotation=request)
         if hasattr(backend, "finalize_gathered"):
             all_hits = backend.finalize_gathered(all_hits)
     if l_dev != args.l:  # a length outside the engine's range: the literal keep-filter, on the host
@@ -465,11 +502,6 @@ def run(args, backend=None, out=sys.stdout, group=None):
         group.close()
         group = None
     stages["upload_scan_fetch_s"] = time.perf_counter() - t_stage
-
-    annot = None
-    if getattr(args, "annotate", False):
-        from . import annotate
-        annot = annotate.Annotation(args.g, args.p)
 
     # (the native formatter's row buffers are sized for guide lengths 1..50; other lengths take the csv module)
     native = getattr(args, "csv_writer", "native") == "native" and NATIVE_GUIDE_LENGTHS[0] <= args.l <= NATIVE_GUIDE_LENGTHS[1]
@@ -487,7 +519,9 @@ def run(args, backend=None, out=sys.stdout, group=None):
     for name, s, hits in zip(names, strings, all_hits):
         print("Searching on Chromosome: ", name[:25], file=out)  # CROPSR.py:410-411
         print("With start of sequence: ", bytes(s[:25]).decode("latin-1"), file=out)
-        feats = annot.for_contig(name, hits, args.l, 1 if formatted else 0, len(s)) if annot is not None else None
+        feats = None
+        if request is not None:  # the device's label-set id per row ('+' rows, then '-' rows) + the string table
+            feats = (request.annotation.strings, np.concatenate([hits["feat_plus"], hits["feat_minus"]]))
         block = (rows.ContigTable(name, s, hits, args.l, features=feats) if native
                  else rows.ContigRows(name, bytes(s).decode("latin-1"), hits, args.l, features=feats))
         if once:

@@ -401,6 +401,11 @@ int crp_arena_destroy(crp_arena *a)
         (void)hipFree(a->d_ot_cnt[s]);
     }
     (void)hipFree(a->d_ot_own);
+    (void)hipFree(a->d_ann_points);
+    (void)hipFree(a->d_ann_ids);
+    (void)hipFree(a->d_ann_bucket);
+    (void)hipFree(a->d_feat[0]);
+    (void)hipFree(a->d_feat[1]);
     delete a;
     return CRP_OK;
 }
@@ -774,6 +779,7 @@ int crp_scan_score(crp_arena *a, int guide_len, int flags, uint64_t *n_plus, uin
     CRP_HIP(ctx, hipSetDevice(ctx->device));
     a->have_hits = false;
     a->have_raw = false;
+    a->have_feat = false;
     // seed words come out of the l = 20 kernel only; for other lengths the off-target step derives them itself
     const ScanWant want{(flags & CRP_SCAN_PRE) != 0, (flags & CRP_SCAN_SEEDS) != 0 && guide_len == 20};
     const uint64_t eff_words = (uint64_t)a->n_tiles * crp::TILE_WORDS;

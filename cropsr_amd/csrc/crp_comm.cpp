@@ -97,7 +97,8 @@ struct crp_comm {
     uint32_t *d_gpos[2] = {nullptr, nullptr};
     double *d_gscore[2] = {nullptr, nullptr};
     uint4 *d_got[2] = {nullptr, nullptr};  // CRP_GATHER_OFFTARGET: per-hit counts
-    uint64_t gpos_cap[2] = {0, 0}, gscore_cap[2] = {0, 0}, got_cap[2] = {0, 0};
+    uint32_t *d_gfeat[2] = {nullptr, nullptr};  // CRP_GATHER_FEATURES: per-hit label-set ids
+    uint64_t gpos_cap[2] = {0, 0}, gscore_cap[2] = {0, 0}, got_cap[2] = {0, 0}, gfeat_cap[2] = {0, 0};
     int gflags = 0;
     std::vector<uint64_t> goff[2];  // element offset of every rank's slice (root's own slice: unused)
     int groot = -1;
@@ -127,6 +128,7 @@ void comm_release(crp_ctx *ctx)
         (void)hipFree(c->d_gpos[s]);
         (void)hipFree(c->d_gscore[s]);
         (void)hipFree(c->d_got[s]);
+        (void)hipFree(c->d_gfeat[s]);
     }
     delete c;
     ctx->comm = nullptr;
@@ -256,9 +258,11 @@ int crp_gather_hits(crp_ctx *ctx, crp_arena *a, int root, int flags, uint64_t *c
     crp_comm *c = ctx->comm;
     if (!c) return CRP_ERR_STATE;
     // (arguments that are the same on every rank by contract: a bad one fails everywhere alike)
-    if (root < 0 || root >= c->world || (flags & ~(CRP_GATHER_OFFTARGET | CRP_GATHER_PRE))) return CRP_ERR_INVALID;
+    if (root < 0 || root >= c->world || (flags & ~(CRP_GATHER_OFFTARGET | CRP_GATHER_PRE | CRP_GATHER_FEATURES)))
+        return CRP_ERR_INVALID;
     const bool send_pre = (flags & CRP_GATHER_PRE) != 0;
     const bool with_ot = (flags & CRP_GATHER_OFFTARGET) != 0;
+    const bool with_feat = (flags & CRP_GATHER_FEATURES) != 0;
     // What can differ from rank to rank -- the state of this rank's arena, the root's allocation -- is never
     // answered with an early return: a rank that left here alone would leave its peers inside a collective
     // that cannot complete.  Each rank's status travels WITH its counts, and everyone acts on all of them.
@@ -266,6 +270,7 @@ int crp_gather_hits(crp_ctx *ctx, crp_arena *a, int root, int flags, uint64_t *c
     if (a && (a->ctx != ctx || !a->have_hits)) local = CRP_ERR_STATE;
     else if (send_pre && a && !a->have_pre) local = CRP_ERR_STATE;
     else if (with_ot && a && (!ctx->ot_solved || a->ot_epoch != ctx->ot_epoch)) local = CRP_ERR_STATE;
+    else if (with_feat && a && !a->have_feat) local = CRP_ERR_STATE;
     if (c->test_fail == 2 && c->rank == c->world - 1) local = CRP_ERR_STATE;  // test hook (CRP_TEST_GATHER_FAIL)
     const Rccl *r = rccl();
     CRP_HIP(ctx, hipSetDevice(ctx->device));
@@ -300,6 +305,8 @@ int crp_gather_hits(crp_ctx *ctx, crp_arena *a, int root, int flags, uint64_t *c
                 alloc = crp::grow(ctx, reinterpret_cast<void **>(&c->d_gscore[s]), &c->gscore_cap[s], total, sizeof(double));
             if (alloc == CRP_OK && with_ot)
                 alloc = crp::grow(ctx, reinterpret_cast<void **>(&c->d_got[s]), &c->got_cap[s], total, sizeof(uint4));
+            if (alloc == CRP_OK && with_feat)
+                alloc = crp::grow(ctx, reinterpret_cast<void **>(&c->d_gfeat[s]), &c->gfeat_cap[s], total, sizeof(uint32_t));
         }
         if (c->test_fail == 1) {  // test hook: as if the receive buffers did not fit
             alloc = CRP_ERR_NOMEM;
@@ -329,6 +336,8 @@ int crp_gather_hits(crp_ctx *ctx, crp_arena *a, int root, int flags, uint64_t *c
                     st = r->Recv(c->d_gscore[s] + c->goff[s][(size_t)p], n, ncclDouble, p, c->comm, ctx->stream);
                 if (st == ncclSuccess && with_ot)
                     st = r->Recv(c->d_got[s] + c->goff[s][(size_t)p], 4 * n, ncclUint32, p, c->comm, ctx->stream);
+                if (st == ncclSuccess && with_feat)
+                    st = r->Recv(c->d_gfeat[s] + c->goff[s][(size_t)p], n, ncclUint32, p, c->comm, ctx->stream);
             }
         }
     } else {
@@ -338,6 +347,7 @@ int crp_gather_hits(crp_ctx *ctx, crp_arena *a, int root, int flags, uint64_t *c
             if (st == ncclSuccess)
                 st = r->Send(send_pre ? a->d_pre[s] : a->d_score[s], mine[s], ncclDouble, root, c->comm, ctx->stream);
             if (st == ncclSuccess && with_ot) st = r->Send(a->d_ot_cnt[s], 4 * mine[s], ncclUint32, root, c->comm, ctx->stream);
+            if (st == ncclSuccess && with_feat) st = r->Send(a->d_feat[s], mine[s], ncclUint32, root, c->comm, ctx->stream);
         }
     }
     const ncclResult_t st_end = r->GroupEnd();
@@ -390,6 +400,31 @@ int crp_gathered_fetch(crp_ctx *ctx, int rank, uint32_t *pos_plus, double *score
         if (ho[s]) rc = crp::staged_d2h(ctx, ho[s], dt, n * sizeof(uint4));
         if (rc == CRP_OK && hp[s]) rc = crp::staged_d2h(ctx, hp[s], dp, n * sizeof(uint32_t));
         if (rc == CRP_OK && hs[s]) rc = crp::staged_d2h(ctx, hs[s], ds, n * sizeof(double));
+        if (rc != CRP_OK) return rc;
+    }
+    CRP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CRP_OK;
+}
+
+int crp_gathered_fetch_features(crp_ctx *ctx, int rank, uint32_t *feat_plus, uint32_t *feat_minus)
+{
+    if (!ctx) return CRP_ERR_INVALID;
+    crp_comm *c = ctx->comm;
+    if (!c || !c->have_gather || c->rank != c->groot || !(c->gflags & CRP_GATHER_FEATURES)) return CRP_ERR_STATE;
+    if (rank < 0 || rank >= c->world) return CRP_ERR_INVALID;
+    CRP_HIP(ctx, hipSetDevice(ctx->device));
+    uint32_t *hf[2] = {feat_plus, feat_minus};
+    for (int s = 0; s < 2; ++s) {
+        const uint64_t n = c->counts[2 * (size_t)rank + s];
+        if (!n || !hf[s]) continue;
+        const uint32_t *df;
+        if (rank == c->groot) {  // root's own rows never moved
+            if (!c->garena || !c->garena->have_feat) return CRP_ERR_STATE;
+            df = c->garena->d_feat[s];
+        } else {
+            df = c->d_gfeat[s] + c->goff[s][(size_t)rank];
+        }
+        const int rc = crp::staged_d2h(ctx, hf[s], df, n * sizeof(uint32_t));
         if (rc != CRP_OK) return rc;
     }
     CRP_HIP(ctx, hipStreamSynchronize(ctx->stream));

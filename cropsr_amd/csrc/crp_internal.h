@@ -94,6 +94,15 @@ struct crp_arena {
     uint64_t *d_ot_own = nullptr;  // own_ranges of the last crp_offtarget_add
     uint64_t ot_own_cap = 0;
     uint64_t ot_epoch = 0;         // ctx->ot_epoch at the time of crp_offtarget_add (0: never added)
+    // annotation join (crp_annotate.hip): the track of this arena and the per-hit label-set ids of the last look-up
+    uint32_t *d_ann_points = nullptr, *d_ann_ids = nullptr;  // cut points (arena positions, ascending) and their ids
+    uint64_t track_cap = 0, n_ann_points = 0;
+    uint32_t *d_ann_bucket = nullptr;  // points before every bucket of 2 048 arena positions
+    uint64_t bucket_cap = 0, n_ann_entries = 0;
+    uint32_t *d_feat[2] = {nullptr, nullptr};  // same order as the hit tables
+    uint64_t feat_cap[2] = {0, 0};
+    bool have_track = false;
+    bool have_feat = false;  // d_feat belongs to the current tables (cleared by the next scan)
 };
 
 #define CRP_HIP(ctx, call)                                                              \

@@ -59,6 +59,7 @@ class Hits:
         self.pos_plus, self.pre_plus, self.score_plus = cols[0:3]
         self.pos_minus, self.pre_minus, self.score_minus = cols[3:6]
         self.ot_plus = self.ot_minus = None  # (n, 4) uint32 once an off-target scan has run
+        self.feat_plus = self.feat_minus = None  # uint32 label-set ids once the annotation join has run
         ends = offsets + lengths
         self._cut_plus = (np.searchsorted(self.pos_plus, offsets, "left"),
                           np.searchsorted(self.pos_plus, ends, "left"))
@@ -85,6 +86,8 @@ class Hits:
             score_minus=self.score_minus[c:d])
         if self.ot_plus is not None:  # off-target counts travel with the rows they belong to
             out["ot_plus"], out["ot_minus"] = self.ot_plus[a:b], self.ot_minus[c:d]
+        if self.feat_plus is not None:
+            out["feat_plus"], out["feat_minus"] = self.feat_plus[a:b], self.feat_minus[c:d]
         return out
 
 
@@ -160,6 +163,28 @@ class Arena:
         n = ctypes.c_uint64()
         nat.check(nat.lib().crp_count_scored(self._h, ctypes.byref(n)), "crp_count_scored", self._engine._ctx)
         return n.value
+
+    # ---- annotation join (opt-in; include/cropsr_hip.h)
+    def annotate_set_track(self, points, ids):
+        """The arena's track: strictly ascending arena positions and the label-set id each one opens
+        (annotate.Annotation.arena_track builds it)."""
+        points = np.ascontiguousarray(points, dtype=np.uint32)
+        ids = np.ascontiguousarray(ids, dtype=np.uint32)
+        if points.shape != ids.shape or points.ndim != 1:
+            raise ValueError("points and ids must be 1-d arrays of one length")
+        nat.check(nat.lib().crp_annotate_set_track(self._h, points.ctypes.data_as(nat.u32p), ids.ctypes.data_as(nat.u32p),
+                                                   points.size), "crp_annotate_set_track", self._engine._ctx)
+
+    def annotate_lookup(self, n_plus, n_minus, fetch=True):
+        """Label-set id per kept hit of the last scan (NO_FEATURE: none / no cut site), computed on the GPU from the
+        resident tables; fetch=False leaves them in HBM for gather_hits(features=True)."""
+        if not fetch:
+            nat.check(nat.lib().crp_annotate_lookup(self._h, None, None), "crp_annotate_lookup", self._engine._ctx)
+            return None
+        fp, fm = np.empty(n_plus, dtype=np.uint32), np.empty(n_minus, dtype=np.uint32)
+        nat.check(nat.lib().crp_annotate_lookup(self._h, fp.ctypes.data_as(nat.u32p), fm.ctypes.data_as(nat.u32p)),
+                  "crp_annotate_lookup", self._engine._ctx)
+        return fp, fm
 
     # ---- off-target seed scan (opt-in; include/cropsr_hip.h)
     def offtarget_add(self, guide_len=20, own_ranges=None):
@@ -419,19 +444,19 @@ class Engine:
                   "crp_comm_allreduce_f64", self._ctx)
         return list(a)
 
-    def gather_hits(self, arena, root=0, offtarget=False, pre=False):
+    def gather_hits(self, arena, root=0, offtarget=False, pre=False, features=False):
         """The gatherv of the path (crp_gather_hits): every rank's tables of `arena` (None: empty) into
         root's HBM.  pre=True: the f64 column is the pre-sigmoid sum instead of the score.  Returns
         the (world, 2) counts every rank contributed."""
         world = self.query()["comm_world"]
         counts = np.zeros((world, 2), dtype=np.uint64)
-        flags = (nat.GATHER_OFFTARGET if offtarget else 0) | (nat.GATHER_PRE if pre else 0)
+        flags = (nat.GATHER_OFFTARGET if offtarget else 0) | (nat.GATHER_PRE if pre else 0) | (nat.GATHER_FEATURES if features else 0)
         nat.check(nat.lib().crp_gather_hits(self._ctx, arena._h if arena is not None else None, int(root),
                                             flags, counts.ctypes.data_as(nat.u64p)),
                   "crp_gather_hits", self._ctx)
         return counts
 
-    def gathered_fetch(self, rank, counts, offtarget=False):
+    def gathered_fetch(self, rank, counts, offtarget=False, features=False):
         """Root: host copies of what `rank` contributed to the last gather_hits -> column dict."""
         n_plus, n_minus = int(counts[rank][0]), int(counts[rank][1])
         out = {"pos_plus": np.empty(n_plus, np.uint32), "score_plus": np.empty(n_plus, np.float64),
@@ -444,6 +469,11 @@ class Engine:
                                                ptr("ot_plus", nat.u32p), ptr("pos_minus", nat.u32p),
                                                ptr("score_minus", nat.f64p), ptr("ot_minus", nat.u32p)),
                   "crp_gathered_fetch", self._ctx)
+        if features:
+            out["feat_plus"], out["feat_minus"] = np.empty(n_plus, np.uint32), np.empty(n_minus, np.uint32)
+            nat.check(nat.lib().crp_gathered_fetch_features(self._ctx, int(rank), out["feat_plus"].ctypes.data_as(nat.u32p),
+                                                            out["feat_minus"].ctypes.data_as(nat.u32p)),
+                      "crp_gathered_fetch_features", self._ctx)
         return out
 
     # ---- off-target seed scan, engine-wide steps (per-arena steps: Arena.offtarget_*)
@@ -557,19 +587,33 @@ class Genome:
         if cur or not groups:
             groups.append(cur)
         self.arenas = [engine.arena([bufs[k] for k in g], pack=pack) for g in groups]
+        self.groups = groups  # contig indices per arena, in arena order
         self._where = {}
         for a, g in enumerate(groups):
             for j, k in enumerate(g):
                 self._where[k] = (a, j)
         self.n_contigs = len(bufs)
 
-    def scan_score(self, guide_len=20, want_pre=False, offtarget=False, seeds_from_scan=True):
+    def annotate(self, request, counts, fetch=True):
+        """The annotation join over every arena's resident tables (annotate.Request; counts: (n_plus, n_minus) per
+        arena).  Returns [(feat_plus, feat_minus)] per arena, or None with fetch=False."""
+        out = []
+        for a, g, (n_plus, n_minus) in zip(self.arenas, self.groups, counts):
+            a.annotate_set_track(*request.track([(k, int(a.offsets[j]), int(a.lengths[j])) for j, k in enumerate(g)]))
+            out.append(a.annotate_lookup(n_plus, n_minus, fetch=fetch))
+        return out if fetch else None
+
+    def scan_score(self, guide_len=20, want_pre=False, offtarget=False, seeds_from_scan=True, annotation=None):
         """Seam 1 + 2 for every contig.  offtarget=True also runs the genome-wide seed scan over all
         arenas (single process: no reduce) and attaches (n, 4) counts to every contig's hits;
         seeds_from_scan=False makes the off-target step derive its seeds from the planes itself (the
         path guide lengths other than 20 always take) instead of receiving them from the scan."""
         if not offtarget:
-            return GenomeHits(self, [a.scan_score(guide_len, want_pre) for a in self.arenas])
+            per_arena = [a.scan_score(guide_len, want_pre) for a in self.arenas]
+            if annotation is not None:  # (the tables of an arena stay valid until its next scan)
+                for h, f in zip(per_arena, self.annotate(annotation, [(h.n_plus, h.n_minus) for h in per_arena])):
+                    h.feat_plus, h.feat_minus = f
+            return GenomeHits(self, per_arena)
         eng = self._engine
         eng.offtarget_reset()
         counts, per_arena = [], []
@@ -583,6 +627,9 @@ class Genome:
             h = Hits(a.offsets, a.lengths, guide_len, a.fetch(n_plus, n_minus, want_pre))
             h.ot_plus, h.ot_minus = a.offtarget_counts(n_plus, n_minus)
             per_arena.append(h)
+        if annotation is not None:
+            for h, f in zip(per_arena, self.annotate(annotation, counts)):
+                h.feat_plus, h.feat_minus = f
         return GenomeHits(self, per_arena)
 
     def close(self):

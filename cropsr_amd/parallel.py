@@ -27,7 +27,8 @@ scan_resident(texts, guide_len, offtarget=False) -> Resident   (offtarget: the s
     .layout                          [(arena index, arena offset, length)] per text
     .offtarget(group, own_by_arena)  seed scan over all ranks' sites; own_by_arena: per arena the
                                      [begin, end) arena positions whose hits this rank owns
-    .gather(group, dst, offtarget)   on dst: per rank, per arena, a column dict (numpy; arena
+    .annotate(request)               annotation join over the resident tables (annotate.Request for this rank's texts)
+    .gather(group, dst, offtarget[, features])  on dst: per rank, per arena, a column dict (numpy; arena
                                      positions); None elsewhere
     .release()
 """
@@ -86,33 +87,33 @@ def stitch_pieces(piece_hits):
     [start, end) contains its match index (the regex match position of CROPSR.py:98-104)."""
     out = {}
     for strand in ("plus", "minus"):
-        cols = {c: [] for c in ("pos", "score", "pre", "ot")}
+        cols = {c: [] for c in ("pos", "score", "pre", "ot", "feat")}
         for start, end, shift, hits in piece_hits:
             pos = np.asarray(hits["pos_" + strand]).astype(np.int64) - shift + start  # contig coordinates
             own = (pos >= start) & (pos < end)
             cols["pos"].append(pos[own].astype(np.uint32))
             cols["score"].append(np.asarray(hits["score_" + strand])[own])
-            for extra in ("pre", "ot"):
+            for extra in ("pre", "ot", "feat"):
                 if hits.get(extra + "_" + strand) is not None:
                     cols[extra].append(np.asarray(hits[extra + "_" + strand])[own])
         out["pos_" + strand] = np.concatenate(cols["pos"]) if cols["pos"] else np.empty(0, np.uint32)
         out["score_" + strand] = np.concatenate(cols["score"]) if cols["score"] else np.empty(0)
-        for extra in ("pre", "ot"):
+        for extra in ("pre", "ot", "feat"):
             if cols[extra]:
                 out[extra + "_" + strand] = np.concatenate(cols[extra])
     return out
 
 
-def _table_keys(offtarget):
-    return COLUMNS + (("ot_plus", "ot_minus") if offtarget else ())
+def _table_keys(offtarget, features=False):
+    return COLUMNS + (("ot_plus", "ot_minus") if offtarget else ()) + (("feat_plus", "feat_minus") if features else ())
 
 
-def gather_host(group, arenas_cols, dst=0, offtarget=False):
+def gather_host(group, arenas_cols, dst=0, offtarget=False, features=False):
     """gatherv over the control sockets: arenas_cols = this rank's column dicts (numpy), one per
     arena.  Returns on dst [rank][arena] -> column dict, None elsewhere."""
     if dst != 0:
         raise ValueError("the host transport gathers to rank 0")
-    keys = _table_keys(offtarget)
+    keys = _table_keys(offtarget, features)
     n_arenas = group.all_gather(len(arenas_cols))
     if group.rank != dst:
         for cols in arenas_cols:
@@ -138,6 +139,8 @@ def slice_piece(cols, off, ln):
                pos_minus=pm[c:d] - np.uint32(off), score_minus=np.asarray(cols["score_minus"])[c:d])
     if "ot_plus" in cols:
         out["ot_plus"], out["ot_minus"] = np.asarray(cols["ot_plus"])[a:b], np.asarray(cols["ot_minus"])[c:d]
+    if "feat_plus" in cols:
+        out["feat_plus"], out["feat_minus"] = np.asarray(cols["feat_plus"])[a:b], np.asarray(cols["feat_minus"])[c:d]
     return out
 
 
@@ -153,7 +156,7 @@ def merge_gathered(gathered, layouts):
     return out
 
 
-def sharded_scan(backend, strings, guide_len, group, dst=0, max_piece=None, offtarget=False):
+def sharded_scan(backend, strings, guide_len, group, dst=0, max_piece=None, offtarget=False, annotation=None):
     """The scan of `strings` (the same list on every rank) spread over the ranks of `group`.
 
     Contigs are cut into pieces of at most a rank's fair share (cut_contigs), the pieces are dealt
@@ -162,6 +165,10 @@ def sharded_scan(backend, strings, guide_len, group, dst=0, max_piece=None, offt
     them to `dst`, where the pieces of each contig are stitched back.  Returns on `dst` what
     backend.scan(strings, guide_len) returns on one GPU -- a list of hit dicts, one per contig,
     bit for bit -- and None on the other ranks.
+
+    annotation (annotate.Request for `strings`, the same on every rank): every rank also joins ITS resident tables with
+    the annotation track of its pieces (Resident.annotate) and the label-set ids travel with the tables; the hit dicts
+    then carry feat_plus / feat_minus.
 
     A rank that fails before the exchange (a share that does not fit its GPU, a HIP error) reports
     it through group.check, so EVERY rank raises rendezvous.RankError with the same message
@@ -185,8 +192,11 @@ def sharded_scan(backend, strings, guide_len, group, dst=0, max_piece=None, offt
             for q, (v, shift), (a, off, _ln) in zip(mine, views, res.layout):
                 own[a].append((int(off) + shift, int(off) + shift + pieces[q][2] - pieces[q][1]))
             res.offtarget(group, [sorted(o) for o in own])
+        if annotation is not None:
+            # a piece's text starts `shift` characters before the piece (its halo): index of its first character
+            res.annotate(annotation.pieces([pieces[q][0] for q in mine], [pieces[q][1] - shift for q, (_, shift) in zip(mine, views)]))
         layouts = group.all_gather([(q, int(a), int(off), int(ln)) for q, (a, off, ln) in zip(mine, res.layout)])
-        gathered = res.gather(group, dst, offtarget)
+        gathered = res.gather(group, dst, offtarget, features=True) if annotation is not None else res.gather(group, dst, offtarget)
     finally:
         res.release()
     if rank != dst:

@@ -226,9 +226,12 @@ class ContigTable:
         self.guide_len = guide_len
         self.feat_blob = self.feat_off = self.feat_idx = None
         if features is not None:
-            enc = [t.encode("utf-8") for t in features[0]]
-            self.feat_blob = np.frombuffer(b"".join(enc) or b"\0", dtype=np.uint8)
-            self.feat_off = np.concatenate([[0], np.cumsum([len(e) for e in enc])]).astype(np.uint64)
+            if hasattr(features[0], "blob"):  # annotate.StringTable: already the form the writer takes (shared, not copied)
+                self.feat_blob, self.feat_off = features[0].blob, features[0].off
+            else:
+                enc = [t.encode("utf-8") for t in features[0]]
+                self.feat_blob = np.frombuffer(b"".join(enc) or b"\0", dtype=np.uint8)
+                self.feat_off = np.concatenate([[0], np.cumsum([len(e) for e in enc])]).astype(np.uint64)
             self.feat_idx = np.ascontiguousarray(features[1], dtype=np.uint32)
         self.ot = None
         if hits.get("ot_plus") is not None:

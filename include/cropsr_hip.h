@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define CRP_ABI_VERSION 3
+#define CRP_ABI_VERSION 4
 
 typedef enum crp_status {
     CRP_OK = 0,
@@ -260,11 +260,66 @@ int crp_comm_allreduce_f64(crp_ctx *ctx, double *values, int n, int op);
 /* CRP_GATHER_PRE: the f64 column that travels is the pre-sigmoid sum (crp_scan_score with want_pre)
  * instead of the score -- for a root that applies its own host's exp (cli --score-finalize=host). */
 #define CRP_GATHER_PRE 2
+/* CRP_GATHER_FEATURES: also gathers the per-hit label-set ids of the annotation join (crp_annotate_lookup must
+ * have run on `arena` since its last scan; else CRP_ERR_STATE, agreed on like the others). */
+#define CRP_GATHER_FEATURES 4
 int crp_gather_hits(crp_ctx *ctx, crp_arena *arena, int root, int flags, uint64_t *counts_all);
 /* Root only: copy the tables rank `rank` contributed to the last crp_gather_hits to host arrays
  * (sizes from counts_all; ot_*: 4 x uint32 per hit; any pointer may be NULL). */
 int crp_gathered_fetch(crp_ctx *ctx, int rank, uint32_t *pos_plus, double *score_plus, uint32_t *ot_plus,
                        uint32_t *pos_minus, double *score_minus, uint32_t *ot_minus);
+
+/* Root only, after a crp_gather_hits with CRP_GATHER_FEATURES: the ids rank `rank` contributed (uint32 per hit). */
+int crp_gathered_fetch_features(crp_ctx *ctx, int rank, uint32_t *feat_plus, uint32_t *feat_minus);
+
+/* ---- annotation join (opt-in; a no-op in the reference) -------------------- */
+/* BASELINE.json configs[2], [3] name a GFF and a Phytozome annotation_info file.  The reference parses the GFF
+ * (CROPSR.py:77-95, called at :375), drops the table and writes '' into `features` (:466, :468), so the join is
+ * this engine's own, opt-in, and the default CSV stays byte-identical (definition: cropsr_amd/annotate.py,
+ * DESIGN.md section 11; parity unpinned).  The host builds, per arena, a TRACK: strictly ascending arena positions
+ * points[k], each opening an elementary interval [points[k], points[k+1]) whose set of gene / CDS labels is
+ * constant and named by ids[k] (an index into the caller's string table, or CRP_NO_FEATURE for "none"; every
+ * contig starts with a point of its own, so nothing leaks from its predecessor).  The library keeps a copy in HBM
+ * together with a bucket index over the arena's positions. */
+#define CRP_NO_FEATURE 0xFFFFFFFFu
+/* Host side (no GPU needed).  GFF3 bytes (+ the bytes of a Phytozome annotation_info file, or NULL) as text mode hands
+ * them over -> the annotation: the distinct label-set strings and, per seqid, the elementary intervals of its gene /
+ * CDS rows.  The definition (which rows, which label, which order) is stated at the top of
+ * cropsr_amd/csrc/crp_annotation.cpp and restated as a brute-force loop in oracle/annotate_oracle.py. */
+typedef struct crp_annotation crp_annotation;
+int crp_annotation_build(const uint8_t *gff, uint64_t gff_len, const uint8_t *info_text, uint64_t info_len,
+                         crp_annotation **out);
+int crp_annotation_destroy(crp_annotation *annotation);
+/* Sizes: seqids with at least one gene / CDS row, distinct label-set strings, bytes of all strings, gene and CDS
+ * rows read (any pointer may be NULL). */
+int crp_annotation_stats(const crp_annotation *annotation, uint64_t *n_seqids, uint64_t *n_strings, uint64_t *blob_bytes,
+                         uint64_t *n_genes, uint64_t *n_cds);
+/* The string table in the form crp_write_rows_ex takes: blob (blob_bytes) and n_strings + 1 offsets. */
+int crp_annotation_strings(const crp_annotation *annotation, uint8_t *blob, uint64_t *offsets);
+/* Seqid k (order of first appearance in the GFF): its name and its intervals in 1-based genome coordinates --
+ * interval j = [points[j], points[j+1]) carries string ids[j] (CRP_NO_FEATURE: none).  The pointers stay valid
+ * until crp_annotation_destroy. */
+int crp_annotation_seqid(const crp_annotation *annotation, uint64_t k, const uint8_t **name, uint64_t *name_len,
+                         const int64_t **points, const uint32_t **ids, uint64_t *n_points);
+/* The track of one arena for crp_annotate_set_track.  entries: 4 x uint64 per text of the arena, in arena order --
+ * {seqid index (any value >= n_seqids: the text has no features), index of the text's first character inside its
+ * contig string (0 unless the text is a piece of a cut contig), length of the text, arena offset of the text}.
+ * dec: the contig strings start with `dec` decoration characters before the first base (1 in the reference's
+ * re-formatted path, 0 otherwise): string index = 1-based genome coordinate + dec - 1.
+ * Every text opens with a point of its own.  Returns CRP_ERR_CAPACITY with the needed size in *n_out when cap is
+ * too small (cap 0: sizing call). */
+int crp_annotation_track(const crp_annotation *annotation, const uint64_t *entries, uint64_t n_entries, int dec,
+                         uint32_t *points, uint32_t *ids, uint64_t cap, uint64_t *n_out);
+/* Device side. */
+int crp_annotate_set_track(crp_arena *arena, const uint32_t *points, const uint32_t *ids, uint64_t n_points);
+/* After crp_scan_score on `arena` (whose tables it reads where they lie): per kept hit the id of the interval its
+ * cut site falls in -- cut site = end_pos - 3 (CROPSR.py:155-158): i - 3 on the '+' table, j on the '-' table --
+ * or CRP_NO_FEATURE for a hit before the first point and for a row WITHOUT a cut site (long_sequence is not 30
+ * characters, CROPSR.py:466-468: exactly the rows whose score is -1).  One streaming pass over the position and
+ * score columns (12 B in, 4 B out per hit).  The ids stay in HBM for crp_gather_hits(CRP_GATHER_FEATURES) and
+ * are copied to feat_plus / feat_minus (n_plus / n_minus values, table order; either may be NULL); they are what
+ * crp_write_rows_ex takes as feat_idx. */
+int crp_annotate_lookup(crp_arena *arena, uint32_t *feat_plus, uint32_t *feat_minus);
 
 /* ---- off-target seed scan (opt-in; absent from the reference) ------------- */
 /* BASELINE.json configs[4]: genome-wide off-target <=3-mismatch seed scan.  The reference has no such
@@ -351,7 +406,8 @@ int crp_profile_read(crp_ctx *ctx, double ms[3], uint64_t launches[3], int reset
 #define CRP_K_OT_LOOKUP 5    /* off-target: per-hit counts */
 #define CRP_K_GATHER 6       /* RCCL gatherv of the hit tables (count all-gather + grouped send/recv) */
 #define CRP_K_OT_REDUCE 7    /* RCCL all-reduce of the site histogram */
-#define CRP_K_KINDS 8
+#define CRP_K_ANNOTATE 8     /* annotation join: both look-up launches of one crp_annotate_lookup */
+#define CRP_K_KINDS 9
 int crp_profile_read_kind(crp_ctx *ctx, int kind, double *ms, uint64_t *launches, int reset);
 /* Blocks until everything queued on the library's stream has finished. */
 int crp_synchronize(crp_ctx *ctx);

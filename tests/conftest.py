@@ -132,9 +132,21 @@ class OracleResident:
             np.add.at(total, i, v)
         self.cols["ot_plus"], self.cols["ot_minus"] = orc.offtarget_enum(sp, total), orc.offtarget_enum(sm, total)
 
-    def gather(self, group, dst, offtarget):
+    def annotate(self, request):
+        """The join by the oracle's numpy statement (oracle/annotate_oracle.host_join), text by text."""
+        import numpy as np
+        from oracle import annotate_oracle
+        fp, fm = [], []
+        for k, (t, h) in enumerate(zip(self.texts, self.hits)):
+            a, b = annotate_oracle.host_join(request.annotation, request.names[k], request.starts[k], request.dec, h, self.l, len(t))
+            fp.append(a)
+            fm.append(b)
+        cat = lambda xs: np.concatenate(xs) if xs else np.empty(0, np.uint32)
+        self.cols["feat_plus"], self.cols["feat_minus"] = cat(fp), cat(fm)
+
+    def gather(self, group, dst, offtarget, features=False):
         from cropsr_amd import parallel
-        return parallel.gather_host(group, [self.cols], dst, offtarget)
+        return parallel.gather_host(group, [self.cols], dst, offtarget, features)
 
     def release(self):
         pass
@@ -151,9 +163,14 @@ class OracleBackend:
         from cropsr_amd import cli
         return cli.host_sigmoid(pre)
 
-    def scan(self, strings, l, offtarget=False):
+    def scan(self, strings, l, offtarget=False, annotation=None):
         texts = [s.encode("ascii", "replace") if isinstance(s, str) else bytes(s) for s in strings]
         out = [self.orc.scan_score(t, l) for t in texts]
+        if annotation is not None:  # in place of the GPU look-up: the oracle's numpy statement of it
+            from oracle import annotate_oracle
+            for k, (t, h) in enumerate(zip(texts, out)):
+                h["feat_plus"], h["feat_minus"] = annotate_oracle.host_join(
+                    annotation.annotation, annotation.names[k], annotation.starts[k], annotation.dec, h, l, len(t))
         if self.finalize == "host":
             for h in out:
                 h["score_plus"], h["score_minus"] = self._sigmoid(h["pre_plus"]), self._sigmoid(h["pre_minus"])

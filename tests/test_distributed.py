@@ -272,6 +272,41 @@ def test_cli_multi_process_offtarget_equals_single_process(tmp_path, monkeypatch
     assert b"offtarget_seed_mm3\r\n" in want.split(b"\r\n", 1)[0] + b"\r\n"
 
 
+def test_cli_multi_process_annotate_equals_single_process_and_brute_force(tmp_path, monkeypatch, oracle, manifest):
+    """--annotate through the sharded flow (pieces of 100 characters with their halos over 3 ranks; every rank joins its
+    own pieces with the track of THOSE pieces and the label-set ids travel with the tables): the bytes of one process,
+    and the `features` column of every row equals the brute-force loop over the GFF (oracle/annotate_oracle.py)."""
+    import csv
+    import io
+    from conftest import GOLDEN, OracleBackend, run_cli
+    from oracle import annotate_oracle
+    gff = tmp_path / "mixed.gff"
+    gff.write_text("##gff-version 3\n"
+                   "mix\tsrc\tgene\t40\t410\t.\t+\t.\tID=g1;Name=L1\n"      # spans four cuts
+                   "mix\tsrc\tCDS\t95\t105\t.\t+\t0\tID=g1.cds1\n"        # straddles the first cut
+                   "mix\tsrc\tCDS\t200\t200\t.\t+\t0\tID=g1.cds2\n"       # one base, on a cut
+                   "mix\tsrc\tgene\t400\t1123\t.\t-\t.\tID=g2\n"
+                   "mix\tsrc\tCDS\t1100\t2000\t.\t-\t0\tParent=g2\n"      # runs past the contig's end
+                   "tail\tsrc\tgene\t1\t60\t.\t+\t.\tID=t1\n")
+    info = tmp_path / "info.txt"
+    info.write_text("1\tL1\tx\ty\t\t\t\t\t\t\tAT1G1.1\tsym\ta defline\n")
+    extra = ("-g", str(gff), "-p", str(info), "--annotate")
+    assert _spawn(_cli_worker, 3, "mixed", 100, str(tmp_path), extra) == [0, 0, 0]
+    single = tmp_path / "single"
+    single.mkdir()
+    want, _ = run_cli(single, monkeypatch, os.path.join(GOLDEN, "probe_mixed.fa"), OracleBackend(oracle), manifest["seed"], extra=extra)
+    with open(tmp_path / "rank0" / "out.csv", "rb") as f:
+        got = f.read()
+    assert got == want
+    rows = list(csv.reader(io.StringIO(got.decode("latin-1"), newline="")))[1:]
+    brute = annotate_oracle.features_of_rows([[c if i != 10 else "" for i, c in enumerate(r)] for r in rows],
+                                             lambda chrom: chrom.strip("[(',"), 1, str(gff), annotate_oracle.parse_info(str(info)))
+    assert [r[10] for r in rows if len(r) == 12] == [w for r, w in zip(rows, brute) if len(r) == 12]
+    labels = set(r[10] for r in rows if len(r) == 12)
+    assert "gene:g1|AT1G1.1|a defline;CDS:g1.cds1" in labels and "gene:g1|AT1G1.1|a defline;gene:g2" in labels
+    assert "gene:g2;CDS:g2" in labels and "gene:t1" in labels and "" in labels
+
+
 def _dying_worker(rank, world, port, out_dir):
     group = _group(rank, world, port)
     if rank == 1:

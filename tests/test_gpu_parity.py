@@ -719,9 +719,21 @@ def _rccl_world1(out_path, port):
     eng.offtarget_reduce()
     eng.offtarget_solve()
     ot = arena.offtarget_counts(n_plus, n_minus)
+    # the annotation join's ids travel as one more column (CRP_GATHER_FEATURES); without a look-up the flag is a
+    # state error every rank agrees on, and the communicator stays usable
+    try:
+        eng.gather_hits(arena, 0, features=True)
+        ok = False
+    except Exception as e:
+        ok = ok and getattr(e, "status", 0) == -5
+    arena.annotate_set_track(np.array([int(arena.offsets[0]), int(arena.offsets[0]) + 700, int(arena.offsets[1])], np.uint32),
+                             np.array([7, 0xFFFFFFFF, 9], np.uint32))
+    feat = arena.annotate_lookup(n_plus, n_minus)
     for _ in range(2):
-        counts = eng.gather_hits(arena, 0, offtarget=True)
-        got = eng.gathered_fetch(0, counts, offtarget=True)
+        counts = eng.gather_hits(arena, 0, offtarget=True, features=True)
+        got = eng.gathered_fetch(0, counts, offtarget=True, features=True)
+    ok = ok and (got["feat_plus"] == feat[0]).all() and (got["feat_minus"] == feat[1]).all()
+    ok = ok and set(np.unique(feat[0]).tolist()) == {7, 9, 0xFFFFFFFF}
     cols = arena.fetch(n_plus, n_minus)
     ok = ok and counts.tolist() == [[n_plus, n_minus]]
     ok = ok and (got["pos_plus"] == cols[0]).all() and (got["pos_minus"] == cols[3]).all()
