@@ -130,6 +130,7 @@ class EngineResident:
         """The annotation join over this rank's resident tables (annotate.Request for ITS texts); the ids stay in HBM
         and travel with the tables in gather()."""
         self.genome.annotate(request, self.counts, fetch=False)
+        self.backend.last_annotate_s = self.genome.annotate_s
         self._annotated = True
 
     def offtarget(self, group, own_by_arena):
@@ -210,6 +211,7 @@ class EngineBackend:
         # rccl: the tables cross xGMI inside the library; host: every rank copies its tables over its
         # own PCIe link and the control sockets carry them (ranks sharing one GPU, where RCCL cannot run)
         self.transport = os.environ.get("CROPSR_GATHER", "rccl")
+        self.last_annotate_s = None  # --bench-json: seconds the last annotation join took on this rank
 
     def connect(self):
         """Collective over the group: create the RCCL communicator (transport "rccl")."""
@@ -240,6 +242,7 @@ class EngineBackend:
         genome = self.engine.genome(contig_strings)  # as many arenas as the genome needs
         hits = genome.scan_score(guide_len, want_pre=self.finalize == "host", offtarget=offtarget, annotation=annotation)
         out = [self._finalize(hits.contig(k)) for k in range(len(contig_strings))]
+        self.last_annotate_s = genome.annotate_s
         genome.close()
         return out
 
@@ -375,7 +378,14 @@ def run(args, backend=None, out=sys.stdout, group=None):
     early = _Early(make_backend) if backend is None else None
     # --annotate: the GFF (+ annotation_info) is parsed natively (crp_annotation_build releases the GIL) beside the FASTA read
     annotating = bool(getattr(args, "annotate", False))
-    early_annot = _Early(lambda: __import__(__package__ + ".annotate", fromlist=["Annotation"]).Annotation(args.g, args.p)) if annotating else None
+    def build_annotation():
+        from . import annotate
+        t0 = time.perf_counter()
+        a = annotate.Annotation(args.g, args.p)
+        stages["annotation_build_s"] = time.perf_counter() - t0  # (on its own thread, beside the FASTA read and the GPU start-up)
+        return a
+
+    early_annot = _Early(build_annotation) if annotating else None
 
     def annotation_request(data, table):
         """annotate.Request for the contig strings of `table` (every rank builds the same one)."""
@@ -430,8 +440,20 @@ def run(args, backend=None, out=sys.stdout, group=None):
         """, file=out)
 
     timing = open("time.txt", "w")  # CROPSR.py:371 (CWD side effect, kept)
-    # import_gff_file below imports pandas like the reference does (0.2 s): start that now, beside the FASTA read
-    _Early(lambda: __import__("pandas"))
+    # CROPSR.py:375 reads the GFF into a DataFrame it never uses (pandas: 0.2 s to import, ~1 s per 40 MB of GFF).  Its
+    # observable behaviour -- two -v messages, the exceptions of a missing or malformed file -- is kept, at the place the
+    # reference has it; the work itself starts NOW on a helper thread, beside the FASTA read and the scan
+    import io as _io
+    gff_messages = _io.StringIO()
+
+    def reference_gff_import():
+        t0 = time.perf_counter()
+        try:
+            return import_gff_file(args.g, verbose, gff_messages)
+        finally:
+            stages["reference_gff_import_s"] = time.perf_counter() - t0  # (thread time; what the run waits for: ..._wait_s)
+
+    early_gff = _Early(reference_gff_import)
 
     # CROPSR.py:374, 54-74 -- read as text mode would (universal newlines), kept as bytes
     t_stage = time.perf_counter()
@@ -452,7 +474,12 @@ def run(args, backend=None, out=sys.stdout, group=None):
     stages["read_fasta_s"] = time.perf_counter() - t_stage
     if verbose:
         print("The genome was successfully converted to a dictionary", file=out)
-    import_gff_file(args.g, verbose, out)  # CROPSR.py:375 (raises like the reference if -g is missing)
+    t_wait = time.perf_counter()
+    try:
+        early_gff.get()  # CROPSR.py:375 (raises like the reference if -g is missing or unreadable)
+    finally:
+        out.write(gff_messages.getvalue())
+        stages["reference_gff_import_wait_s"] = time.perf_counter() - t_wait
 
     if verbose:
         # (the blank line in the middle carries the reference's 12 blanks of indentation)
@@ -502,6 +529,9 @@ def run(args, backend=None, out=sys.stdout, group=None):
         group.close()
         group = None
     stages["upload_scan_fetch_s"] = time.perf_counter() - t_stage
+    if request is not None:
+        stages["annotation_join_s"] = getattr(backend, "last_annotate_s", None)  # part of upload_scan_fetch_s (this rank's share)
+        stages["annotation_strings"] = len(request.annotation.strings)
 
     # (the native formatter's row buffers are sized for guide lengths 1..50; other lengths take the csv module)
     native = getattr(args, "csv_writer", "native") == "native" and NATIVE_GUIDE_LENGTHS[0] <= args.l <= NATIVE_GUIDE_LENGTHS[1]

@@ -588,6 +588,7 @@ class Genome:
             groups.append(cur)
         self.arenas = [engine.arena([bufs[k] for k in g], pack=pack) for g in groups]
         self.groups = groups  # contig indices per arena, in arena order
+        self.annotate_s = None
         self._where = {}
         for a, g in enumerate(groups):
             for j, k in enumerate(g):
@@ -597,10 +598,13 @@ class Genome:
     def annotate(self, request, counts, fetch=True):
         """The annotation join over every arena's resident tables (annotate.Request; counts: (n_plus, n_minus) per
         arena).  Returns [(feat_plus, feat_minus)] per arena, or None with fetch=False."""
+        import time
+        t0 = time.perf_counter()
         out = []
         for a, g, (n_plus, n_minus) in zip(self.arenas, self.groups, counts):
             a.annotate_set_track(*request.track([(k, int(a.offsets[j]), int(a.lengths[j])) for j, k in enumerate(g)]))
             out.append(a.annotate_lookup(n_plus, n_minus, fetch=fetch))
+        self.annotate_s = time.perf_counter() - t0  # track lay-out + upload + look-up (+ the copy of the ids to the host)
         return out if fetch else None
 
     def scan_score(self, guide_len=20, want_pre=False, offtarget=False, seeds_from_scan=True, annotation=None):

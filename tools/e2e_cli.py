@@ -1,6 +1,6 @@
 """End-to-end timing of `python -m cropsr_amd` on a synthetic genome written as FASTA.
 
-usage: python tools/e2e_cli.py {ecoli|tair10|switchgrass[:scale]} [--reference-behaviour] [--profile]
+usage: python tools/e2e_cli.py {ecoli|tair10|sorghum|switchgrass[:scale]} [--reference-behaviour] [--profile] [--annotate N_GENES]
 Writes the FASTA and the CSV under $TMPDIR (default /tmp), prints one JSON line.
 """
 import argparse
@@ -55,10 +55,13 @@ def main():
                          "one sequential MT19937 stream the reference's ids come from")
     ap.add_argument("--cli-flag", action="append", default=[], metavar="FLAG",
                     help="extra flag for the CLI, e.g. --cli-flag=--offtarget (repeatable)")
+    ap.add_argument("--annotate", type=int, default=0, metavar="N_GENES",
+                    help="write a seeded synthetic Phytozome-style GFF3 with that many gene models and an annotation_info "
+                         "file (bench_workload.synthetic_annotation) and run the CLI with -g / -p / --annotate")
     a = ap.parse_args()
     import bench_workload as bw
     name, _, scale = a.workload.partition(":")
-    wl = {"ecoli": bw.ecoli_like, "tair10": bw.tair10_like}.get(name)
+    wl = {"ecoli": bw.ecoli_like, "tair10": bw.tair10_like, "sorghum": bw.sorghum_like}.get(name)
     wl = wl() if wl else bw.switchgrass_like(scale=float(scale or 1.0))
     tmp = os.environ.get("TMPDIR", "/tmp")
     fa = os.path.join(tmp, "e2e_%s.fa" % wl.name)
@@ -66,10 +69,17 @@ def main():
     out_csv = a.out or os.path.join(tmp, "e2e_out.csv")
     t0 = time.time()
     write_fasta(wl, fa)
-    with open(gff, "w") as f:
-        f.write("##gff-version 3\n")
+    gff_rows = None
+    extra = []
+    if a.annotate:
+        info = os.path.join(tmp, "e2e_annotation_info.txt")
+        gff_rows = bw.synthetic_annotation(wl, gff, info, n_genes=a.annotate)
+        extra = ["-p", info, "--annotate"]
+    else:
+        with open(gff, "w") as f:
+            f.write("##gff-version 3\n")
     t_gen = time.time() - t0
-    argv = ["-f", fa, "-g", gff, "-o", out_csv, "--cas9", "--seed", "1"]
+    argv = ["-f", fa, "-g", gff, "-o", out_csv, "--cas9", "--seed", "1"] + extra
     if not a.reference_behaviour:
         argv.append("--each-contig-once")
     argv += a.cli_flag
@@ -85,7 +95,7 @@ def main():
             sys.exit(p.stderr[-3000:])
         size = os.path.getsize(out_csv)
         print(json.dumps({"workload": wl.name, "procs": a.procs, "csv_bytes": size, "wall_incl_process_start_s": round(wall, 3),
-                          "md5": file_md5(out_csv) if a.md5 else None}))
+                          "gff_gene_cds_rows": gff_rows, "md5": file_md5(out_csv) if a.md5 else None}))
         os.remove(out_csv)
         os.remove(fa)
         return
@@ -111,7 +121,8 @@ def main():
         rows = sum(chunk.count(b"\n") for chunk in iter(lambda: f.read(1 << 24), b"")) - 1
     print(json.dumps({"workload": wl.name, "bases": wl.n_bases, "rows": rows, "csv_bytes": size,
                       "fasta_write_s": round(t_gen, 2), "cli_wall_s": round(wall, 3),
-                      "rows_per_s": round(rows / wall), "phases": json.load(open(stages_json)),
+                      "rows_per_s": round(rows / wall), "phases": json.load(open(stages_json)), "gff_gene_cds_rows": gff_rows,
+                      "gff_bytes": os.path.getsize(gff),
                       "md5": file_md5(out_csv) if a.md5 else None}))
     if prof:
         s = io.StringIO()
