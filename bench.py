@@ -72,8 +72,15 @@ def parse_args():
     ap.add_argument("--collective-timeout", type=float, default=300.0,
                     help="N > 1: rank 0 prints the line with the timed steps' numbers and aborts the run if the final gatherv "
                          "or the off-target block does not return within this many seconds (0 = wait for ever)")
-    ap.add_argument("--launch-timeout", type=float, default=1500.0,
-                    help="--gpus N without a launcher: stop the self-started ranks after this many seconds")
+    ap.add_argument("--launch-timeout", type=float, default=900.0,
+                    help="--gpus N without a launcher: stop the self-started ranks after this many seconds (kept well below "
+                         "a 1500 s step time-out of whoever runs the bench, so that the launcher's own 124 path comes first)")
+    ap.add_argument("--no-strong", action="store_true",
+                    help="N > 1: skip the strong-scaling block (ONE genome cut over the N ranks, BASELINE.json configs[3], [4])")
+    ap.add_argument("--strong-steps", type=int, default=0, help="timed steps of the strong-scaling block (0 = --steps)")
+    ap.add_argument("--no-strong-check", action="store_true",
+                    help="strong-scaling block: skip rank 0's N = 1 scan of the whole genome (the efficiency's denominator and "
+                         "the digest the stitched tables are compared with)")
     ap.add_argument("--offtarget-steps", type=int, default=5,
                     help="timed steps of the off-target seed scan (0 = skip that block)")
     ap.add_argument("--offtarget-seeds-from-planes", action="store_true",
@@ -159,6 +166,158 @@ def load_profile_facts(build_id, workload):
     if tj.get("build_id") != build_id:
         return None, "profiles/traffic.json was measured on build %s, this is %s: stale, not used" % (tj.get("build_id"), build_id)
     return tj, tj.get("source", "profiles/traffic.json")
+
+
+def table_digests(per_contig):
+    """sha256 over (positions, score bits) per strand of every contig's tables: one hex string per contig."""
+    import hashlib
+    import numpy as np
+    out = []
+    for h in per_contig:
+        d = hashlib.sha256()
+        for key in ("pos_plus", "score_plus", "pos_minus", "score_minus"):
+            d.update(np.ascontiguousarray(h[key]).tobytes())
+        out.append(d.hexdigest())
+    return out
+
+
+def strong_scaling_block(args, eng, group, use_rccl, fence, reduce):
+    """BASELINE.json configs[3], [4] as written: ONE genome over the N GPUs of the node ("per-chromosome shard across
+    8 x MI355X + RCCL gatherv").  The reference's contig loop (CROPSR.py:409) is what shards: parallel.strong_plan cuts
+    every contig longer than a rank's fair share into pieces (128 characters of halo either side, hits owned by match
+    position) and deals the pieces by LPT; every rank scans ITS share (no collective), then the one exchange of the path,
+    crp_gather_hits, brings the tables to rank 0, which stitches them.  Timed: the scan (max over ranks) and the exchange,
+    each fenced on both sides.  Rank 0 also scans the WHOLE genome alone (the N = 1 time the efficiency is quoted against)
+    and compares the digest of its stitched tables with the digest of those N = 1 tables, contig by contig."""
+    import numpy as np
+    from cropsr_amd import parallel
+    from cropsr_amd.engine import Hits
+    rank, world = group.rank, group.world
+    steps = args.strong_steps or args.steps
+    check = not args.no_strong_check
+    wl = make_workload(args.workload, 0, args.scale)
+    lengths = [s.length + 4 for s in wl.specs]
+    plan = parallel.strong_plan(lengths, world)
+    pieces, mine = plan["pieces"], plan["by_rank"][rank]
+    wanted = {}
+    for q in mine:
+        wanted.setdefault(pieces[q][0], []).append(q)
+    ref_builder = eng.arena_builder(lengths) if (rank == 0 and check) else None
+    t_gen = time.perf_counter()
+    views = {}
+    for k in (range(len(lengths)) if ref_builder is not None else sorted(wanted)):
+        s = wl.contig_string(k)
+        if ref_builder is not None:
+            ref_builder.add(s)
+        for q in wanted.get(k, ()):
+            v, shift = parallel.piece_view(s, pieces[q][1], pieces[q][2])
+            views[q] = (np.array(v, dtype=np.uint8, copy=True), shift)  # (a copy: the contig itself is released)
+        del s
+    builder = eng.arena_builder([views[q][0].size for q in mine])
+    for q in mine:
+        builder.add(views[q][0])
+    arena = builder.seal()
+    layout = [(q, 0, int(arena.offsets[j]), int(arena.lengths[j])) for j, q in enumerate(mine)]
+    shifts = {q: views[q][1] for q in mine}
+    del views
+    t_gen = time.perf_counter() - t_gen
+
+    def gatherv(n_plus, n_minus):
+        if use_rccl:
+            counts = eng.gather_hits(arena, 0)
+            return [[eng.gathered_fetch(r, counts)] for r in range(world)] if rank == 0 else None
+        cols = arena.fetch(n_plus, n_minus)
+        return parallel.gather_host(group, [dict(zip(parallel.COLUMNS, (cols[0], cols[2], cols[3], cols[5])))], 0)
+
+    n_plus, n_minus = arena.scan_score_device(20)
+    scored = arena.count_scored()
+    t_pre = time.perf_counter()
+    n_warm = max(1, args.warmup)
+    for _ in range(n_warm):
+        arena.scan_score_device(20)
+    spent = time.perf_counter() - t_pre
+    extra = int(reduce([max(0.0, args.preheat_ms * 1e-3 - spent) / max(spent / n_warm, 1e-6)], "max")[0] + 0.999)
+    for _ in range(extra):
+        arena.scan_score_device(20)
+    eng.profile(1)
+    eng.profile_read(reset=True)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        arena.scan_score_device(20)
+    fence()
+    dt_scan = reduce([time.perf_counter() - t0], "max")[0] / steps
+    emit = eng.profile_read(reset=True)["emit_score"]
+    eng.profile(0)
+    mine_report = {"rank": rank, "pieces": len(mine), "bases": int(sum(pieces[q][2] - pieces[q][1] for q in mine)),
+                   "characters_with_halos": int(arena.stats()["n_chars"]), "tiles": int(-(-arena.stats()["n_words"] // 1024)),
+                   "kept_hits": int(n_plus + n_minus), "kernel_ms": emit["ms"] / max(1, emit["launches"])}
+    per_rank = group.all_gather(mine_report)
+    layouts = group.all_gather(layout)
+    gatherv(n_plus, n_minus)  # warm-up: RCCL sets up its point-to-point channels
+    fence()
+    tg = time.perf_counter()
+    gathered = gatherv(n_plus, n_minus)
+    fence()
+    dt_gather = reduce([time.perf_counter() - tg], "max")[0]
+    hits_all, scored_all = reduce([n_plus + n_minus, scored], "sum")
+    out = {"workload": wl.name, "scaling": "strong", "genomes": 1, "steps": steps, "pieces": len(pieces),
+           "contigs_cut": int(sum(1 for k in range(len(lengths)) if sum(1 for p in pieces if p[0] == k) > 1)),
+           "halo": parallel.HALO, "ms_scan_max_rank": dt_scan * 1e3, "ms_gatherv": dt_gather * 1e3,
+           "gatherv_transport": "RCCL (in-library)" if use_rccl else "host-socket",
+           "value": None, "unit": "gRNAs/s", "per_rank": per_rank, "setup_s": t_gen}
+    # an owned hit is a hit of the whole contig; halo hits are counted by their owner only -- the unit is taken from the
+    # stitched tables when the check runs, else from the sum over ranks minus nothing (halo hits are < 0.001 % of it)
+    out["kept_hits_all_ranks_incl_halos"] = int(hits_all)
+    out["value_scan_only"] = scored_all / dt_scan
+    out["value"] = scored_all / (dt_scan + dt_gather)
+    if rank == 0:
+        per_piece = parallel.merge_gathered(gathered, layouts)
+        stitched, q = [], 0
+        for k in range(len(lengths)):
+            parts = []
+            while q < len(pieces) and pieces[q][0] == k:
+                _, start, end = pieces[q]
+                parts.append((start, end, start - max(0, start - parallel.HALO), per_piece[q]))
+                q += 1
+            stitched.append(parallel.stitch_pieces(parts))
+        out["kept_hits"] = int(sum(h["pos_plus"].size + h["pos_minus"].size for h in stitched))
+        n_scored = int(sum((h["score_plus"] != -1).sum() + (h["score_minus"] != -1).sum() for h in stitched))
+        out["gRNAs_scored"] = n_scored
+        out["value_scan_only"] = n_scored / dt_scan
+        out["value"] = n_scored / (dt_scan + dt_gather)
+        del gathered, per_piece
+    if check:
+        # the N = 1 scan of the same genome on rank 0's GPU (the other ranks wait at the fence)
+        t1 = None
+        if rank == 0:
+            ref = ref_builder.seal()
+            rp, rm = ref.scan_score_device(20)
+            for _ in range(n_warm + extra):
+                ref.scan_score_device(20)
+            eng.profile(1)
+            eng.profile_read(reset=True)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                ref.scan_score_device(20)
+            t1 = (time.perf_counter() - t0) / steps
+            e1 = eng.profile_read(reset=True)["emit_score"]
+            eng.profile(0)
+            whole = Hits(ref.offsets, ref.lengths, 20, ref.fetch(rp, rm))
+            want = table_digests([whole.contig(k) for k in range(len(lengths))])
+            got = table_digests(stitched)
+            bad = [k for k in range(len(lengths)) if want[k] != got[k]]
+            out["n1"] = {"ms_scan": t1 * 1e3, "kernel_ms": e1["ms"] / max(1, e1["launches"]), "kept_hits": int(rp + rm)}
+            out["digest_ok"] = not bad
+            if bad:
+                out["digest_mismatch_contigs"] = bad[:10]
+            out["speedup_vs_n1"] = t1 / (dt_scan + dt_gather)
+            out["efficiency_vs_n1"] = t1 / (dt_scan + dt_gather) / world
+            out["efficiency_vs_n1_scan_only"] = t1 / dt_scan / world
+            ref.close()
+        fence()
+    arena.close()
+    return out
 
 
 def main():
@@ -323,7 +482,7 @@ def main():
     build_id = nat.lib().crp_build_id().decode()
     n_chars = arena.stats()["n_chars"]
 
-    def build_line(gather_info, ot):
+    def build_line(gather_info, ot, strong=None):
         hits = n_plus + n_minus
         algo_bytes = (n_chars + 3) // 4 + 2 * ((n_chars + 7) // 8) + 12 * hits  # SURVEY.md 8d, rank 0's launch
         emit = prof["emit_score"]
@@ -373,6 +532,8 @@ def main():
         }
         if rccl_error:
             line["rccl_error"] = rccl_error
+        if strong is not None:
+            line["strong"] = strong
         if ot is not None:
             if facts and "roofline" in ot:
                 # counter traffic exists for the ball passes only (streaming reads, where the gfx950 FETCH_SIZE correction
@@ -399,6 +560,7 @@ def main():
     # even if the node's RCCL cannot complete a point-to-point exchange.
     import threading
     watch = {"stage": None, "timer": None, "lock": threading.Lock(), "fired": False}
+    gather_info = strong = None  # (what the watchdog prints for the stages that have not run yet)
 
     def _timed_out():
         with watch["lock"]:  # the collective may return at the very moment the timer fires: one of the two prints
@@ -408,9 +570,10 @@ def main():
         stage = watch["stage"]
         why = "%s did not return within %.0f s" % (stage, args.collective_timeout)
         gi = {"error": why} if stage == "final gatherv" else gather_info
-        oi = {"error": why} if stage != "final gatherv" else None
+        si = {"error": why} if stage == "strong-scaling block" else strong
+        oi = {"error": why} if stage.startswith("off-target") else None
         try:
-            print(json.dumps(build_line(gi, oi)), flush=True)
+            print(json.dumps(build_line(gi, oi, si)), flush=True)
         finally:
             group.abort("bench: " + why)
 
@@ -445,6 +608,19 @@ def main():
             gather_info = {"s": tg}  # rank 0 finishes last: it waits for every receive
         except Exception as e:  # the bench line is printed even if the exchange fails on this node
             gather_info = {"error": repr(e)[:300]}
+        unguard()
+
+    # ---- strong scaling: ONE genome over the N ranks (the headline above stays weak scaling)
+    if world > 1 and not args.no_strong and not (gather_info and "error" in gather_info):
+        guard("strong-scaling block")
+        try:
+            strong = strong_scaling_block(args, eng, group, use_rccl, fence, reduce)
+        except rendezvous.RankError:
+            raise
+        except Exception as e:
+            import traceback
+            traceback.print_exc()
+            strong = {"error": repr(e)[:300]}
         unguard()
 
     # ---- the opt-in off-target seed scan of cfg 5 on the same resident genome and hit tables
@@ -529,7 +705,7 @@ def main():
         unguard()
 
     if rank == 0:
-        line = build_line(gather_info, ot)
+        line = build_line(gather_info, ot, strong)
         if world == 1 and args.cpu_sample_bases > 0:
             from oracle import oracle as _o
             _o.lib()
@@ -537,7 +713,8 @@ def main():
             line["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
         print(json.dumps(line), flush=True)
 
-    failed = bool(gather_info and "error" in gather_info) or bool(ot and "error" in ot)
+    failed = (bool(gather_info and "error" in gather_info) or bool(ot and "error" in ot) or
+              bool(strong and ("error" in strong or strong.get("digest_ok") is False)))
     if failed:
         # the communicator is in an unknown state after a failed exchange: no collective teardown,
         # and the run must not be recorded as a clean success

@@ -323,11 +323,15 @@ def refilter_hits(hits, n, l):
 class _Early:
     """fn() on a helper thread; get() joins and returns its result or raises what it raised."""
 
-    def __init__(self, fn):
+    def __init__(self, fn, start=True):
+        """start=False: nothing runs ahead; get() calls fn itself (for work that is only worth starting when the
+        cheap checks of the command line have passed)."""
         import threading
         self._out = []
-        self._thread = threading.Thread(target=self._run, args=(fn,), name="cropsr-open-gpu")
-        self._thread.start()
+        self._fn = fn
+        self._thread = threading.Thread(target=self._run, args=(fn,), name="cropsr-early") if start else None
+        if start:
+            self._thread.start()
 
     def _run(self, fn):
         try:
@@ -336,7 +340,11 @@ class _Early:
             self._out.append((None, e))
 
     def get(self):
-        self._thread.join()
+        if self._thread is None:
+            if not self._out:
+                self._run(self._fn)
+        else:
+            self._thread.join()
         value, error = self._out[0]
         if error is not None:
             raise error
@@ -375,7 +383,9 @@ def run(args, backend=None, out=sys.stdout, group=None):
 
     # Opening the GPU (HIP start-up, code object, two pinned staging buffers: ~0.3 s) starts NOW on a helper thread and
     # is collected where the backend is first needed: it overlaps reading and parsing the FASTA.
-    early = _Early(make_backend) if backend is None else None
+    # (not for a FASTA that is not there: that run ends with the reference's own exception and needs no GPU)
+    readable = isinstance(args.f, str) and os.path.isfile(args.f)
+    early = _Early(make_backend, start=readable) if backend is None else None
     # --annotate: the GFF (+ annotation_info) is parsed natively (crp_annotation_build releases the GIL) beside the FASTA read
     annotating = bool(getattr(args, "annotate", False))
     def build_annotation():
@@ -385,7 +395,7 @@ def run(args, backend=None, out=sys.stdout, group=None):
         stages["annotation_build_s"] = time.perf_counter() - t0  # (on its own thread, beside the FASTA read and the GPU start-up)
         return a
 
-    early_annot = _Early(build_annotation) if annotating else None
+    early_annot = _Early(build_annotation, start=readable) if annotating else None
 
     def annotation_request(data, table):
         """annotate.Request for the contig strings of `table` (every rank builds the same one)."""
@@ -593,33 +603,54 @@ def run(args, backend=None, out=sys.stdout, group=None):
             f.write("\n")
 
 
+def _leave(status):
+    """The one way out of main() for a process that opened the GPU: if a communicator bootstrap never returned
+    (Engine.comm_init), a helper thread still sits inside RCCL and the runtime's tear-down at a normal exit may wait for
+    it -- flush and leave through os._exit, on the error paths too."""
+    eng_mod = sys.modules.get(__package__ + ".engine")  # (only a run that opened the GPU has imported it)
+    if eng_mod is not None:
+        eng_mod.leave_if_comm_stuck(status)
+
+
 def main(argv=None):
+    import os
     args = build_parser().parse_args(argv)
     from . import launch
     if launch.wanted(getattr(args, "gpus", 1)):
         # no launcher in the environment: this process (which never touches the GPU) starts the ranks as fresh
         # children of the same command line and leaves with their status (cropsr_amd/launch.py)
+        if getattr(args, "device", None) is not None and os.environ.get("CROPSR_GATHER", "rccl") != "host":
+            # every rank would open the same GPU, RCCL would refuse the duplicate device after a whole bootstrap round
+            # and the run would crawl on over the host transport without a word
+            sys.exit("cropsr_amd: --device names ONE GPU, but --gpus %d puts every rank on the GPU of its own rank; drop "
+                     "--device (or, to rehearse several ranks on one GPU, set CROPSR_GATHER=host)" % args.gpus)
         sys.stdout.flush()
         sys.exit(launch.spawn_ranks([sys.executable, "-m", "cropsr_amd"] + list(sys.argv[1:] if argv is None else argv),
                                     args.gpus))
+    status = 0
     try:
         run(args)
-        eng_mod = sys.modules.get(__package__ + ".engine")  # (only a run that opened the GPU has imported it)
-        if eng_mod is not None:
-            eng_mod.leave_if_comm_stuck(0)
+    except SystemExit as e:  # (sys.exit(message) inside run: the message goes to stderr, the status is 1)
+        if isinstance(e.code, str):
+            sys.stderr.write(e.code + "\n")
+        status = e.code if isinstance(e.code, int) else (1 if e.code else 0)
     except Exception as e:
+        import traceback
         from . import rendezvous
+        status = 1
         if isinstance(e, rendezvous.RankError):  # agreed on by every rank: all leave the same way, together
             if _ACTIVE_GROUP is not None:
                 _ACTIVE_GROUP.close()
-            sys.exit("cropsr_amd: " + str(e))
-        if _ACTIVE_GROUP is not None and _ACTIVE_GROUP.world > 1:
-            # this rank alone failed (a HIP or RCCL error in the middle of the exchange, ...): its peers may sit in
-            # a collective that will never complete -- take the whole run down with the reason
-            import traceback
+            sys.stderr.write("cropsr_amd: " + str(e) + "\n")
+        else:
             traceback.print_exc()
-            _ACTIVE_GROUP.abort("%s: %s" % (type(e).__name__, e))
-        raise
+            if _ACTIVE_GROUP is not None and _ACTIVE_GROUP.world > 1:
+                # this rank alone failed (a HIP or RCCL error in the middle of the exchange, ...): its peers may sit in
+                # a collective that will never complete -- take the whole run down with the reason
+                _ACTIVE_GROUP.abort("%s: %s" % (type(e).__name__, e))
+    # every way out of a process that may have opened the GPU ends here
+    _leave(status)
+    sys.exit(status)
 
 
 if __name__ == "__main__":

@@ -37,23 +37,15 @@ inline uint64_t round_up(uint64_t x, uint64_t m) { return (x + m - 1) / m * m; }
 
 namespace crp {
 
-// populate: every thread first asks the kernel for its slice's pages in ONE call (MADV_POPULATE_WRITE, Linux 5.14+;
-// ignored where unknown) instead of taking a page fault per 4 KiB inside memcpy.  On plain malloc'ed memory that is
-// 56 GB/s with four threads against 6-14 GB/s by faults (profiles/microbench/pcie_copy.hip); numpy's large arrays,
-// however, are already advised for huge pages, and for them the plain copy measured faster (fetch of the bench
-// workload's tables: 0.044 s against 0.055 s) -- so the table fetches do not use it.
-void parallel_copy(void *dst, const void *src, size_t n, int threads, bool populate)
+// memcpy spread over a few threads.  (Asking the kernel for the destination's pages up front -- MADV_POPULATE_WRITE -- was
+// measured and dropped: numpy's large arrays are already advised for huge pages and the plain copy was faster there,
+// 0.044 s against 0.055 s for the bench workload's tables; profiles/microbench/pcie_copy.hip.)
+void parallel_copy(void *dst, const void *src, size_t n, int threads)
 {
     constexpr size_t MIN_PER_THREAD = 2ull << 20;
     const int t = (int)std::max<size_t>(1, std::min<size_t>((size_t)threads, n / MIN_PER_THREAD));
     auto piece = [=](size_t a, size_t b) {
-        uint8_t *d = static_cast<uint8_t *>(dst) + a;
-        if (populate) {
-            const uintptr_t p0 = (reinterpret_cast<uintptr_t>(d) + 4095) & ~(uintptr_t)4095;
-            const uintptr_t p1 = (reinterpret_cast<uintptr_t>(d) + (b - a)) & ~(uintptr_t)4095;
-            if (p1 > p0) (void)madvise(reinterpret_cast<void *>(p0), p1 - p0, 23 /* MADV_POPULATE_WRITE */);
-        }
-        std::memcpy(d, static_cast<const uint8_t *>(src) + a, b - a);
+        std::memcpy(static_cast<uint8_t *>(dst) + a, static_cast<const uint8_t *>(src) + a, b - a);
     };
     if (t <= 1) {
         piece(0, n);
@@ -117,7 +109,7 @@ int staged_h2d(crp_ctx *ctx, void *d_dst, const void *src, size_t n)
         const size_t len = std::min(STAGE_CHUNK, n - off);
         rc = pin_wait(ctx, b);  // the copy that last read this buffer has left
         if (rc != CRP_OK) return rc;
-        parallel_copy(ctx->pin[b], static_cast<const uint8_t *>(src) + off, len, ctx->copy_threads, false);
+        parallel_copy(ctx->pin[b], static_cast<const uint8_t *>(src) + off, len, ctx->copy_threads);
         CRP_HIP(ctx, hipMemcpyAsync(static_cast<uint8_t *>(d_dst) + off, ctx->pin[b], len, hipMemcpyHostToDevice, ctx->stream));
         CRP_HIP(ctx, hipEventRecord(ctx->pin_done[b], ctx->stream));
         ctx->pin_busy[b] = true;
@@ -150,7 +142,7 @@ int staged_d2h(crp_ctx *ctx, void *dst, const void *d_src, size_t n)
         CRP_HIP(ctx, hipEventRecord(ctx->pin_done[b], ctx->stream));
         if (prev_len) {
             CRP_HIP(ctx, hipEventSynchronize(ctx->pin_done[prev_b]));
-            parallel_copy(static_cast<uint8_t *>(dst) + prev_off, ctx->pin[prev_b], prev_len, ctx->copy_threads, false);
+            parallel_copy(static_cast<uint8_t *>(dst) + prev_off, ctx->pin[prev_b], prev_len, ctx->copy_threads);
         }
         prev_off = off;
         prev_len = len;
@@ -158,7 +150,7 @@ int staged_d2h(crp_ctx *ctx, void *dst, const void *d_src, size_t n)
     }
     if (prev_len) {
         CRP_HIP(ctx, hipEventSynchronize(ctx->pin_done[prev_b]));
-        parallel_copy(static_cast<uint8_t *>(dst) + prev_off, ctx->pin[prev_b], prev_len, ctx->copy_threads, false);
+        parallel_copy(static_cast<uint8_t *>(dst) + prev_off, ctx->pin[prev_b], prev_len, ctx->copy_threads);
     }
     return CRP_OK;
 }
@@ -453,7 +445,7 @@ int crp_arena_add_contig_ascii(crp_arena *a, const uint8_t *text, uint64_t len, 
                 CRP_HIP(ctx, hipEventSynchronize(ctx->pin_done[b]));
                 ctx->pin_busy[b] = false;
             }
-            crp::parallel_copy(ctx->pin[b], text + c0, c1 - c0, ctx->copy_threads, false);
+            crp::parallel_copy(ctx->pin[b], text + c0, c1 - c0, ctx->copy_threads);
             CRP_HIP(ctx, hipMemcpyAsync(ctx->d_text, ctx->pin[b], c1 - c0, hipMemcpyHostToDevice, ctx->stream));
             CRP_HIP(ctx, hipEventRecord(ctx->pin_done[b], ctx->stream));
             ctx->pin_busy[b] = true;
@@ -488,12 +480,6 @@ int crp_arena_add_contigs_ascii(crp_arena *a, const uint8_t *const *texts, const
     constexpr uint32_t kMaxGroups = (1u << 20) / sizeof(crp::PackGroup) - 1;  // sits in the buffer's last MiB
     for (uint64_t i = 0; i < n; ++i)
         if (lens[i] && !texts[i]) return CRP_ERR_INVALID;
-    std::vector<crp::PackGroup> groups;
-    try {
-        groups.reserve(kMaxGroups);  // the only allocation of this call: nothing below can throw
-    } catch (...) {
-        return CRP_ERR_NOMEM;
-    }
     uint64_t i = 0;
     while (i < n) {
         if (lens[i] >= kSmall) {
@@ -515,21 +501,23 @@ int crp_arena_add_contigs_ascii(crp_arena *a, const uint8_t *const *texts, const
             CRP_HIP(ctx, hipEventSynchronize(ctx->pin_done[b]));
             ctx->pin_busy[b] = false;
         }
-        groups.clear();
+        // the group table is written where it travels from: the last MiB of the pinned buffer (no allocation in this call)
+        crp::PackGroup *groups = reinterpret_cast<crp::PackGroup *>(ctx->pin[b] + kTextRoom);
+        uint32_t n_table = 0;
         uint64_t cursor = 0;
         const uint64_t first = i;
         while (i < n && lens[i] < kSmall) {
             const uint64_t len = lens[i], n_words = crp_arena_words_for(len), n_groups = (n_words + 63) / 64;
             // (a group reads 4096 bytes from its start: keep that inside the text part of the buffer)
-            if (cursor + n_groups * 4096 > kTextRoom || groups.size() + n_groups > kMaxGroups) break;
+            if (cursor + n_groups * 4096 > kTextRoom || n_table + n_groups > kMaxGroups) break;
             uint64_t w_first = 0;
             rc = arena_reserve(a, len, &w_first);
             if (rc != CRP_OK) break;
             if (len) std::memcpy(ctx->pin[b] + cursor, texts[i], len);
             for (uint64_t g = 0; g < n_groups; ++g) {
                 const uint64_t c0 = g * 4096;
-                groups.push_back(crp::PackGroup{(uint32_t)(cursor + c0), (uint32_t)(len > c0 ? std::min<uint64_t>(4096, len - c0) : 0),
-                                                w_first + g * 64, (uint32_t)std::min<uint64_t>(64, n_words - g * 64), 0});
+                groups[n_table++] = crp::PackGroup{(uint32_t)(cursor + c0), (uint32_t)(len > c0 ? std::min<uint64_t>(4096, len - c0) : 0),
+                                                   w_first + g * 64, (uint32_t)std::min<uint64_t>(64, n_words - g * 64), 0};
             }
             a->used_words += n_words;
             a->n_contigs += 1;
@@ -539,15 +527,14 @@ int crp_arena_add_contigs_ascii(crp_arena *a, const uint8_t *const *texts, const
             ++i;
         }
         if (i == first) return rc != CRP_OK ? rc : CRP_ERR_CAPACITY;  // not even one contig fitted (cannot happen for small ones)
-        std::memcpy(ctx->pin[b] + kTextRoom, groups.data(), groups.size() * sizeof(crp::PackGroup));
         // one copy for the characters, one for the table (both from the pinned buffer), one launch
         CRP_HIP(ctx, hipMemcpyAsync(ctx->d_text, ctx->pin[b], cursor, hipMemcpyHostToDevice, ctx->stream));
-        CRP_HIP(ctx, hipMemcpyAsync(ctx->d_text + kTextRoom, ctx->pin[b] + kTextRoom, groups.size() * sizeof(crp::PackGroup),
+        CRP_HIP(ctx, hipMemcpyAsync(ctx->d_text + kTextRoom, ctx->pin[b] + kTextRoom, n_table * sizeof(crp::PackGroup),
                                     hipMemcpyHostToDevice, ctx->stream));
         CRP_HIP(ctx, hipEventRecord(ctx->pin_done[b], ctx->stream));
         ctx->pin_busy[b] = true;
         CRP_HIP(ctx, crp::launch_pack_groups(ctx->stream, ctx->d_text, reinterpret_cast<const crp::PackGroup *>(ctx->d_text + kTextRoom),
-                                             (uint32_t)groups.size(), a->d_plane[0], a->d_plane[1], a->d_plane[2], a->d_plane[3]));
+                                             n_table, a->d_plane[0], a->d_plane[1], a->d_plane[2], a->d_plane[3]));
         if (rc != CRP_OK) return rc;  // (the arena ran out of room in the middle of the batch: what fitted is uploaded)
     }
     return CRP_OK;

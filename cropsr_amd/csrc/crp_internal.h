@@ -141,13 +141,12 @@ inline void prof_collect(crp_ctx *ctx, int kind)
 // runtime's own pageable path does this with one thread: ~17 GB/s up, ~10 GB/s down into untouched pages on the
 // MI355X boxes).  Small copies go straight through hipMemcpyAsync.  Both are synchronous for the caller's memory:
 // on return of staged_h2d `src` may be reused (the device copy is ordered on the stream); staged_d2h returns with
-// `dst` filled.  `after_chunk`, if given, is called after chunk k's copy has been queued (e.g. to launch a kernel
-// that consumes it from a reused device buffer) with (offset, length).
+// `dst` filled.
 constexpr size_t STAGE_CHUNK = 32ull << 20;
 int staged_h2d(crp_ctx *ctx, void *d_dst, const void *src, size_t n);
 int staged_d2h(crp_ctx *ctx, void *dst, const void *d_src, size_t n);
 int staging_ready(crp_ctx *ctx);
-void parallel_copy(void *dst, const void *src, size_t n, int threads, bool populate);
+void parallel_copy(void *dst, const void *src, size_t n, int threads);
 
 // grow-only device buffer: *p holds at least `need` elements of `elem` bytes afterwards
 int grow(crp_ctx *ctx, void **p, uint64_t *cap, uint64_t need, size_t elem);

@@ -683,8 +683,6 @@ __global__ __launch_bounds__(TILE_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8
         off_minus = off.y;
         if (n_all == 0) return;
     }
-    // the scorer's tables are first read after the barrier that follows the hit-list build; staging them
-    // only now keeps them out of the way of the counts that later tiles wait for (-3.5 %)
     // The scorer's tables (exp: 2 KiB; chain prefixes: 7.5 KiB, l = 20 only) are first read after the barrier that
     // follows the hit-list build; staging them only now keeps them out of the way of the counts that later tiles wait
     // for (-3.5 %).  (Staging by LDS-DMA, or requesting the words earlier and writing them here, both measured

@@ -104,20 +104,12 @@ __device__ __forceinline__ void crp_score_masks(uint32_t mA, uint32_t mT, uint32
     double sA = PAM ? CRP_PAM_INIT_sA : 0.0, sT = PAM ? CRP_PAM_INIT_sT : 0.0;
     double sC = PAM ? CRP_PAM_INIT_sC : 0.0, sG = PAM ? CRP_PAM_INIT_sG : 0.0;
     if (PAM) {
-#if defined(CRP_SCORER_NO_TABLES)  // every term a gated FMA (the form the tables were derived from)
-        CRP_SCORE_BODY_PAM(mA, mT, mC, mG)
-#else
         CRP_SCORE_BODY_PAM_TABLES(mA, mT, mC, mG)
-#endif
     } else {
         CRP_SCORE_BODY(mA, mT, mC, mG)
     }
     const double s1 = (fA + fC) + (fT + fG);
     const double s2 = (sA + sC) + (sT + sG);
     pre = (((s1 + s2) + CRP_INTERSECT) + CRP_LOW_GC) * -1.0;
-#if defined(CRP_EXPERIMENT_NO_EXP)
-    score = pre;
-#else
     score = crp_recip(1.0 + crp_exp(pre, exp_tab));
-#endif
 }

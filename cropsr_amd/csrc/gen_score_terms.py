@@ -293,7 +293,8 @@ def generate(def_path):
             init[chain] = init[chain] + t[6]
         elif st == "live":
             seen_live.add(chain)
-    emit_body("CRP_SCORE_BODY_PAM", lambda t: settled[id(t)] == "live", table)
+    # (the all-gated-FMA form of the PAM variant -- what the tables are derived from -- is no longer emitted: it lives on
+    # as the executable specification in tests/test_host.py::test_score_tables_equal_sequential_sums)
     emit_table_scorer(out, [t for t in ordered if settled[id(t)] == "live"], init, table, emit_copies)
     for c in sorted(init):
         out.append("#define CRP_PAM_INIT_%s %s" % (c, float(init[c]).hex()))

@@ -236,6 +236,15 @@ def leave_if_comm_stuck(status=0):
         os._exit(status)
 
 
+def _comm_init_hook(rank):
+    """Called on the helper thread right before crp_comm_init.  Production: nothing.  The GPU tests start their ranks with
+    CROPSR_TEST_HOOKS=1 and CROPSR_TEST_COMM_INIT_STALL=<rank> to make that rank's bootstrap hang for ever."""
+    import os
+    if os.environ.get("CROPSR_TEST_HOOKS") == "1" and os.environ.get("CROPSR_TEST_COMM_INIT_STALL") == str(rank):
+        import threading
+        threading.Event().wait()
+
+
 @atexit.register
 def _close_live_engines():
     for eng in list(_LIVE_ENGINES):
@@ -413,9 +422,11 @@ class Engine:
         done = {}
 
         def init():
-            if os.environ.get("CROPSR_TEST_COMM_INIT_STALL") == str(group.rank):  # tests: this rank's bootstrap hangs
-                threading.Event().wait()
-            done["st"] = L.crp_comm_init(self._ctx, buf, group.rank, group.world)
+            try:
+                _comm_init_hook(group.rank)  # (a no-op; the tests replace it to make one rank's bootstrap hang)
+                done["st"] = L.crp_comm_init(self._ctx, buf, group.rank, group.world)
+            except BaseException as e:  # the thread must not die silently: its error becomes this rank's error below
+                done["exc"] = "%s: %s" % (type(e).__name__, e)
 
         worker = threading.Thread(target=init, name="crp_comm_init", daemon=True)
         worker.start()
@@ -424,6 +435,8 @@ class Engine:
         if worker.is_alive():
             self.comm_stuck = _COMM_STUCK = True
             err = "crp_comm_init did not return within %.0f s (RCCL bootstrap)" % timeout_s
+        elif "st" not in done:
+            err = "crp_comm_init was never made: " + done.get("exc", "the helper thread ended without a result")
         elif done["st"] != nat.CRP_OK:
             err = "crp_comm_init: %s [%s]" % (L.crp_strerror(done["st"]).decode(), L.crp_last_error(self._ctx).decode())
         try:

@@ -16,11 +16,18 @@ and waits for them.  Standard output and error are inherited, so rank 0's one JS
 line (or the CLI's stdout) reaches the caller unchanged.  The parent's exit status is
 0 only if every rank's is; the first rank that fails decides it, its peers get a grace
 period to leave through the rendezvous abort channel and are then terminated -- by
-their exact pids, never by a pattern.
+their exact pids, never by a pattern.  A launcher that is itself told to stop (SIGTERM /
+SIGHUP / SIGINT: a driver's step time-out, `timeout(1)`, a scheduler's cancel) stops its
+ranks before it leaves with 128 + signal; should it be killed outright (SIGKILL), the
+ranks get SIGTERM from the kernel (PR_SET_PDEATHSIG) -- no rank is ever left behind
+holding a GPU.
 """
+import ctypes
 import os
+import signal
 import subprocess
 import sys
+import threading
 import time
 
 ENV_MARK = "CROPSR_LAUNCHED"
@@ -43,15 +50,41 @@ def rank_env(rank, world, key, base=None):
     return env
 
 
+class _Stopped(Exception):
+    def __init__(self, signum):
+        super().__init__(signum)
+        self.signum = signum
+
+
+def _die_with_parent():
+    """preexec_fn of a rank (between fork and exec, so before anything could touch a GPU): SIGTERM when the launcher dies."""
+    try:
+        ctypes.CDLL(None, use_errno=True).prctl(1, int(signal.SIGTERM), 0, 0, 0)  # PR_SET_PDEATHSIG
+    except Exception:  # not Linux: the handlers below are all there is
+        pass
+
+
 def spawn_ranks(argv, world, timeout_s=None, grace_s=20.0, poll_s=0.05, env=None):
     """Run `argv` as `world` processes (ranks 0..world-1) and wait.  Returns the exit
     status for the caller: 0 if all ranks returned 0, else the status of the first rank
-    seen failing (a rank killed by a signal counts as 128 + signal); 124 on timeout."""
+    seen failing (a rank killed by a signal counts as 128 + signal); 124 on timeout;
+    128 + signal when the launcher itself was told to stop (its ranks are stopped first)."""
     key = "self_%d_%s" % (os.getpid(), os.urandom(4).hex())
     procs = []
+    # SIGTERM / SIGHUP / SIGINT while the ranks run: raise out of the wait so that the `finally` below stops them
+    # (the default action would end this process at once and orphan N ranks inside a collective, GPUs held)
+    old = {}
+    if threading.current_thread() is threading.main_thread():
+        def on_signal(signum, _frame):
+            raise _Stopped(signum)
+        for sig in (signal.SIGTERM, signal.SIGHUP, signal.SIGINT):
+            try:
+                old[sig] = signal.signal(sig, on_signal)
+            except (OSError, ValueError):
+                pass
     try:
         for r in range(world):
-            procs.append(subprocess.Popen(list(argv), env=rank_env(r, world, key, env)))
+            procs.append(subprocess.Popen(list(argv), env=rank_env(r, world, key, env), preexec_fn=_die_with_parent))
         deadline = None if timeout_s is None else time.monotonic() + timeout_s
         status, first_fail_at, seen = 0, None, set()
         while True:
@@ -78,8 +111,15 @@ def spawn_ranks(argv, world, timeout_s=None, grace_s=20.0, poll_s=0.05, env=None
                 break  # the peers did not leave by themselves (abort channel): stop them below
             time.sleep(poll_s)
         return status
+    except _Stopped as e:
+        sys.stderr.write("[cropsr_amd.launch] signal %d: stopping the ranks\n" % e.signum)
+        return 128 + e.signum
     finally:
+        for sig in old:  # (a second signal must not interrupt the clean-up)
+            signal.signal(sig, signal.SIG_IGN)
         _stop(procs)
+        for sig, handler in old.items():
+            signal.signal(sig, handler)
 
 
 def _stop(procs):

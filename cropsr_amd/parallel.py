@@ -71,6 +71,59 @@ def cut_contigs(lengths, world_size, max_piece=None):
     return pieces
 
 
+def split_evenly(lengths, world_size, min_piece=4096):
+    """(pieces, owner): the contigs, in their order, dealt to the ranks as CONTIGUOUS runs of equal size -- rank r gets the
+    characters [r, r + 1) * total / world of the concatenated genome; a contig that straddles a boundary is cut there
+    (unless one side would be shorter than min_piece: then it stays whole on the side that holds most of it).  At most
+    world - 1 cuts, shares equal to within min_piece -- where dealing whole chromosomes by LPT leaves 16 % (switchgrass-like)
+    to 39 % (sorghum-like) on the busiest of 8 ranks."""
+    total = int(sum(int(n) for n in lengths))
+    bounds = [(r + 1) * total // world_size for r in range(world_size)]
+    pieces, owner = [], []
+    r, acc = 0, 0
+    for k, n in enumerate(lengths):
+        n, start = int(n), 0
+        while True:
+            rest = n - start
+            room = bounds[r] - acc
+            if r == world_size - 1 or rest <= room:
+                pieces.append((k, start, n))
+                owner.append(r)
+                acc += rest
+                break
+            if room >= min_piece and rest - room >= min_piece:  # cut at the boundary
+                pieces.append((k, start, start + room))
+                owner.append(r)
+                acc += room
+                start += room
+                r += 1
+            elif 2 * room >= rest:  # a sliver would be left over: the rest of the contig stays here
+                pieces.append((k, start, n))
+                owner.append(r)
+                acc += rest
+                break
+            else:                   # a sliver would be cut off: the next rank takes the contig from here
+                r += 1
+        while r < world_size - 1 and acc >= bounds[r]:
+            r += 1
+    return pieces, owner
+
+
+def strong_plan(lengths, world_size, max_piece=None):
+    """How ONE genome is spread over the ranks (BASELINE.json configs[3], [4]; bench.py's strong-scaling block and
+    sharded_scan share it): {"pieces": [(contig, start, end)] in contig order, "owner": rank per piece, "by_rank": piece
+    indices per rank in piece order, "bases": owned characters per rank}.  Default: split_evenly (equal contiguous
+    shares).  max_piece given (CROPSR_DIST_MAX_PIECE): cut_contigs into pieces of at most that length, dealt by LPT."""
+    if max_piece is None:
+        pieces, owner = split_evenly(lengths, world_size)
+    else:
+        pieces = cut_contigs(lengths, world_size, max_piece)
+        owner = partition_contigs([e - s for _, s, e in pieces], world_size)
+    by_rank = [[q for q, o in enumerate(owner) if o == r] for r in range(world_size)]
+    bases = [int(sum(pieces[q][2] - pieces[q][1] for q in qs)) for qs in by_rank]
+    return {"pieces": pieces, "owner": owner, "by_rank": by_rank, "bases": bases}
+
+
 def piece_view(contig, start, end):
     """(characters to scan, index of `start` inside them) for the piece [start, end) of a contig
     string (bytes-like, one byte per character): the piece plus HALO characters either side."""
@@ -159,8 +212,8 @@ def merge_gathered(gathered, layouts):
 def sharded_scan(backend, strings, guide_len, group, dst=0, max_piece=None, offtarget=False, annotation=None):
     """The scan of `strings` (the same list on every rank) spread over the ranks of `group`.
 
-    Contigs are cut into pieces of at most a rank's fair share (cut_contigs), the pieces are dealt
-    to the ranks by LPT (partition_contigs), every rank scans its pieces -- with their halo, no
+    The contigs are dealt to the ranks in equal contiguous shares, cut where a share ends inside one (strong_plan; with
+    max_piece: cut into pieces of at most that length and dealt by LPT), every rank scans its pieces -- with their halo, no
     exchange -- and the one exchange of the path, the gatherv of the per-rank hit tables, brings
     them to `dst`, where the pieces of each contig are stitched back.  Returns on `dst` what
     backend.scan(strings, guide_len) returns on one GPU -- a list of hit dicts, one per contig,
@@ -174,9 +227,8 @@ def sharded_scan(backend, strings, guide_len, group, dst=0, max_piece=None, offt
     it through group.check, so EVERY rank raises rendezvous.RankError with the same message
     instead of waiting in a collective."""
     rank, world = group.rank, group.world
-    pieces = cut_contigs([len(s) for s in strings], world, max_piece)
-    owner = partition_contigs([e - s for _, s, e in pieces], world)
-    mine = [q for q, o in enumerate(owner) if o == rank]
+    plan = strong_plan([len(s) for s in strings], world, max_piece)
+    pieces, mine = plan["pieces"], plan["by_rank"][rank]
     res, err = None, None
     try:
         views = [piece_view(strings[pieces[q][0]], pieces[q][1], pieces[q][2]) for q in mine]

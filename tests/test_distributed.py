@@ -166,6 +166,65 @@ def test_many_tiny_contigs_stitch_in_linear_time(oracle):
     assert grouped == n and time.time() - t0 < 2.0
 
 
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_strong_plan_of_the_bench_genome_and_stitching(world, oracle):
+    """parallel.strong_plan -- what bench.py's strong-scaling block and the CLI's sharded scan deal out for ONE genome
+    (BASELINE.json configs[3], [4]): on the switchgrass-like contig lengths every character is owned exactly once, no
+    piece exceeds a rank's fair share, the ranks' shares differ by a few per cent; and on a small genome the oracle's
+    tables of every rank's pieces (scanned with their halos), stitched, are the whole contigs' tables."""
+    import bench_workload as bw
+    from cropsr_amd import parallel
+    lengths = [s.length + 4 for s in bw.switchgrass_like().specs]
+    plan = parallel.strong_plan(lengths, world)
+    total = sum(lengths)
+    covered = {}
+    for k, a, b in plan["pieces"]:
+        assert 0 <= a < b <= lengths[k]
+        covered.setdefault(k, []).append((a, b))
+    assert len(plan["pieces"]) <= len(lengths) + world - 1 and plan["owner"] == sorted(plan["owner"])
+    for k, n in enumerate(lengths):
+        spans = sorted(covered[k])
+        assert spans[0][0] == 0 and spans[-1][1] == n and all(x[1] == y[0] for x, y in zip(spans, spans[1:]))
+    assert sum(plan["bases"]) == total and sorted(q for qs in plan["by_rank"] for q in qs) == list(range(len(plan["pieces"])))
+    assert max(plan["bases"]) <= total / world + 4096 and min(plan["bases"]) >= total / world - 2 * 4096 * world, plan["bases"]
+    for other in (bw.sorghum_like(), bw.tair10_like(), bw.ecoli_like()):
+        ls = [s.length + 4 for s in other.specs]
+        shares = parallel.strong_plan(ls, world)["bases"]
+        assert sum(shares) == sum(ls) and max(shares) <= sum(ls) / world + 4096, (other.name, shares)
+    # any list of lengths (empty contigs, fewer characters than ranks, one giant): every character owned once, in order
+    rng = np.random.default_rng(100 + world)
+    for trial in range(200):
+        ls = [int(x) for x in rng.choice([0, 1, 5, 63, 4096, 5000, 20000, 300000], size=int(rng.integers(0, 12)))]
+        pieces, owner = parallel.split_evenly(ls, world, min_piece=int(rng.choice([1, 64, 4096])))
+        assert owner == sorted(owner) and all(0 <= o < world for o in owner) and len(pieces) == len(owner)
+        seen = {}
+        for k, a, b in pieces:
+            assert a == seen.get(k, 0) and a <= b <= ls[k]
+            seen[k] = b
+        assert [seen.get(k, None) for k in range(len(ls))] == ls and [p[0] for p in pieces] == sorted(p[0] for p in pieces)
+    # a small genome through the same plan, the oracle as hit provider
+    rng = np.random.default_rng(world)
+    strings = [b"'" + rng.choice(np.frombuffer(b"ACGTacgtNGGCC", np.uint8), n).tobytes() + b"')," for n in (30000, 9000, 700, 64, 12000)]
+    plan = parallel.strong_plan([len(s) for s in strings], world)
+    per_piece = {}
+    for r in range(world):
+        for q in plan["by_rank"][r]:
+            k, a, b = plan["pieces"][q]
+            view, shift = parallel.piece_view(strings[k], a, b)
+            per_piece[q] = (shift, oracle.scan_score(bytes(view), 20))
+    assert any(sum(1 for p in plan["pieces"] if p[0] == k) > 1 for k in range(len(strings)))
+    q = 0
+    for k, s in enumerate(strings):
+        parts = []
+        while q < len(plan["pieces"]) and plan["pieces"][q][0] == k:
+            _, a, b = plan["pieces"][q]
+            parts.append((a, b, per_piece[q][0], per_piece[q][1]))
+            q += 1
+        got, want = parallel.stitch_pieces(parts), oracle.scan_score(s, 20)
+        for key in ("pos_plus", "score_plus", "pos_minus", "score_minus"):
+            assert (np.asarray(got[key]).view(np.uint8) == np.asarray(want[key]).view(np.uint8)).all(), (k, key)
+
+
 def test_partition_is_balanced_and_deterministic():
     from cropsr_amd import parallel
     lens = [81, 70, 66, 64, 62, 61, 59, 58, 57, 55] + [1] * 857

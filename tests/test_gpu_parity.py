@@ -857,6 +857,15 @@ def test_bench_starts_its_own_ranks(launcher):
     ranks = d["per_rank"]
     assert [r["rank"] for r in ranks] == [0, 1] and all(r["kernel_ms"] > 0 and r["kept_hits"] > 0 for r in ranks)
     assert sum(r["kept_hits"] for r in ranks) == d["config"]["kept_hits_total"]
+    # the strong-scaling block: ONE genome cut over the two ranks, scanned, gathered, stitched on rank 0
+    # and compared, contig by contig, with rank 0's own N = 1 scan of the whole genome
+    st = d["strong"]
+    assert st["scaling"] == "strong" and st["genomes"] == 1 and st["digest_ok"] is True, st
+    assert st["ms_scan_max_rank"] > 0 and st["ms_gatherv"] > 0 and st["value"] > 0 and st["value"] < st["value_scan_only"]
+    assert st["contigs_cut"] >= 1 and [r["rank"] for r in st["per_rank"]] == [0, 1]
+    assert st["kept_hits"] == st["n1"]["kept_hits"] and 0 < st["efficiency_vs_n1"] <= st["efficiency_vs_n1_scan_only"]
+    assert abs(st["per_rank"][0]["bases"] - st["per_rank"][1]["bases"]) < 0.02 * st["per_rank"][0]["bases"]
+    assert all(r["tiles"] > 0 and r["kernel_ms"] > 0 for r in st["per_rank"])
 
 
 def test_bench_prints_its_line_when_the_exchange_never_returns():
@@ -893,7 +902,7 @@ def test_bench_goes_on_when_the_rccl_bootstrap_never_returns():
     import sys
     from conftest import ROOT
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "CROPSR_LAUNCHED")}
-    env.update(CROPSR_BENCH_FORCE_RCCL="1", CROPSR_TEST_COMM_INIT_STALL="1", CROPSR_COMM_INIT_TIMEOUT_S="5")
+    env.update(CROPSR_BENCH_FORCE_RCCL="1", CROPSR_TEST_HOOKS="1", CROPSR_TEST_COMM_INIT_STALL="1", CROPSR_COMM_INIT_TIMEOUT_S="5")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu0", "--scale", "0.02",
                         "--steps", "3", "--warmup", "1", "--offtarget-steps", "0"],
                        capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)

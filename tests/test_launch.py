@@ -104,6 +104,71 @@ def test_timeout(tmp_path):
     assert r.returncode == 124 and dt < 30
 
 
+def _pids_alive(pids):
+    out = []
+    for pid in pids:
+        try:
+            with open("/proc/%d/stat" % pid) as f:
+                if f.read().rsplit(")", 1)[1].split()[0] != "Z":
+                    out.append(pid)
+        except OSError:
+            pass
+    return out
+
+
+def _launcher_with_sleeping_ranks(tmp_path, world=3):
+    """A launcher process whose ranks write their pids and sleep; returns (Popen of the launcher, rank pids)."""
+    prog = _script(tmp_path, """
+        import time
+        open(os.path.join(%r, "pid%%s" %% os.environ["RANK"]), "w").write(str(os.getpid()))
+        time.sleep(600)
+    """ % str(tmp_path))
+    driver = tmp_path / "driver.py"
+    driver.write_text(textwrap.dedent("""
+        import sys
+        sys.path.insert(0, %r)
+        from cropsr_amd import launch
+        sys.exit(launch.spawn_ranks([sys.executable, %r], %d))
+        """ % (ROOT, prog, world)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", launch.ENV_MARK)}
+    p = subprocess.Popen([sys.executable, str(driver)], env=env, stderr=subprocess.PIPE, text=True)
+    t0 = time.time()
+    while time.time() - t0 < 60 and not all(os.path.exists(tmp_path / ("pid%d" % r)) and (tmp_path / ("pid%d" % r)).read_text()
+                                            for r in range(world)):
+        time.sleep(0.05)
+    pids = [int((tmp_path / ("pid%d" % r)).read_text()) for r in range(world)]
+    assert len(_pids_alive(pids)) == world
+    return p, pids
+
+
+def test_a_launcher_told_to_stop_takes_its_ranks_along(tmp_path):
+    """SIGTERM to the launcher (a driver's step time-out, timeout(1)) must not orphan the ranks: the handler
+    raises out of the wait, the ranks are terminated by pid, the status is 128 + 15."""
+    import signal
+    p, pids = _launcher_with_sleeping_ranks(tmp_path)
+    p.send_signal(signal.SIGTERM)
+    err = p.communicate(timeout=60)[1]
+    assert p.returncode == 128 + signal.SIGTERM, (p.returncode, err)
+    assert "stopping the ranks" in err
+    t0 = time.time()
+    while _pids_alive(pids) and time.time() - t0 < 10:
+        time.sleep(0.05)
+    assert not _pids_alive(pids)
+
+
+def test_a_launcher_killed_outright_takes_its_ranks_along(tmp_path):
+    """SIGKILL cannot be handled: the ranks were started with PR_SET_PDEATHSIG and get SIGTERM from the kernel."""
+    import signal
+    p, pids = _launcher_with_sleeping_ranks(tmp_path, world=2)
+    p.send_signal(signal.SIGKILL)
+    p.communicate(timeout=60)
+    assert p.returncode == -signal.SIGKILL
+    t0 = time.time()
+    while _pids_alive(pids) and time.time() - t0 < 10:
+        time.sleep(0.05)
+    assert not _pids_alive(pids)
+
+
 def test_bench_parent_does_not_touch_the_gpu_library(tmp_path):
     """`python bench.py --gpus 2` in a process without a launcher takes the spawn branch BEFORE importing the
     engine: with a stub in place of the ranks' interpreter-side work the parent just relays the status.  (The
