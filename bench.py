@@ -472,8 +472,13 @@ def main():
     scored_all, bases_all, hits_all = reduce([scored, my_bases, n_plus + n_minus], "sum")
     # every rank's own view of the timed region, for the line (control sockets: a few numbers per rank)
     my_emit = prof["emit_score"]
+    hbm_free, hbm_total = eng.hbm()
     mine_report = {"rank": rank, "device": local_rank, "kernel_ms": my_emit["ms"] / max(1, my_emit["launches"]),
-                   "bases": int(my_bases), "kept_hits": int(n_plus + n_minus), "gRNAs_scored": int(scored)}
+                   "bases": int(my_bases), "kept_hits": int(n_plus + n_minus), "gRNAs_scored": int(scored),
+                   # start-up: how long this rank waited for the group to form, and what the DEVICE holds now (all processes
+                   # on it: with --share-gpu0 that is every rank's context, arena and tables together)
+                   "rendezvous_s": round(group.connect_s, 3) if group else 0.0,
+                   "device_hbm_in_use_GiB": round((hbm_total - hbm_free) / 2.0 ** 30, 3)}
     per_rank = group.all_gather(mine_report) if group else [mine_report]
 
     # ---- everything the line needs that the collectives below cannot change, taken NOW: if the exchange (or the

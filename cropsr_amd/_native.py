@@ -88,7 +88,7 @@ SIGNATURES = {
 CRP_OK = 0
 ORDER_BODY4, ORDER_TAIL2, ORDER_DOT1 = 0, 1, 2
 OPT_TWO_PASS, OPT_CHAIN_TIMEOUT_US = 1, 2
-Q_CHAIN_TIMEOUTS, Q_TWO_PASS_ACTIVE, Q_COMM_WORLD, Q_COMM_RANK = 1, 2, 3, 4
+Q_CHAIN_TIMEOUTS, Q_TWO_PASS_ACTIVE, Q_COMM_WORLD, Q_COMM_RANK, Q_HBM_FREE, Q_HBM_TOTAL = 1, 2, 3, 4, 5, 6
 KINDS = ("count", "tile_scan", "emit_score", "ot_seed", "ot_ball", "ot_lookup", "gatherv", "ot_reduce",
          "annotate")  # CRP_K_*
 REDUCE_SUM, REDUCE_MAX = 0, 1

@@ -931,6 +931,13 @@ int crp_query(const crp_ctx *ctx, int what, int64_t *value)
         case CRP_Q_TWO_PASS_ACTIVE: *value = (ctx->two_pass || ctx->two_pass_latched) ? 1 : 0; return CRP_OK;
         case CRP_Q_COMM_WORLD: *value = crp::comm_world(ctx); return CRP_OK;
         case CRP_Q_COMM_RANK: *value = crp::comm_rank(ctx); return CRP_OK;
+        case CRP_Q_HBM_FREE:
+        case CRP_Q_HBM_TOTAL: {
+            size_t free_b = 0, total_b = 0;
+            if (hipSetDevice(ctx->device) != hipSuccess || hipMemGetInfo(&free_b, &total_b) != hipSuccess) return CRP_ERR_HIP;
+            *value = (int64_t)(what == CRP_Q_HBM_FREE ? free_b : total_b);
+            return CRP_OK;
+        }
         default: return CRP_ERR_INVALID;
     }
 }

@@ -388,6 +388,15 @@ class Engine:
             out[name] = int(v.value)
         return out
 
+    def hbm(self):
+        """(free, total) bytes of device memory right now -- the whole device, whoever holds it (hipMemGetInfo)."""
+        out = []
+        for what in (nat.Q_HBM_FREE, nat.Q_HBM_TOTAL):
+            v = ctypes.c_int64()
+            nat.check(nat.lib().crp_query(self._ctx, what, ctypes.byref(v)), "crp_query", self._ctx)
+            out.append(int(v.value))
+        return tuple(out)
+
     # ---- multi-GPU: RCCL inside the library (crp_comm.cpp); `group` is a rendezvous.Group
     def comm_init(self, group, timeout_s=None):
         """Create the RCCL communicator of this engine: rank 0 draws the unique id, the group's

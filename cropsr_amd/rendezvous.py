@@ -112,6 +112,8 @@ class Group:
         self._closing = False
         self._listener = None
         self._file = None
+        self.connect_s = 0.0  # how long this rank waited for the group to form (start-up skew included)
+        t_start = time.time()
         # a run's clients prove they belong to it: rank 0 draws a token and publishes it in the rendezvous file
         # (mode 0600); with an explicit endpoint there is no file, and the token is CROPSR_RDZV_TOKEN (or empty)
         self._token = os.environ.get("CROPSR_RDZV_TOKEN", "")
@@ -203,6 +205,7 @@ class Group:
                         raise TimeoutError("rank %d: no rendezvous with rank 0 within %.0f s" % (self.rank, _CONNECT_TIMEOUT_S))
                     time.sleep(0.05)
         threading.Thread(target=self._watch, name="cropsr-abort-watch", daemon=True).start()
+        self.connect_s = time.time() - t_start
         global LAST_GROUP
         LAST_GROUP = self
 

@@ -384,6 +384,8 @@ int crp_configure(crp_ctx *ctx, int option, int64_t value);
 #define CRP_Q_TWO_PASS_ACTIVE 2  /* 1 when scans currently run as three launches (configured or latched) */
 #define CRP_Q_COMM_WORLD 3       /* ranks of the RCCL communicator (0: none) */
 #define CRP_Q_COMM_RANK 4
+#define CRP_Q_HBM_FREE 5         /* bytes of device memory free right now, as hipMemGetInfo sees the whole device (all processes) */
+#define CRP_Q_HBM_TOTAL 6
 int crp_query(const crp_ctx *ctx, int what, int64_t *value);
 /* Identifies the build: a hash of the library's sources taken by the Makefile ("unknown" otherwise).
  * profiles/traffic.json carries the id of the build it was measured on; bench.py refuses another. */
