@@ -61,6 +61,8 @@ def parse_args():
                          "of them (GPU clocks back at steady state); 0 = exactly W")
     ap.add_argument("--workload", default="switchgrass", choices=["switchgrass", "tair10", "ecoli"])
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the switchgrass-like genome (debug)")
+    ap.add_argument("--geometry", default="auto", choices=["auto", "large", "small"],
+                    help="tile shape of the scan (CRP_OPT_TILE_GEOMETRY); auto = by the arena's size: large for the >= 1 Gb genome")
     ap.add_argument("--two-pass", action="store_true",
                     help="count / tile-scan / emit launch sequence (CRP_OPT_TWO_PASS=1) instead of the default single launch")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the final RCCL gatherv altogether")
@@ -250,7 +252,8 @@ def strong_scaling_block(args, eng, group, use_rccl, fence, reduce):
     emit = eng.profile_read(reset=True)["emit_score"]
     eng.profile(0)
     mine_report = {"rank": rank, "pieces": len(mine), "bases": int(sum(pieces[q][2] - pieces[q][1] for q in mine)),
-                   "characters_with_halos": int(arena.stats()["n_chars"]), "tiles": int(-(-arena.stats()["n_words"] // 1024)),
+                   "characters_with_halos": int(arena.stats()["n_chars"]), "tiles": arena.tiles()["n_tiles"],
+                   "tile_geometry": arena.tiles()["geometry"],
                    "kept_hits": int(n_plus + n_minus), "kernel_ms": emit["ms"] / max(1, emit["launches"])}
     per_rank = group.all_gather(mine_report)
     layouts = group.all_gather(layout)
@@ -348,6 +351,8 @@ def main():
     eng = Engine(local_rank)  # raises without libcropsr_hip.so / GPU: no fallback
     if args.two_pass:
         eng.configure(two_pass=True)
+    if args.geometry != "auto":
+        eng.configure(geometry=args.geometry)
     rccl_error = None
     if use_rccl:
         from cropsr_amd import rendezvous
@@ -486,6 +491,7 @@ def main():
     info = eng.device_info() if rank == 0 else None
     build_id = nat.lib().crp_build_id().decode()
     n_chars = arena.stats()["n_chars"]
+    tiles = arena.tiles()
 
     def build_line(gather_info, ot, strong=None):
         hits = n_plus + n_minus
@@ -518,6 +524,8 @@ def main():
             "config": {"workload": genomes[0].name, "genomes": world, "contigs_per_genome": len(genomes[0].specs),
                        "bases_total": int(bases_all), "kept_hits_total": int(hits_all),
                        "guide_len": 20,
+                       # rank 0's arena: tile shape (picked by the arena's size unless --geometry) and workgroups per launch
+                       "tile_geometry": tiles["geometry"], "tiles_per_launch": tiles["n_tiles"], "tile_words": tiles["tile_words"],
                        "launches_per_step": 3 if three_launches else 1,
                        # single-launch scans that timed out in a look-back and were repeated as three launches
                        "chain_timeouts": state["chain_timeouts"],

@@ -36,6 +36,7 @@ SIGNATURES = {
     "crp_arena_add_contig_packed": (ctypes.c_int, [ctypes.c_void_p, u64p, u64p, u64p, u64p,
                                                    ctypes.c_uint64, u64p]),
     "crp_arena_seal": (ctypes.c_int, [ctypes.c_void_p]),
+    "crp_arena_tiles": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), u64p, u64p]),
     "crp_arena_stats": (ctypes.c_int, [ctypes.c_void_p, u64p, u64p, u64p]),
     "crp_scan_score": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, u64p, u64p]),
     "crp_fetch_hits": (ctypes.c_int, [ctypes.c_void_p, u32p, f64p, f64p, u32p, f64p, f64p]),
@@ -87,7 +88,8 @@ SIGNATURES = {
 
 CRP_OK = 0
 ORDER_BODY4, ORDER_TAIL2, ORDER_DOT1 = 0, 1, 2
-OPT_TWO_PASS, OPT_CHAIN_TIMEOUT_US = 1, 2
+OPT_TWO_PASS, OPT_CHAIN_TIMEOUT_US, OPT_TILE_GEOMETRY = 1, 2, 3
+GEOMETRIES = {"auto": 0, "large": 1, "small": 2}
 Q_CHAIN_TIMEOUTS, Q_TWO_PASS_ACTIVE, Q_COMM_WORLD, Q_COMM_RANK, Q_HBM_FREE, Q_HBM_TOTAL = 1, 2, 3, 4, 5, 6
 KINDS = ("count", "tile_scan", "emit_score", "ot_seed", "ot_ball", "ot_lookup", "gatherv", "ot_reduce",
          "annotate")  # CRP_K_*

@@ -587,8 +587,15 @@ int crp_arena_seal(crp_arena *a)
     if (a->sealed) return CRP_OK;
     crp_ctx *ctx = a->ctx;
     CRP_HIP(ctx, hipSetDevice(ctx->device));
-    const uint64_t eff = round_up(a->used_words, crp::TILE_WORDS);  // <= padded_words
-    a->n_tiles = (uint32_t)(eff / crp::TILE_WORDS);
+    // Tile geometry (crp_kernels.h), fixed for the arena's life: by default from the arena's size against the GPU's -- an
+    // arena that gives a CU one or two LARGE tiles at most is all latency and takes the SMALL shape (half the tile, half the
+    // life), anything bigger the throughput shape
+    const uint64_t large_tiles = round_up(a->used_words, crp::GeoLarge::WORDS) / crp::GeoLarge::WORDS;
+    const uint64_t cus = (uint64_t)std::max(1, ctx->n_cu);
+    a->geo = ctx->geometry > 0 ? ctx->geometry - 1 : 2 * large_tiles < 3 * cus ? crp::GEO_SMALL : crp::GEO_LARGE;
+    const uint64_t tw = (uint64_t)crp::tile_words(a->geo);
+    const uint64_t eff = round_up(a->used_words, tw);  // <= padded_words
+    a->n_tiles = (uint32_t)(eff / tw);
     CRP_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&a->d_tile_cnt), a->n_tiles * sizeof(uint2)));
     CRP_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&a->d_tile_off), a->n_tiles * sizeof(uint2)));
     for (int b = 0; b < 2; ++b) {
@@ -601,6 +608,16 @@ int crp_arena_seal(crp_arena *a)
     if (rc != CRP_OK) return rc;
     CRP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     a->sealed = true;
+    return CRP_OK;
+}
+
+int crp_arena_tiles(const crp_arena *a, int *geometry, uint64_t *n_tiles, uint64_t *tile_words)
+{
+    if (!a) return CRP_ERR_INVALID;
+    if (!a->sealed) return CRP_ERR_STATE;
+    if (geometry) *geometry = a->geo + 1;
+    if (n_tiles) *n_tiles = a->n_tiles;
+    if (tile_words) *tile_words = (uint64_t)crp::tile_words(a->geo);
     return CRP_OK;
 }
 
@@ -676,7 +693,7 @@ static int scan_two_pass(crp_arena *a, const crp::Planes &pl, uint64_t eff_words
     const uint32_t n_tiles = a->n_tiles;
     const bool speculative = tables_exist(a, want);
     prof_begin(ctx, 0);
-    CRP_HIP(ctx, crp::launch_count(ctx->stream, pl, eff_words, guide_len, a->d_tile_cnt, n_tiles));
+    CRP_HIP(ctx, crp::launch_count(ctx->stream, a->geo, pl, eff_words, guide_len, a->d_tile_cnt, n_tiles));
     prof_end(ctx, 0);
     prof_begin(ctx, 1);
     CRP_HIP(ctx, crp::launch_tile_scan(ctx->stream, a->d_tile_cnt, n_tiles, a->d_tile_off, a->d_totals));
@@ -691,7 +708,7 @@ static int scan_two_pass(crp_arena *a, const crp::Planes &pl, uint64_t eff_words
     }
     crp::HitTables out = table_args(a, want);
     prof_begin(ctx, 2);
-    CRP_HIP(ctx, crp::launch_emit(ctx->stream, pl, eff_words, guide_len, a->d_tile_off, out));
+    CRP_HIP(ctx, crp::launch_emit(ctx->stream, a->geo, pl, eff_words, guide_len, a->d_tile_off, out));
     prof_end(ctx, 2);
     CRP_HIP(ctx, hipMemcpyAsync(a->h_totals, a->d_totals, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
     CRP_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -704,7 +721,7 @@ static int scan_two_pass(crp_arena *a, const crp::Planes &pl, uint64_t eff_words
         int rc = reserve_tables(a, n, want);
         if (rc != CRP_OK) return rc;
         out = table_args(a, want);
-        CRP_HIP(ctx, crp::launch_emit(ctx->stream, pl, eff_words, guide_len, a->d_tile_off, out));
+        CRP_HIP(ctx, crp::launch_emit(ctx->stream, a->geo, pl, eff_words, guide_len, a->d_tile_off, out));
         CRP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     return CRP_OK;
@@ -731,7 +748,7 @@ static int scan_single_pass(crp_arena *a, const crp::Planes &pl, uint64_t eff_wo
         uint64_t *cur = a->d_chain[a->chain_cur], *next = a->d_chain[a->chain_cur ^ 1];
         a->h_totals[0] = a->h_totals[1] = a->h_totals[2] = 0;
         prof_begin(ctx, 2);
-        CRP_HIP(ctx, crp::launch_emit_chained(ctx->stream, pl, eff_words, guide_len, cur, next, out, ctx->mute_tile,
+        CRP_HIP(ctx, crp::launch_emit_chained(ctx->stream, a->geo, pl, eff_words, guide_len, cur, next, out, ctx->mute_tile,
                                                   ctx->chain_timeout_ticks));
         prof_end(ctx, 2);
         // header: fail << 32, total '+', total '-' -- the kernel also writes it to h_totals (pinned)
@@ -769,7 +786,7 @@ int crp_scan_score(crp_arena *a, int guide_len, int flags, uint64_t *n_plus, uin
     a->have_feat = false;
     // seed words come out of the l = 20 kernel only; for other lengths the off-target step derives them itself
     const ScanWant want{(flags & CRP_SCAN_PRE) != 0, (flags & CRP_SCAN_SEEDS) != 0 && guide_len == 20};
-    const uint64_t eff_words = (uint64_t)a->n_tiles * crp::TILE_WORDS;
+    const uint64_t eff_words = (uint64_t)a->n_tiles * (uint64_t)crp::tile_words(a->geo);
     crp::Planes pl{{a->d_plane[0], a->d_plane[1], a->d_plane[2], a->d_plane[3]}};
     uint64_t n[2] = {0, 0};
     int rc;
@@ -918,6 +935,10 @@ int crp_configure(crp_ctx *ctx, int option, int64_t value)
         case CRP_OPT_CHAIN_TIMEOUT_US:
             if (value < 1 || value > 10000000) return CRP_ERR_INVALID;
             ctx->chain_timeout_ticks = (uint32_t)(value * 100);  // 100 MHz counter
+            return CRP_OK;
+        case CRP_OPT_TILE_GEOMETRY:
+            if (value < 0 || value > crp::GEO_COUNT) return CRP_ERR_INVALID;
+            ctx->geometry = (int)value;  // arenas sealed from now on
             return CRP_OK;
         default: return CRP_ERR_INVALID;
     }

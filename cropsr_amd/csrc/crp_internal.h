@@ -31,6 +31,7 @@ struct crp_ctx {
     int timeout_streak = 0;
     uint64_t chain_timeouts = 0;    // single-launch scans that were repeated with three launches
     uint32_t chain_timeout_ticks = 2000000;  // CRP_OPT_CHAIN_TIMEOUT_US in ticks of the 100 MHz real-time counter
+    int geometry = 0;  // CRP_OPT_TILE_GEOMETRY: 0 = by arena size, else GEO_* + 1
     uint32_t mute_tile = 0xffffffffu;  // test hook (environment CRP_TEST_MUTE_TILE): see crp_kernels.h
     // host <-> device staging for large transfers from / to pageable caller memory (crp_api.cpp: staged_h2d / staged_d2h):
     // two pinned buffers, filled / drained by a few host threads while the other one is on the link
@@ -75,6 +76,7 @@ struct crp_arena {
     uint64_t *d_totals = nullptr;
     uint64_t *h_totals = nullptr;  // pinned
     uint32_t n_tiles = 0;
+    int geo = 0;  // GEO_*: tile geometry, chosen at seal
     // hit tables: [0] = '+', [1] = '-'
     uint32_t *d_pos[2] = {nullptr, nullptr};
     double *d_score[2] = {nullptr, nullptr};

@@ -73,7 +73,7 @@ __device__ __forceinline__ uint64_t wave_inclusive_scan(uint64_t v)
 }
 
 // Block-wide exclusive scan of a packed (plus | minus << 32) count.
-// `wave_tot` is LDS scratch of TILE_BLOCK/64 entries.  Returns the exclusive prefix,
+// `wave_tot` is LDS scratch of WAVES entries.  Returns the exclusive prefix,
 // sets `total` to the block total.
 // The per-lane counts are small (<= 128 per strand), so both fit one 32-bit
 // word as 16-bit fields and the wave scan is six DPP adds (row_shr 1,2,4,8 inside
@@ -97,6 +97,7 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan_u32(uint32_t v)
     return v;
 }
 
+template <int WAVES>
 __device__ __forceinline__ uint64_t block_exclusive_scan(uint64_t v, uint64_t *wave_tot, uint64_t &total)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -107,7 +108,7 @@ __device__ __forceinline__ uint64_t block_exclusive_scan(uint64_t v, uint64_t *w
     __syncthreads();
     uint64_t base = 0, tot = 0;
 #pragma unroll
-    for (int w = 0; w < TILE_BLOCK / 64; ++w) {
+    for (int w = 0; w < WAVES; ++w) {
         const uint64_t t = wave_tot[w];
         if (w < wave) base += t;
         tot += t;
@@ -145,56 +146,79 @@ __device__ __forceinline__ void masks_of(uint64_t g_c, uint64_t g_n, uint64_t c_
     mminus = m;
 }
 
+// The words a lane owns (WPT = 2: one 16-byte load per plane; WPT = 1: one 8-byte load) and the kept-hit masks of those
+// words.  w0 = first word of the lane's WAVE, which covers 64 * WPT consecutive words; the neighbouring words' derived
+// masks come from the adjacent lanes, and lanes 0 / 63 read the word just outside the wave from memory (void beyond the
+// arena).  Must be called by whole waves.
+template <int WPT>
+__device__ __forceinline__ void own_words_and_masks(const Planes &pl, uint64_t n_words_padded, uint64_t w0, int lane, int l,
+                                                    uint64_t (&q)[4][WPT], uint64_t (&mp)[WPT], uint64_t (&mm)[WPT])
+{
+    static_assert(WPT == 1 || WPT == 2, "one or two words per owning lane");
+    const uint64_t wa = w0 + (uint64_t)WPT * lane;
+    if constexpr (WPT == 2) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(pl.plane[p] + wa);
+            q[p][0] = v.x;
+            q[p][WPT - 1] = v.y;
+        }
+    } else {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) q[p][0] = pl.plane[p][wa];
+    }
+    uint64_t e[4] = {ALL, ALL, 0, 0};  // void beyond the arena
+    if (lane == 0 && w0 > 0) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) e[p] = pl.plane[p][w0 - 1];
+    } else if (lane == 63 && w0 + 64 * WPT < n_words_padded) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) e[p] = pl.plane[p][w0 + 64 * WPT];
+    }
+    uint64_t ga, ca, va, gb, cb, vb, ge, ce, ve;
+    derive(q[0][0], q[1][0], q[2][0], q[3][0], ga, ca, va);
+    derive(q[0][WPT - 1], q[1][WPT - 1], q[2][WPT - 1], q[3][WPT - 1], gb, cb, vb);  // (WPT = 1: the same word)
+    derive(e[0], e[1], e[2], e[3], ge, ce, ve);
+    // left neighbour's last word, right neighbour's first word
+    uint64_t v_left = __shfl_up(vb, 1, 64);
+    uint64_t g_right = __shfl_down(ga, 1, 64), c_right = __shfl_down(ca, 1, 64), v_right = __shfl_down(va, 1, 64);
+    if (lane == 0) v_left = ve;
+    if (lane == 63) { g_right = ge; c_right = ce; v_right = ve; }
+    if constexpr (WPT == 2) {
+        masks_of(ga, gb, ca, cb, v_left, va, vb, l, mp[0], mm[0]);
+        masks_of(gb, g_right, cb, c_right, va, vb, v_right, l, mp[WPT - 1], mm[WPT - 1]);
+    } else {
+        masks_of(ga, g_right, ca, c_right, v_left, va, v_right, l, mp[0], mm[0]);
+    }
+}
+
 // LFIX > 0: guide length known at compile time (20, the reference's default), so
 // every funnel shift has a constant amount and becomes one v_alignbit_b32 per half.
-template <int LFIX>
-__global__ __launch_bounds__(TILE_BLOCK) void count_kernel(Planes pl, uint64_t n_words_padded, int l_arg,
-                                                       uint2 *__restrict__ tile_cnt)
+// G: the tile geometry (crp_kernels.h); one workgroup produces the counts of one emit tile, its owner waves only.
+template <class G, int LFIX>
+__global__ __launch_bounds__(G::BLOCK) void count_kernel(Planes pl, uint64_t n_words_padded, int l_arg,
+                                                         uint2 *__restrict__ tile_cnt)
 {
     const int l = LFIX > 0 ? LFIX : l_arg;
-    static_assert(TILE_WORDS == 2 * TILE_BLOCK, "count pass geometry: one workgroup = one emit tile, 128 words per wave");
     const uint32_t tile = blockIdx.x;
-    __shared__ uint64_t wave_tot[TILE_BLOCK / 64];
+    __shared__ uint64_t wave_tot[G::BLOCK / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint64_t c = 0;
-    const uint64_t w0 = (uint64_t)tile * TILE_WORDS + (uint64_t)wave * 128;  // first word of this wave
-    if (w0 < n_words_padded) {
-        const uint64_t wa = w0 + 2 * lane;  // this lane owns words wa, wa+1
-        ulonglong2 q[4];
+    const uint64_t w0 = (uint64_t)tile * G::WORDS + (uint64_t)wave * 64 * G::WPT;  // first word of this wave
+    if (wave < G::OWNERS / 64 && w0 < n_words_padded) {
+        uint64_t q[4][G::WPT], mp[G::WPT], mm[G::WPT];
+        own_words_and_masks<G::WPT>(pl, n_words_padded, w0, lane, l, q, mp, mm);
 #pragma unroll
-        for (int p = 0; p < 4; ++p) q[p] = *reinterpret_cast<const ulonglong2 *>(pl.plane[p] + wa);
-        // words just outside the wave: void beyond the arena
-        uint64_t e[4] = {ALL, ALL, 0, 0};
-        if (lane == 0 && w0 > 0) {
-#pragma unroll
-            for (int p = 0; p < 4; ++p) e[p] = pl.plane[p][w0 - 1];
-        } else if (lane == 63 && w0 + 128 < n_words_padded) {
-#pragma unroll
-            for (int p = 0; p < 4; ++p) e[p] = pl.plane[p][w0 + 128];
-        }
-        uint64_t ga, ca, va, gb, cb, vb, ge, ce, ve;
-        derive(q[0].x, q[1].x, q[2].x, q[3].x, ga, ca, va);
-        derive(q[0].y, q[1].y, q[2].y, q[3].y, gb, cb, vb);
-        derive(e[0], e[1], e[2], e[3], ge, ce, ve);
-        // left neighbour's second word, right neighbour's first word
-        uint64_t v_left = __shfl_up(vb, 1, 64);
-        uint64_t g_right = __shfl_down(ga, 1, 64), c_right = __shfl_down(ca, 1, 64), v_right = __shfl_down(va, 1, 64);
-        if (lane == 0) v_left = ve;
-        if (lane == 63) { g_right = ge; c_right = ce; v_right = ve; }
-        uint64_t mp, mm;
-        masks_of(ga, gb, ca, cb, v_left, va, vb, l, mp, mm);
-        c = (uint64_t)__popcll(mp) | ((uint64_t)__popcll(mm) << 32);
-        masks_of(gb, g_right, cb, c_right, va, vb, v_right, l, mp, mm);
-        c += (uint64_t)__popcll(mp) | ((uint64_t)__popcll(mm) << 32);
+        for (int k = 0; k < G::WPT; ++k) c += (uint64_t)__popcll(mp[k]) | ((uint64_t)__popcll(mm[k]) << 32);
     }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d, 64);
     if (lane == 0) wave_tot[wave] = c;
     __syncthreads();
-    if (threadIdx.x == 0 && (uint64_t)tile * TILE_WORDS < n_words_padded) {
+    if (threadIdx.x == 0 && (uint64_t)tile * G::WORDS < n_words_padded) {
         uint64_t t = 0;
 #pragma unroll
-        for (int w = 0; w < TILE_BLOCK / 64; ++w) t += wave_tot[w];
+        for (int w = 0; w < G::BLOCK / 64; ++w) t += wave_tot[w];
         tile_cnt[tile] = make_uint2((uint32_t)t, (uint32_t)(t >> 32));
     }
 }
@@ -558,9 +582,9 @@ __device__ __forceinline__ void peel32(uint32_t m, uint32_t base, uint32_t &addr
         : "vcc", "memory");
 }
 
-template <bool PAM, bool CHAINED, bool PRE, bool SEEDS>
-__device__ __forceinline__ void emit_rounds(uint64_t (*sh)[TILE_WORDS + 2], uint16_t *list, uint64_t *exp_tab, double *score_tab,
-                                            const uint64_t (&mp)[TILE_WPT], const uint64_t (&mm)[TILE_WPT], uint64_t ex,
+template <class G, bool PAM, bool CHAINED, bool PRE, bool SEEDS>
+__device__ __forceinline__ void emit_rounds(uint64_t (*sh)[G::WORDS + 2], uint16_t *list, uint64_t *exp_tab, double *score_tab,
+                                            const uint64_t (&mp)[G::WPT], const uint64_t (&mm)[G::WPT], uint64_t ex,
                                             uint32_t n_plus, uint32_t n_minus, int l, uint32_t tile_pos,
                                             uint64_t off_plus, uint64_t off_minus, const HitTables &out,
                                             const ChainArgs &ch);
@@ -581,24 +605,26 @@ __device__ __forceinline__ void emit_rounds(uint64_t (*sh)[TILE_WORDS + 2], uint
 //                  published by the last tile.
 // CHAINED = false: third pass of the count / scan / emit sequence (offsets from tile_off).
 // PRE: the pre-sigmoid column is written too.  SEEDS: so is the off-target scan's raw seed word.
-template <bool CHAINED, int LFIX, bool PRE, bool SEEDS>
-__global__ __launch_bounds__(TILE_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8))) void emit_kernel(
+// G: the tile geometry (crp_kernels.h): G::BLOCK threads on a tile of G::WORDS words, of which the first G::OWNERS threads
+//    own G::WPT words each (load them, derive their masks, build their part of the hit list); all threads score.
+template <class G, bool CHAINED, int LFIX, bool PRE, bool SEEDS>
+__global__ __launch_bounds__(G::BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8))) void emit_kernel(
     Planes pl, uint64_t n_words_padded, int l_arg, const uint2 *__restrict__ tile_off, uint64_t *chain,
     uint64_t *__restrict__ chain_next, HitTables out, uint32_t mute_tile, uint32_t timeout_ticks)
 {
     const int l = LFIX > 0 ? LFIX : l_arg;
-    constexpr int TW = TILE_WORDS;
+    constexpr int TW = G::WORDS;
     __shared__ uint64_t sh[4][TW + 2];
     // exp table (256 words) + chain-prefix tables of the scorer
     __shared__ uint64_t tabs[256 + CRP_SCORE_TAB_N];
     uint64_t *const exp_tab = tabs;
     double *const score_tab = reinterpret_cast<double *>(tabs + 256);
-    __shared__ uint64_t wave_tot[TILE_BLOCK / 64];
+    __shared__ uint64_t wave_tot[G::BLOCK / 64];
     __shared__ uint64_t s_excl;
     __shared__ uint32_t s_flag;
-    __shared__ uint16_t list[LIST_CAP];
-    static_assert(sizeof(sh) + sizeof(tabs) + sizeof(wave_tot) + sizeof(s_excl) + 8 + sizeof(list) <= TILE_LDS_LIMIT,
-                  "three workgroups per CU: see LIST_CAP");
+    __shared__ uint16_t list[G::LIST];
+    static_assert(sizeof(sh) + sizeof(tabs) + sizeof(wave_tot) + sizeof(s_excl) + 8 + sizeof(list) <= G::LDS_LIMIT,
+                  "workgroups per CU: see the geometry's LIST");
 
     const int tid = threadIdx.x;
     const uint32_t tile = blockIdx.x;  // dispatch order = index order: every tile this one waits for has started
@@ -607,55 +633,36 @@ __global__ __launch_bounds__(TILE_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8
     // single-launch mode: later tiles wait for this tile's counts, so the short phase that produces
     // them (loads, masks, block scan) runs ahead of the scoring of the other workgroups on this CU
     if (CHAINED) __builtin_amdgcn_s_setprio(3);
-    // Every thread loads the two words it owns of each plane (one 16-byte load per plane) and derives
+    // Every owning thread loads the words it owns of each plane (one load per plane) and derives
     // its hit masks from those REGISTERS, taking the neighbouring words' G / C / void masks from the
     // adjacent lanes by wave shuffles (lanes 0 and 63 read the word just outside the wave from
     // memory) -- the count pass's scheme.  The words also go to LDS, but only the window extraction
     // after the block scan reads them there: no barrier and no LDS round trip stand between the loads
     // and the tile's counts.
-    uint64_t mp[TILE_WPT], mm[TILE_WPT];
-    {
+    uint64_t mp[G::WPT], mm[G::WPT];
+#pragma unroll
+    for (int k = 0; k < G::WPT; ++k) mp[k] = mm[k] = 0;
+    if (G::OWNERS == G::BLOCK || tid < G::OWNERS) {  // (whole waves: OWNERS is a multiple of 64)
         const int lane = tid & 63;
-        const uint64_t wa = t0 + 2 * (uint64_t)tid;          // this thread owns words wa, wa + 1
-        const uint64_t w0 = t0 + 128 * (uint64_t)(tid >> 6);  // first word of this wave
-        ulonglong2 q[4];
+        const uint64_t w0 = t0 + (uint64_t)(64 * G::WPT) * (uint64_t)(tid >> 6);  // first word of this wave
+        uint64_t q[4][G::WPT];
+        own_words_and_masks<G::WPT>(pl, n_words_padded, w0, lane, l, q, mp, mm);
 #pragma unroll
-        for (int p = 0; p < 4; ++p) q[p] = *reinterpret_cast<const ulonglong2 *>(pl.plane[p] + wa);
-        uint64_t e[4] = {ALL, ALL, 0, 0};  // void beyond the arena
-        if (lane == 0 && w0 > 0) {
+        for (int p = 0; p < 4; ++p)
 #pragma unroll
-            for (int p = 0; p < 4; ++p) e[p] = pl.plane[p][w0 - 1];
-        } else if (lane == 63 && w0 + 128 < n_words_padded) {
-#pragma unroll
-            for (int p = 0; p < 4; ++p) e[p] = pl.plane[p][w0 + 128];
-        }
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            sh[p][1 + 2 * tid] = q[p].x;
-            sh[p][2 + 2 * tid] = q[p].y;
-        }
+            for (int k = 0; k < G::WPT; ++k) sh[p][1 + G::WPT * tid + k] = q[p][k];
         if (tid < 8) {  // the tile's own halo words, for windows that reach across its ends
             const int p = tid >> 1;
             const uint64_t voidw = (p < 2) ? ALL : 0ull;
             if (tid & 1) sh[p][TW + 1] = t0 + TW < n_words_padded ? pl.plane[p][t0 + TW] : voidw;
             else sh[p][0] = t0 > 0 ? pl.plane[p][t0 - 1] : voidw;
         }
-        uint64_t ga, ca, va, gb, cb, vb, ge, ce, ve;
-        derive(q[0].x, q[1].x, q[2].x, q[3].x, ga, ca, va);
-        derive(q[0].y, q[1].y, q[2].y, q[3].y, gb, cb, vb);
-        derive(e[0], e[1], e[2], e[3], ge, ce, ve);
-        uint64_t v_left = __shfl_up(vb, 1, 64);
-        uint64_t g_right = __shfl_down(ga, 1, 64), c_right = __shfl_down(ca, 1, 64), v_right = __shfl_down(va, 1, 64);
-        if (lane == 0) v_left = ve;
-        if (lane == 63) { g_right = ge; c_right = ce; v_right = ve; }
-        masks_of(ga, gb, ca, cb, v_left, va, vb, l, mp[0], mm[0]);
-        masks_of(gb, g_right, cb, c_right, va, vb, v_right, l, mp[1], mm[1]);
     }
     uint64_t c = 0;
 #pragma unroll
-    for (int k = 0; k < TILE_WPT; ++k) c += (uint64_t)__popcll(mp[k]) | ((uint64_t)__popcll(mm[k]) << 32);
+    for (int k = 0; k < G::WPT; ++k) c += (uint64_t)__popcll(mp[k]) | ((uint64_t)__popcll(mm[k]) << 32);
     uint64_t total;
-    const uint64_t ex = block_exclusive_scan(c, wave_tot, total);
+    const uint64_t ex = block_exclusive_scan<G::BLOCK / 64>(c, wave_tot, total);
     const uint32_t n_plus = (uint32_t)total, n_minus = (uint32_t)(total >> 32);
     const uint32_t n_all = n_plus + n_minus;
     uint64_t off_plus = 0, off_minus = 0;
@@ -687,22 +694,22 @@ __global__ __launch_bounds__(TILE_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8
     // follows the hit-list build; staging them only now keeps them out of the way of the counts that later tiles wait
     // for (-3.5 %).  (Staging by LDS-DMA, or requesting the words earlier and writing them here, both measured
     // slower: profiles/EXPERIMENTS.md.)
-    for (int k = tid; k < 256; k += TILE_BLOCK) exp_tab[k] = CRP_TABS.exp_tab[k];
+    for (int k = tid; k < 256; k += G::BLOCK) exp_tab[k] = CRP_TABS.exp_tab[k];
     if (LFIX == 20)
-        for (int k = tid; k < CRP_SCORE_TAB_N; k += TILE_BLOCK) score_tab[k] = CRP_TABS.score_tab[k];
-    emit_rounds<LFIX == 20, CHAINED, PRE, SEEDS>(sh, list, exp_tab, score_tab, mp, mm, ex, n_plus, n_minus, l, (uint32_t)(t0 * 64),
+        for (int k = tid; k < CRP_SCORE_TAB_N; k += G::BLOCK) score_tab[k] = CRP_TABS.score_tab[k];
+    emit_rounds<G, LFIX == 20, CHAINED, PRE, SEEDS>(sh, list, exp_tab, score_tab, mp, mm, ex, n_plus, n_minus, l, (uint32_t)(t0 * 64),
                                                  off_plus, off_minus, out, ch);
 }
 
-// Compact the kept hits of one staged tile and score them, LIST_CAP list entries per round.
-template <bool PAM, bool CHAINED, bool PRE, bool SEEDS>
-__device__ __forceinline__ void emit_rounds(uint64_t (*sh)[TILE_WORDS + 2], uint16_t *list, uint64_t *exp_tab, double *score_tab,
-                                            const uint64_t (&mp)[TILE_WPT], const uint64_t (&mm)[TILE_WPT], uint64_t ex,
+// Compact the kept hits of one staged tile and score them, G::LIST list entries per round.
+template <class G, bool PAM, bool CHAINED, bool PRE, bool SEEDS>
+__device__ __forceinline__ void emit_rounds(uint64_t (*sh)[G::WORDS + 2], uint16_t *list, uint64_t *exp_tab, double *score_tab,
+                                            const uint64_t (&mp)[G::WPT], const uint64_t (&mm)[G::WPT], uint64_t ex,
                                             uint32_t n_plus, uint32_t n_minus, int l, uint32_t tile_pos,
                                             uint64_t off_plus, uint64_t off_minus, const HitTables &out,
                                             const ChainArgs &ch)
 {
-    constexpr uint32_t CAP = LIST_CAP;
+    constexpr uint32_t CAP = G::LIST;
     const int tid = threadIdx.x;
     const uint32_t n_all = n_plus + n_minus;
     TileStores ts;
@@ -724,24 +731,26 @@ __device__ __forceinline__ void emit_rounds(uint64_t (*sh)[TILE_WORDS + 2], uint
             // every entry of this round fits: no per-entry capacity test
             const bool with_plus = !by_strand || lo_rank == 0, with_minus = !by_strand || lo_rank != 0;
             uint32_t ap = list_lds + 2 * rp0, am = list_lds + 2 * rm0;
+            if (G::OWNERS == G::BLOCK || tid < G::OWNERS) {  // (wave-uniform; the other waves own no words, hence list nothing)
 #pragma unroll
-            for (int k = 0; k < TILE_WPT; ++k) {
-                const uint32_t wbase = (uint32_t)(tid * TILE_WPT + k) * 64u;
-                if (with_plus) {
-                    peel32((uint32_t)mp[k], wbase, ap);
-                    peel32((uint32_t)(mp[k] >> 32), wbase + 32, ap);
-                }
-                if (with_minus) {
-                    peel32((uint32_t)mm[k], wbase, am);
-                    peel32((uint32_t)(mm[k] >> 32), wbase + 32, am);
+                for (int k = 0; k < G::WPT; ++k) {
+                    const uint32_t wbase = (uint32_t)(tid * G::WPT + k) * 64u;
+                    if (with_plus) {
+                        peel32((uint32_t)mp[k], wbase, ap);
+                        peel32((uint32_t)(mp[k] >> 32), wbase + 32, ap);
+                    }
+                    if (with_minus) {
+                        peel32((uint32_t)mm[k], wbase, am);
+                        peel32((uint32_t)(mm[k] >> 32), wbase + 32, am);
+                    }
                 }
             }
         } else {
-            // rare (a tile with more than LIST_CAP hits on ONE strand: poly-G and the like): windows of CAP ranks
+            // rare (a tile with more than G::LIST hits on ONE strand: poly-G and the like): windows of CAP ranks
             uint32_t rp = rp0, rm = rm0;
 #pragma unroll
-            for (int k = 0; k < TILE_WPT; ++k) {
-                const uint32_t wbase = (uint32_t)(tid * TILE_WPT + k) * 64u;
+            for (int k = 0; k < G::WPT; ++k) {
+                const uint32_t wbase = (uint32_t)(tid * G::WPT + k) * 64u;
                 for (uint64_t m = mp[k]; m; m &= m - 1, ++rp)
                     if (rp < CAP) list[rp] = (uint16_t)(wbase + __builtin_ctzll(m));
                 for (uint64_t m = mm[k]; m; m &= m - 1, ++rm)
@@ -840,7 +849,7 @@ __device__ __forceinline__ void emit_rounds(uint64_t (*sh)[TILE_WORDS + 2], uint
             before_first_store(any);
             if (any) {
                 store(first);
-                for (k += TILE_BLOCK; k < n_round; k += TILE_BLOCK) store(score(fetch(k)));
+                for (k += G::BLOCK; k < n_round; k += G::BLOCK) store(score(fetch(k)));
             }
         };
         if (!CHAINED) {
@@ -850,7 +859,7 @@ __device__ __forceinline__ void emit_rounds(uint64_t (*sh)[TILE_WORDS + 2], uint
             // also resolves the tile's prefix.  So wave 0 takes the chunks of 64 rows nobody would miss: waves 1 ... 7
             // own chunks 0 ... 6 (mod 8) and wave 0 chunk 7 -- when the row count is not a multiple of 512 it is
             // wave 0 that has one chunk less, not one more.
-            const uint32_t k0 = (uint32_t)(tid & 63) | ((((uint32_t)tid >> 6) + (TILE_BLOCK / 64 - 1)) % (TILE_BLOCK / 64)) << 6;
+            const uint32_t k0 = (uint32_t)(tid & 63) | ((((uint32_t)tid >> 6) + (G::BLOCK / 64 - 1)) % (G::BLOCK / 64)) << 6;
             // the whole look-back BEFORE wave 0 scores anything (nothing of the scorer is live then)
             if (lo_rank == 0 && tid < 64) chain_resolve(ch);
             // The other waves score their first rows meanwhile and need the offsets only to STORE them: by then
@@ -1041,15 +1050,30 @@ __global__ __launch_bounds__(BLOCK) void pack_groups_kernel(const uint8_t *__res
 }
 
 // ------------------------------------------------------------ launch wrappers
-hipError_t launch_count(hipStream_t s, const Planes &pl, uint64_t n_words_padded, int l, uint2 *tile_cnt,
+template <class G>
+static hipError_t launch_count_geo(hipStream_t s, const Planes &pl, uint64_t n_words_padded, int l, uint2 *tile_cnt, uint32_t n_tiles)
+{
+    if (l == 20)
+        hipLaunchKernelGGL((count_kernel<G, 20>), dim3(n_tiles), dim3(G::BLOCK), 0, s, pl, n_words_padded, l, tile_cnt);
+    else
+        hipLaunchKernelGGL((count_kernel<G, 0>), dim3(n_tiles), dim3(G::BLOCK), 0, s, pl, n_words_padded, l, tile_cnt);
+    return hipGetLastError();
+}
+
+#define CRP_BY_GEOMETRY(geo, CALL)                 \
+    switch (geo) {                                 \
+        case GEO_LARGE: return CALL(GeoLarge);     \
+        case GEO_SMALL: return CALL(GeoSmall);     \
+        default: return hipErrorInvalidValue;      \
+    }
+
+hipError_t launch_count(hipStream_t s, int geo, const Planes &pl, uint64_t n_words_padded, int l, uint2 *tile_cnt,
                         uint32_t n_tiles)
 {
     if (n_tiles == 0) return hipSuccess;
-    if (l == 20)
-        hipLaunchKernelGGL(count_kernel<20>, dim3(n_tiles), dim3(TILE_BLOCK), 0, s, pl, n_words_padded, l, tile_cnt);
-    else
-        hipLaunchKernelGGL(count_kernel<0>, dim3(n_tiles), dim3(TILE_BLOCK), 0, s, pl, n_words_padded, l, tile_cnt);
-    return hipGetLastError();
+#define CRP_CALL(G) launch_count_geo<G>(s, pl, n_words_padded, l, tile_cnt, n_tiles)
+    CRP_BY_GEOMETRY(geo, CRP_CALL)
+#undef CRP_CALL
 }
 
 // one workgroup per chunk of SCAN_CHUNK_TILES tiles
@@ -1061,19 +1085,19 @@ hipError_t launch_tile_scan(hipStream_t s, const uint2 *tile_cnt, uint32_t n_til
     return hipGetLastError();
 }
 
-// the emit kernel's variants: guide length 20 (compile-time windows, chain-prefix tables) or any; with or without the
-// pre-sigmoid column; with or without the off-target scan's seed words (l = 20 only)
-template <bool CHAINED>
+// the emit kernel's variants: the tile geometry; guide length 20 (compile-time windows, chain-prefix tables) or any; with
+// or without the pre-sigmoid column; with or without the off-target scan's seed words (l = 20 only)
+template <class G, bool CHAINED>
 static hipError_t launch_emit_variant(hipStream_t s, const Planes &pl, uint64_t n_words_padded, int l, const uint2 *tile_off,
                                       uint64_t *chain, uint64_t *chain_next, const HitTables &out, uint32_t mute_tile,
                                       uint32_t timeout_ticks)
 {
-    const uint32_t n_tiles = (uint32_t)(n_words_padded / TILE_WORDS);
+    const uint32_t n_tiles = (uint32_t)(n_words_padded / G::WORDS);
     if (n_tiles == 0) return hipSuccess;
     const bool pre = out.pre_plus != nullptr, seeds = out.seed_plus != nullptr;
     if (seeds && l != 20) return hipErrorInvalidValue;
-#define CRP_LAUNCH(LFIX, PRE, SEEDS)                                                                                      \
-    hipLaunchKernelGGL((emit_kernel<CHAINED, LFIX, PRE, SEEDS>), dim3(n_tiles), dim3(TILE_BLOCK), 0, s, pl, n_words_padded, l, \
+#define CRP_LAUNCH(LFIX, PRE, SEEDS)                                                                                       \
+    hipLaunchKernelGGL((emit_kernel<G, CHAINED, LFIX, PRE, SEEDS>), dim3(n_tiles), dim3(G::BLOCK), 0, s, pl, n_words_padded, l, \
                        tile_off, chain, chain_next, out, mute_tile, timeout_ticks)
     if (l == 20) {
         if (seeds) {
@@ -1091,19 +1115,25 @@ static hipError_t launch_emit_variant(hipStream_t s, const Planes &pl, uint64_t 
     return hipGetLastError();
 }
 
-hipError_t launch_emit(hipStream_t s, const Planes &pl, uint64_t n_words_padded, int l, const uint2 *tile_off,
+hipError_t launch_emit(hipStream_t s, int geo, const Planes &pl, uint64_t n_words_padded, int l, const uint2 *tile_off,
                        const HitTables &out)
 {
-    return launch_emit_variant<false>(s, pl, n_words_padded, l, tile_off, nullptr, nullptr, out, 0xffffffffu, 0u);
+#define CRP_CALL(G) launch_emit_variant<G, false>(s, pl, n_words_padded, l, tile_off, nullptr, nullptr, out, 0xffffffffu, 0u)
+    CRP_BY_GEOMETRY(geo, CRP_CALL)
+#undef CRP_CALL
 }
 
 size_t chain_bytes(uint32_t n_tiles) { return (CHAIN_HEADER_WORDS + (size_t)n_tiles) * sizeof(uint64_t); }
 
-hipError_t launch_emit_chained(hipStream_t s, const Planes &pl, uint64_t n_words_padded, int l, uint64_t *chain,
+hipError_t launch_emit_chained(hipStream_t s, int geo, const Planes &pl, uint64_t n_words_padded, int l, uint64_t *chain,
                                uint64_t *chain_next, const HitTables &out, uint32_t mute_tile, uint32_t timeout_ticks)
 {
-    return launch_emit_variant<true>(s, pl, n_words_padded, l, nullptr, chain, chain_next, out, mute_tile, timeout_ticks);
+#define CRP_CALL(G) launch_emit_variant<G, true>(s, pl, n_words_padded, l, nullptr, chain, chain_next, out, mute_tile, timeout_ticks)
+    CRP_BY_GEOMETRY(geo, CRP_CALL)
+#undef CRP_CALL
 }
+
+int tile_words(int geo) { return geo == GEO_SMALL ? GeoSmall::WORDS : GeoLarge::WORDS; }
 
 hipError_t launch_score30(hipStream_t s, const uint8_t *rows, uint64_t n, int order, double *pre, double *score)
 {

@@ -113,6 +113,13 @@ class Arena:
                   "crp_arena_stats")
         return dict(n_contigs=a.value, n_chars=b.value, n_words=c.value)
 
+    def tiles(self):
+        """dict(geometry="large" | "small", n_tiles, tile_words): the tile shape this arena was sealed with."""
+        g, n, w = ctypes.c_int(), ctypes.c_uint64(), ctypes.c_uint64()
+        nat.check(nat.lib().crp_arena_tiles(self._h, ctypes.byref(g), ctypes.byref(n), ctypes.byref(w)), "crp_arena_tiles")
+        name = [k for k, v in nat.GEOMETRIES.items() if v == g.value][0]
+        return dict(geometry=name, n_tiles=int(n.value), tile_words=int(w.value))
+
     def scan_score_device(self, guide_len=20, want_pre=False, want_seeds=False):
         """Run the kernels; tables stay in HBM.  Returns (n_plus, n_minus).  want_seeds: the scan also writes the
         seed words the off-target step works on (CRP_SCAN_SEEDS; offtarget_add then skips its own pass over the
@@ -367,7 +374,7 @@ class Engine:
             score[base:base + 2] = self.score_30mers(sequences[base:base + 2], nat.ORDER_TAIL2)[1]
         return score
 
-    def configure(self, two_pass=None, chain_timeout_us=None):
+    def configure(self, two_pass=None, chain_timeout_us=None, geometry=None):
         """two_pass=False (the default): one launch per scan, table offsets from the chained
         scan inside the emit kernel; True: the count / tile-scan / emit launch sequence.
         Same results either way (every GPU parity test runs in both modes).
@@ -376,6 +383,8 @@ class Engine:
             nat.check(nat.lib().crp_configure(self._ctx, nat.OPT_TWO_PASS, int(bool(two_pass))), "crp_configure")
         if chain_timeout_us is not None:
             nat.check(nat.lib().crp_configure(self._ctx, nat.OPT_CHAIN_TIMEOUT_US, int(chain_timeout_us)), "crp_configure")
+        if geometry is not None:  # "auto" | "large" | "small": the tile shape of arenas sealed from now on
+            nat.check(nat.lib().crp_configure(self._ctx, nat.OPT_TILE_GEOMETRY, nat.GEOMETRIES[geometry]), "crp_configure")
 
     def query(self):
         """Fallback and communicator state: chain_timeouts (single-launch scans repeated as three

@@ -115,6 +115,9 @@ int crp_arena_add_contig_packed(crp_arena *arena, const uint64_t *hi, const uint
                                 uint64_t *arena_offset);
 /* No more contigs; waits for the uploads. */
 int crp_arena_seal(crp_arena *arena);
+/* The tile shape the arena was sealed with (1 LARGE, 2 SMALL: CRP_OPT_TILE_GEOMETRY), its number of tiles
+ * (= workgroups per scan) and the words of one tile.  Any pointer may be NULL. */
+int crp_arena_tiles(const crp_arena *arena, int *geometry, uint64_t *n_tiles, uint64_t *tile_words);
 /* Totals: contigs, characters, words used. */
 int crp_arena_stats(const crp_arena *arena, uint64_t *n_contigs, uint64_t *n_chars, uint64_t *n_words);
 
@@ -377,6 +380,13 @@ int crp_offtarget_seeds(crp_arena *arena, uint32_t *seeds_plus, uint32_t *seeds_
  * tries the single launch again.  Only after three such scans in a row does the context stay with
  * three launches (crp_query reports both). */
 #define CRP_OPT_CHAIN_TIMEOUT_US 2
+/* CRP_OPT_TILE_GEOMETRY (default 0): the tile shape crp_arena_seal gives the arenas sealed AFTER the call.  The scan works
+ * tile by tile, one workgroup per tile; results do not depend on the shape, time does:
+ *   0  by the arena's size against the GPU: SMALL when the arena holds fewer than 1.5 LARGE tiles per CU (E. coli-like:
+ *      one tile's life is the whole kernel), LARGE otherwise
+ *   1  LARGE   512 threads on 1 024 words (65 536 positions), two words per lane: the throughput shape
+ *   2  SMALL   512 threads on 512 words, one word per lane: half the rows per lane, half the tile's life */
+#define CRP_OPT_TILE_GEOMETRY 3
 int crp_configure(crp_ctx *ctx, int option, int64_t value);
 
 /* Read-only state, for logs and bench output. */

@@ -30,13 +30,15 @@ def _engine():
     eng.close()
 
 
-@pytest.fixture(params=["single_pass", "two_pass"])
+@pytest.fixture(params=["single_pass-large", "single_pass-small", "two_pass-large", "two_pass-small"])
 def engine(_engine, request):
-    """Every parity test runs in both scan modes: the default single launch (offsets from the
-    chained scan inside the emit kernel) and the count / tile-scan / emit sequence."""
-    _engine.configure(two_pass=request.param == "two_pass")
+    """Every parity test runs in both scan modes -- the default single launch (offsets from the chained scan inside the
+    emit kernel) and the count / tile-scan / emit sequence -- and with each of the two tile geometries forced
+    (CRP_OPT_TILE_GEOMETRY; by default crp_arena_seal picks one by the arena's size, and these inputs are all small)."""
+    mode, geometry = request.param.split("-")
+    _engine.configure(two_pass=mode == "two_pass", geometry=geometry)
     yield _engine
-    _engine.configure(two_pass=False)
+    _engine.configure(two_pass=False, geometry="auto")
 
 
 def bits(a):
@@ -498,8 +500,8 @@ def _table_digest(h):
 
 
 @pytest.mark.slow
-@pytest.mark.parametrize("config", ["tair10", "sorghum", "switchgrass"])
-def test_baseline_config_workloads_whole_genome_digest(_engine, oracle, config):
+@pytest.mark.parametrize("config,geometry", [("tair10", "auto"), ("tair10", "small"), ("sorghum", "auto"), ("switchgrass", "auto")])
+def test_baseline_config_workloads_whole_genome_digest(_engine, oracle, config, geometry):
     """Configs 3, 4 and 5 of BASELINE.json WHOLE: the oracle is streamed over every
     contig on the host's cores (it is the checker; ctypes releases the GIL) while the contigs are uploaded,
     and the SHA-256 of (positions, scores) per strand of every contig must equal the digest of the GPU's
@@ -508,7 +510,7 @@ def test_baseline_config_workloads_whole_genome_digest(_engine, oracle, config):
     from concurrent.futures import ThreadPoolExecutor
     import bench_workload as bw
     wl = {"tair10": bw.tair10_like, "sorghum": bw.sorghum_like, "switchgrass": bw.switchgrass_like}[config]()
-    _engine.configure(two_pass=False)
+    _engine.configure(two_pass=False, geometry=geometry)  # (auto: LARGE for all three; SMALL forced once)
     threads = max(2, min(16, len(os.sched_getaffinity(0))))
     builder = _engine.arena_builder([s.length + 4 for s in wl.specs])
     want = []
@@ -521,6 +523,9 @@ def test_baseline_config_workloads_whole_genome_digest(_engine, oracle, config):
             while sum(not f.done() for f in want) > threads + 2:  # bound the strings kept alive
                 [f for f in want if not f.done()][0].result()
         arena = builder.seal()
+        _engine.configure(geometry="auto")
+        tiles = arena.tiles()
+        assert tiles["geometry"] == (geometry if geometry != "auto" else "large")
         hits = arena.scan_score(20, want_pre=False)
         want = [f.result() for f in want]
     got = [_table_digest(hits.contig(k)) for k in range(len(wl.specs))]
@@ -529,8 +534,8 @@ def test_baseline_config_workloads_whole_genome_digest(_engine, oracle, config):
     bad = [k for k in range(len(want)) if want[k] != got[k]]
     assert not bad, (config, "contigs whose tables differ from the oracle's", bad[:10])
     assert n_hits > {"tair10": 7_000_000, "sorghum": 25_000_000, "switchgrass": 50_000_000}[config]
-    print("whole-genome digest %s: %d contigs, %d hits, sha256 of digests %s"
-          % (config, len(want), n_hits, hashlib.sha256("".join(got).encode()).hexdigest()))
+    print("whole-genome digest %s (%s tiles x %d): %d contigs, %d hits, sha256 of digests %s"
+          % (config, tiles["geometry"], tiles["n_tiles"], len(want), n_hits, hashlib.sha256("".join(got).encode()).hexdigest()))
 
 
 def test_many_small_contigs_between_large_ones(engine, oracle):
@@ -868,41 +873,42 @@ def test_bench_starts_its_own_ranks(launcher):
     assert all(r["tiles"] > 0 and r["kernel_ms"] > 0 for r in st["per_rank"])
 
 
-def test_bench_six_ranks_on_the_one_gpu():
+def test_bench_five_ranks_on_the_one_gpu():
     """The first real multi-GPU run will start N HIP contexts, N arenas and N rendezvous clients with real skew; rehearsed
-    here with SIX self-launched ranks on the one GPU -- the most processes the GPU pool lets one job put on a card
-    (VERDICT r03 asked for eight; world 8 runs on the CPU in tests/test_distributed.py, and `--gpus 8` is the driver's to
-    start).  One line, six per-rank entries, the host-transport gatherv and the strong-scaling block's digest check green,
-    status 0."""
+    here with FIVE self-launched ranks on the one GPU -- the GPU pool lets one job keep six processes on a card, and the
+    test runner itself holds the GPU (VERDICT r03 asked for eight; world 8 runs on the CPU in tests/test_distributed.py,
+    and `--gpus 8` is the driver's to start).  One line, five per-rank entries, the host-transport gatherv and the
+    strong-scaling block's digest check green, status 0."""
     import json
     import subprocess
     import sys
     from conftest import ROOT
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "CROPSR_LAUNCHED")}
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "6", "--share-gpu0", "--scale", "0.05",
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "5", "--share-gpu0", "--scale", "0.05",
                         "--steps", "3", "--warmup", "1", "--offtarget-steps", "0"],
                        capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 6 and d["gatherv_ok"] is True and d["value"] > 0
-    assert [r["rank"] for r in d["per_rank"]] == list(range(6))
+    assert d["n_gpus"] == 5 and d["gatherv_ok"] is True and d["value"] > 0
+    assert [r["rank"] for r in d["per_rank"]] == list(range(5))
     assert all(r["kernel_ms"] > 0 and r["kept_hits"] > 0 and r["rendezvous_s"] >= 0 and r["device_hbm_in_use_GiB"] > 0 for r in d["per_rank"])
     st = d["strong"]
-    assert st["digest_ok"] is True and len(st["per_rank"]) == 6 and st["kept_hits"] == st["n1"]["kept_hits"], st
+    assert st["digest_ok"] is True and len(st["per_rank"]) == 5 and st["kept_hits"] == st["n1"]["kept_hits"], st
     shares = [r["bases"] for r in st["per_rank"]]
     assert max(shares) - min(shares) <= 6 * 4096 * 2
-    print("six ranks on one GPU: rendezvous %.2f-%.2f s, device HBM in use %.2f GiB; strong: scan %.3f ms + gatherv %.1f ms"
+    print("five ranks on one GPU: rendezvous %.2f-%.2f s, device HBM in use %.2f GiB; strong: scan %.3f ms + gatherv %.1f ms"
           % (min(r["rendezvous_s"] for r in d["per_rank"]), max(r["rendezvous_s"] for r in d["per_rank"]),
              max(r["device_hbm_in_use_GiB"] for r in d["per_rank"]), st["ms_scan_max_rank"], st["ms_gatherv"]))
 
 
 @pytest.mark.slow
-def test_cli_six_ranks_tair10_like_offtarget_equals_one_process(tmp_path):
-    """`python -m cropsr_amd --gpus 6 --offtarget` (no launcher) on the TAIR10-like FASTA, every chromosome cut into 5 Mb pieces
-    (halos, stitching, owned ranges for the site histogram, histograms summed over the ranks), all six ranks on the one GPU
-    over the host transport: the CSV has the md5 of the one-process run (1.1 GB, 7.7 M rows)."""
+def test_cli_five_ranks_tair10_like_offtarget_equals_one_process(tmp_path):
+    """`python -m cropsr_amd --gpus 5 --offtarget` (no launcher) on the TAIR10-like FASTA, every chromosome cut into 5 Mb pieces
+    (halos, stitching, owned ranges for the site histogram, histograms summed over the ranks), all five ranks on the one GPU
+    over the host transport (five: the pool's limit of six processes per card, less the test runner): the CSV has the md5 of
+    the one-process run (1.1 GB, 7.7 M rows)."""
     import hashlib
     import subprocess
     import sys
@@ -934,15 +940,15 @@ def test_cli_six_ranks_tair10_like_offtarget_equals_one_process(tmp_path):
     want = md5(out)
     os.remove(out)
     t0 = time.time()
-    q = subprocess.run([sys.executable, "-m", "cropsr_amd", "--gpus", "6", "-o", out] + common, capture_output=True, text=True,
+    q = subprocess.run([sys.executable, "-m", "cropsr_amd", "--gpus", "5", "-o", out] + common, capture_output=True, text=True,
                        timeout=900, cwd=str(tmp_path), env=dict(env, CROPSR_GATHER="host", CROPSR_DIST_MAX_PIECE="5000000"))
     assert q.returncode == 0, q.stderr[-2000:]
-    t_six = time.time() - t0
+    t_five = time.time() - t0
     got = md5(out)
     os.remove(out)
     assert got == want and want[1] > 1_000_000_000
-    print("TAIR10-like --offtarget: one process %.1f s, six ranks on one GPU (5 Mb pieces, host transport) %.1f s, md5 %s"
-          % (t_one, t_six, want[0]))
+    print("TAIR10-like --offtarget: one process %.1f s, five ranks on one GPU (5 Mb pieces, host transport) %.1f s, md5 %s"
+          % (t_one, t_five, want[0]))
 
 
 def test_bench_prints_its_line_when_the_exchange_never_returns():
