@@ -323,6 +323,19 @@ def strong_scaling_block(args, eng, group, use_rccl, fence, reduce):
     return out
 
 
+def load_offtarget_traffic(build_id, workload):
+    """Counter traffic of the off-target block per step and stage (tools/pmc_calibrate.sh -> profiles/offtarget_traffic.json),
+    used only if it was measured on THIS build and workload."""
+    path = os.path.join(ROOT, "profiles", "offtarget_traffic.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        tj = json.load(f)
+    if tj.get("workload") != workload or tj.get("build_id") != build_id:
+        return None
+    return tj
+
+
 def main():
     args = parse_args()
     from cropsr_amd import launch
@@ -548,11 +561,22 @@ def main():
         if strong is not None:
             line["strong"] = strong
         if ot is not None:
-            if facts and "roofline" in ot:
-                # counter traffic exists for the ball passes only (streaming reads, where the gfx950 FETCH_SIZE correction
-                # is calibrated); the look-up's gathers and the partition's scatters are not calibrated: whole step = null
-                ot["roofline"]["stage_traffic"] = {"ball_passes": facts.get("offtarget_ball_hbm_bytes_per_step")}
-                ot["roofline"]["traffic_source"] = facts_src
+            tj = load_offtarget_traffic(build_id, genomes[0].name) if "roofline" in ot else None
+            if tj:
+                # counter traffic per step and stage; the FETCH_SIZE correction is calibrated for this block's access
+                # patterns (streams, random 16-byte gathers: every line that reaches the fabric is tallied at half its size)
+                r = ot["roofline"]
+                r["traffic"] = tj.get("traffic_bytes_per_step")
+                r["stage_traffic"] = tj.get("stage_traffic_bytes_per_step")
+                r["stage_traffic_over_algorithmic"] = tj.get("stage_traffic_over_algorithmic")
+                r["traffic_source"] = "profiles/offtarget_traffic.json: " + tj.get("correction", "")
+                if r.get("traffic") and ot.get("kernels_ms"):
+                    k = ot["kernels_ms"]
+                    ms = k["ot_seed"] + k["ot_ball"] + k["ot_lookup"]
+                    # what the memory system actually moves per second (whole 128-byte lines for every 16-byte gather)
+                    r["traffic_GBs"] = r["traffic"] / (ms * 1e-3) / 1e9
+                    if r["stage_traffic"].get("lookup_gather") and k["ot_lookup"]:
+                        r["lookup_gather_traffic_GBs"] = r["stage_traffic"]["lookup_gather"] / (k["ot_lookup"] * 1e-3) / 1e9
             line["offtarget"] = ot
         if gather_info is not None:
             line["gatherv_ok"] = "s" in gather_info

@@ -62,28 +62,37 @@ __device__ __forceinline__ uint32_t annot_one(uint32_t pos, double score, uint32
     return lo ? ids[lo - 1] : CRP_NO_FEATURE;
 }
 
-// back: 3 for the '+' table (cut site = i - 3), 0 for the '-' table (cut site = j)
-__global__ __launch_bounds__(BLOCK) void annot_lookup_kernel(const uint32_t *__restrict__ pos, const double *__restrict__ score,
-                                                             uint64_t n, uint32_t back, const uint32_t *__restrict__ points,
-                                                             const uint32_t *__restrict__ ids,
-                                                             const uint32_t *__restrict__ bucket, uint32_t last_bucket,
-                                                             uint32_t *__restrict__ feat)
+// One launch for both tables: the first blocks_plus workgroups walk the '+' table (cut site = i - 3), the others the '-'
+// table (cut site = j).
+struct AnnotTable {
+    const uint32_t *pos;
+    const double *score;
+    uint32_t *feat;
+    uint64_t n;
+};
+
+__global__ __launch_bounds__(BLOCK) void annot_lookup_kernel(AnnotTable plus, AnnotTable minus, uint32_t blocks_plus,
+                                                             const uint32_t *__restrict__ points, const uint32_t *__restrict__ ids,
+                                                             const uint32_t *__restrict__ bucket, uint32_t last_bucket)
 {
-    const uint64_t first = ((uint64_t)blockIdx.x * BLOCK + threadIdx.x) * ANN_ROWS;
-    if (first >= n) return;
-    if (first + ANN_ROWS <= n) {
+    const bool is_minus = blockIdx.x >= blocks_plus;  // (uniform per workgroup)
+    const AnnotTable t = is_minus ? minus : plus;
+    const uint32_t back = is_minus ? 0u : 3u;
+    const uint64_t first = ((uint64_t)(blockIdx.x - (is_minus ? blocks_plus : 0u)) * BLOCK + threadIdx.x) * ANN_ROWS;
+    if (first >= t.n) return;
+    if (first + ANN_ROWS <= t.n) {
         // the tables are read once and the ids written once: keep them out of the way of the track and its index
-        const u32x4 p = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(pos + first));
-        const f64x2 s0 = __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(score + first));
-        const f64x2 s1 = __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(score + first + 2));
+        const u32x4 p = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(t.pos + first));
+        const f64x2 s0 = __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(t.score + first));
+        const f64x2 s1 = __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(t.score + first + 2));
         u32x4 f;
         f.x = annot_one(p.x, s0.x, back, points, ids, bucket, last_bucket);
         f.y = annot_one(p.y, s0.y, back, points, ids, bucket, last_bucket);
         f.z = annot_one(p.z, s1.x, back, points, ids, bucket, last_bucket);
         f.w = annot_one(p.w, s1.y, back, points, ids, bucket, last_bucket);
-        __builtin_nontemporal_store(f, reinterpret_cast<u32x4 *>(feat + first));
+        __builtin_nontemporal_store(f, reinterpret_cast<u32x4 *>(t.feat + first));
     } else {
-        for (uint64_t r = first; r < n; ++r) feat[r] = annot_one(pos[r], score[r], back, points, ids, bucket, last_bucket);
+        for (uint64_t r = first; r < t.n; ++r) t.feat[r] = annot_one(t.pos[r], t.score[r], back, points, ids, bucket, last_bucket);
     }
 }
 
@@ -142,13 +151,14 @@ int crp_annotate_lookup(crp_arena *a, uint32_t *feat_plus, uint32_t *feat_minus)
         if (rc != CRP_OK) return rc;
     }
     crp::prof_begin(ctx, CRP_K_ANNOTATE);
-    for (int s = 0; s < 2; ++s) {
-        const uint64_t n = a->n_hits[s];
-        if (!n) continue;
+    {
         const uint64_t per_block = (uint64_t)crp::BLOCK * crp::ANN_ROWS;
-        hipLaunchKernelGGL(crp::annot_lookup_kernel, dim3((uint32_t)((n + per_block - 1) / per_block)), dim3(crp::BLOCK), 0,
-                           ctx->stream, a->d_pos[s], a->d_score[s], n, s == 0 ? 3u : 0u, a->d_ann_points, a->d_ann_ids,
-                           a->d_ann_bucket, (uint32_t)(a->n_ann_entries - 2), a->d_feat[s]);
+        const uint32_t bp = (uint32_t)((a->n_hits[0] + per_block - 1) / per_block), bm = (uint32_t)((a->n_hits[1] + per_block - 1) / per_block);
+        const crp::AnnotTable plus{a->d_pos[0], a->d_score[0], a->d_feat[0], a->n_hits[0]};
+        const crp::AnnotTable minus{a->d_pos[1], a->d_score[1], a->d_feat[1], a->n_hits[1]};
+        if (bp + bm)
+            hipLaunchKernelGGL(crp::annot_lookup_kernel, dim3(bp + bm), dim3(crp::BLOCK), 0, ctx->stream, plus, minus, bp,
+                               a->d_ann_points, a->d_ann_ids, a->d_ann_bucket, (uint32_t)(a->n_ann_entries - 2));
     }
     CRP_HIP(ctx, hipGetLastError());
     crp::prof_end(ctx, CRP_K_ANNOTATE);

@@ -418,7 +418,7 @@ int crp_profile_read(crp_ctx *ctx, double ms[3], uint64_t launches[3], int reset
 #define CRP_K_OT_LOOKUP 5    /* off-target: per-hit counts */
 #define CRP_K_GATHER 6       /* RCCL gatherv of the hit tables (count all-gather + grouped send/recv) */
 #define CRP_K_OT_REDUCE 7    /* RCCL all-reduce of the site histogram */
-#define CRP_K_ANNOTATE 8     /* annotation join: both look-up launches of one crp_annotate_lookup */
+#define CRP_K_ANNOTATE 8     /* annotation join: the look-up kernel of one crp_annotate_lookup (both tables, one launch) */
 #define CRP_K_KINDS 9
 int crp_profile_read_kind(crp_ctx *ctx, int kind, double *ms, uint64_t *launches, int reset);
 /* Blocks until everything queued on the library's stream has finished. */

@@ -85,16 +85,20 @@ def main():
     argv += a.cli_flag
     if a.procs > 1:
         import subprocess
-        env = dict(os.environ, CROPSR_GATHER="host", PYTHONPATH=ROOT)  # all ranks on device 0: RCCL cannot run
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.procs),
-               "--master-addr", "127.0.0.1", "--master-port", "29551", "-m", "cropsr_amd"] + argv + ["--device", "0"]
+        # the CLI starts its own ranks (cropsr_amd/launch.py); all of them on device 0 here, tables over the host transport
+        # (RCCL cannot put two ranks on one GPU).  Rank 0 writes the stage timings (--bench-json).
+        stages_json = os.path.join(tmp, "stages_procs.json")
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "CROPSR_LAUNCHED")}
+        env.update(CROPSR_GATHER="host", PYTHONPATH=ROOT)
+        cmd = [sys.executable, "-m", "cropsr_amd", "--gpus", str(a.procs)] + argv + ["--device", "0", "--bench-json", stages_json]
         t0 = time.time()
         p = subprocess.run(cmd, cwd=tmp, env=env, capture_output=True, text=True)
         wall = time.time() - t0
         if p.returncode != 0:
             sys.exit(p.stderr[-3000:])
         size = os.path.getsize(out_csv)
-        print(json.dumps({"workload": wl.name, "procs": a.procs, "csv_bytes": size, "wall_incl_process_start_s": round(wall, 3),
+        print(json.dumps({"workload": wl.name, "procs": a.procs, "transport": "host sockets (ranks share GPU 0)", "csv_bytes": size,
+                          "wall_incl_process_start_s": round(wall, 3), "phases": json.load(open(stages_json)),
                           "gff_gene_cds_rows": gff_rows, "md5": file_md5(out_csv) if a.md5 else None}))
         os.remove(out_csv)
         os.remove(fa)

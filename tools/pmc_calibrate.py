@@ -67,6 +67,49 @@ def main():
         json.dump({"streaming_read_factor": f_stream, "kernels": stages,
                    "note": "raw = counter x 1024; see fetch_calibration.json for what a tallied byte stands for per access pattern"},
                   fjson, indent=1)
+    # ---- the off-target block, per STEP of bench.py (both strands' launches), corrected as the calibration says:
+    #   reads : FETCH_SIZE tallies every 128-byte line that reaches the fabric at 64 bytes, for streams, strided and random
+    #           gathers alike (fetch_calibration.json: 8 B raw per 16-byte streaming request, 64 B raw per line touched by a
+    #           gather; the gathers' timings show that whole lines move) -> bytes = raw x 2
+    #   writes: WRITE_SIZE is exact for 16-byte streaming stores and tallies 32 bytes per scattered 4- or 16-byte store
+    #           (the partition kernels' scatters) -> bytes = raw, in 32-byte sectors for scatters
+    bench = {}
+    try:
+        bench = json.loads(open(os.path.join(raw, "bench_under_trace.json")).read().strip().splitlines()[-1])
+    except Exception:
+        pass
+
+    def step_bytes(name, launches_per_step):
+        v = stages.get(name)
+        if not v:
+            return None
+        return launches_per_step * (2 * v["FETCH_SIZE_bytes_raw"] + v["WRITE_SIZE_bytes_raw"])
+    groups = {"seed_partition_histogram": [("crp::ot_seed_from_raw_kernel", 2), ("crp::ot_bucket_scan_kernel", 2),
+                                           ("crp::ot_partition1_kernel", 2), ("crp::ot_partition_kernel", 2),
+                                           ("crp::ot_bucket_hist_kernel", 2)],
+              "ball_passes": [("crp::ot_ball_kernel<0, true>", 1), ("crp::ot_ball_kernel<8, false>", 1), ("crp::ot_ball_kernel<16, false>", 1)],
+              "lookup_gather": [("crp::ot_lookup_kernel", 2)]}
+    ot = {}
+    for g, ks in groups.items():
+        vals = [step_bytes(k, n) for k, n in ks]
+        ot[g] = None if any(v is None for v in vals) else sum(vals)
+    algo = (bench.get("offtarget", {}).get("roofline", {}) or {}).get("stage_bytes", {})
+    ot_json = {"workload": bench.get("config", {}).get("workload"), "build_id": bench.get("config", {}).get("library_build"),
+               "stage_traffic_bytes_per_step": ot,
+               "stage_traffic_over_algorithmic": {g: (ot[g] / algo[g] if ot.get(g) and algo.get(g) else None) for g in ot},
+               "traffic_bytes_per_step": None if any(v is None for v in ot.values()) else sum(ot.values()),
+               "lookup_gather_bytes_per_request": (ot["lookup_gather"] / bench["config"]["kept_hits_total"]
+                                                   if ot.get("lookup_gather") and bench.get("config") else None),
+               "correction": "reads = FETCH_SIZE x 1024 x 2 (every line reaching the fabric is tallied at 64 B: calibrated on "
+                             "streams, strided and random 16-byte gathers, profiles/r04/fetch_calibration.json); writes = "
+                             "WRITE_SIZE x 1024 (exact for streaming stores; 32-byte sectors per scattered store)",
+               "source": "tools/pmc_calibrate.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"}
+    ann = stages.get("crp::annot_lookup_kernel")
+    if ann:
+        ot_json["annotate_lookup_traffic_bytes_per_launch"] = 2 * ann["FETCH_SIZE_bytes_raw"] + ann["WRITE_SIZE_bytes_raw"]
+    with open(os.path.join(out, "offtarget_traffic.json"), "w") as fjson:
+        json.dump(ot_json, fjson, indent=1)
+    print(json.dumps(ot_json, indent=1))
     for r in cal:
         print("%-26s %8.3f ms  req %11.0f  fetch/req %7s  write/req %7s  GB/s if whole lines %8.1f" % (
             r["pattern"], r["ms"], r["requests"],
