@@ -1,9 +1,9 @@
 #!/bin/bash
 # The files of profiles/rNN/ that profiles/collect.sh does not write, for the SAME library build:
-#   bash profiles/extras.sh r03 [soak]     (GPU box, repo root; `soak` adds the 1 200-trial fuzz, ~6 minutes)
+#   bash profiles/extras.sh r04 [soak]     (GPU box, repo root; `soak` adds the 900-trial fuzz in all four scan-mode x geometry combinations, ~8 minutes)
 # Everything lands under gpurun_out/profiles_<tag>/; copy it into profiles/<tag>/ beside collect.sh's files.
 set -e
-TAG=${1:-r03}
+TAG=${1:-r04}
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 RAW=gpurun_out/prof_$TAG
@@ -22,15 +22,25 @@ python3 bench.py --workload ecoli --cpu-sample-bases 0 > $OUT/bench_ecoli_like.j
 # N = 2 started by the program itself, both ranks on this one GPU (host transport for fences and the final gatherv)
 python3 bench.py --gpus 2 --share-gpu0 --scale 0.25 --steps 10 --warmup 3 --cpu-sample-bases 0 \
     > $OUT/bench_2ranks_self_launched_one_gpu.json 2> $RAW/2ranks.err
+# six ranks on the one GPU (the most processes the pool lets one job keep on a card), weak headline + strong-scaling block
+python3 bench.py --gpus 6 --share-gpu0 --scale 0.25 --steps 10 --warmup 3 --cpu-sample-bases 0 --offtarget-steps 0 \
+    > $OUT/bench_6ranks_self_launched_one_gpu.json 2> $RAW/6ranks.err
 # the whole CLI end to end (FASTA in, CSV out)
 python3 tools/e2e_cli.py switchgrass > $OUT/e2e_cli_switchgrass_first_process_on_the_box.json 2> $RAW/e2e0.err
 python3 tools/e2e_cli.py switchgrass > $OUT/e2e_cli_switchgrass.json 2> $RAW/e2e1.err
 python3 tools/e2e_cli.py switchgrass --cli-flag=--offtarget > $OUT/e2e_cli_switchgrass_offtarget.json 2> $RAW/e2e2.err
 python3 tools/e2e_cli.py switchgrass --cli-flag=--score-finalize --cli-flag=host > $OUT/e2e_cli_switchgrass_finalize_host.json 2> $RAW/e2e3.err
 python3 tools/e2e_cli.py tair10 --reference-behaviour > $OUT/e2e_cli_tair10_reference_behaviour.json 2> $RAW/e2e4.err
+# BASELINE.json configs[2], [3]: the genomes that come with a GFF (+ annotation_info): --annotate, one process and two
+python3 tools/e2e_cli.py sorghum > $OUT/e2e_cli_sorghum.json 2> $RAW/e2e5.err
+python3 tools/e2e_cli.py sorghum --annotate 34000 > $OUT/e2e_cli_sorghum_annotate.json 2> $RAW/e2e6.err
+python3 tools/e2e_cli.py tair10 --annotate 27000 > $OUT/e2e_cli_tair10_annotate.json 2> $RAW/e2e7.err
+python3 tools/e2e_cli.py sorghum --annotate 34000 --procs 2 > $OUT/e2e_cli_sorghum_annotate_2ranks_one_gpu.json 2> $RAW/e2e8.err
+python3 tools/annotate_bench.py sorghum 34000 > $OUT/annotate_lookup_sorghum.json 2> $RAW/ann1.err
+python3 tools/annotate_bench.py tair10 27000 > $OUT/annotate_lookup_tair10.json 2> $RAW/ann2.err
 { for p in 1 4; do python3 tools/e2e_cli.py tair10 --procs $p --md5 --cli-flag=--offtarget; done; } > $OUT/multi_process_cli_md5.txt 2> $RAW/md5.err
 if [ "$2" = soak ]; then
-  CROPSR_FUZZ_TRIALS=1200 CROPSR_FUZZ_PROGRESS=$RAW/fuzz_progress.txt python3 -m pytest -q tests/test_gpu_parity.py::test_randomised_arenas_vs_oracle \
-      tests/test_offtarget.py::test_gpu_randomised_genomes_vs_oracle > $OUT/fuzz_soak_1200_trials.log 2>&1
+  CROPSR_FUZZ_TRIALS=900 CROPSR_FUZZ_PROGRESS=$RAW/fuzz_progress.txt python3 -m pytest -q tests/test_gpu_parity.py::test_randomised_arenas_vs_oracle \
+      tests/test_offtarget.py::test_gpu_randomised_genomes_vs_oracle > $OUT/fuzz_soak_900_trials_x4_modes.log 2>&1
 fi
 ls -la $OUT

@@ -8,7 +8,7 @@ cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 RAW=gpurun_out/pmc_cal_$TAG
 rm -rf $RAW
-mkdir -p $RAW
+mkdir -p $RAW gpurun_out/profiles_$TAG
 hipcc -O3 --offload-arch=gfx950 profiles/microbench/fetch_calibration.hip -o $RAW/fetch_cal
 $RAW/fetch_cal > $RAW/patterns.jsonl
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $RAW/cal_fetch -- $RAW/fetch_cal > /dev/null 2> $RAW/cal_fetch.err
