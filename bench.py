@@ -529,6 +529,10 @@ def main():
             # holds its SIMD for 4 cycles on average here): issue slots used / issue slots there were
             roof["valu_issue_frac"] = facts["valu_insts_per_launch"] * 4.0 / N_SIMD / facts["kernel_cycles_per_launch"]
             roof["valu_insts_per_launch"] = facts["valu_insts_per_launch"]
+            # the time those instructions alone take at the part's 2.4 GHz peak shader clock: no schedule of THIS
+            # instruction stream is faster
+            roof["valu_floor_ms"] = facts["valu_insts_per_launch"] * 4.0 / N_SIMD / 2.4e6
+            roof["valu_floor_clock_GHz"] = 2.4
         line = {
             "metric": "gRNAs scored/sec", "value": scored_all * args.steps / dt, "unit": "gRNAs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "untimed_steps_before": n_warm,

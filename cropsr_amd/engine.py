@@ -60,11 +60,11 @@ class Hits:
         self.pos_minus, self.pre_minus, self.score_minus = cols[3:6]
         self.ot_plus = self.ot_minus = None  # (n, 4) uint32 once an off-target scan has run
         self.feat_plus = self.feat_minus = None  # uint32 label-set ids once the annotation join has run
-        ends = offsets + lengths
-        self._cut_plus = (np.searchsorted(self.pos_plus, offsets, "left"),
-                          np.searchsorted(self.pos_plus, ends, "left"))
-        self._cut_minus = (np.searchsorted(self.pos_minus, offsets, "left"),
-                           np.searchsorted(self.pos_minus, ends, "left"))
+        # (needles in the tables' own dtype, uint32: arena positions stay below 2^31 -- otherwise numpy converts the tables)
+        starts = np.asarray(offsets).astype(np.uint32)
+        ends = (np.asarray(offsets) + np.asarray(lengths)).astype(np.uint32)
+        self._cut_plus = (np.searchsorted(self.pos_plus, starts, "left"), np.searchsorted(self.pos_plus, ends, "left"))
+        self._cut_minus = (np.searchsorted(self.pos_minus, starts, "left"), np.searchsorted(self.pos_minus, ends, "left"))
 
     @property
     def n_plus(self):

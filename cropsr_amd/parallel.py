@@ -186,8 +186,11 @@ def slice_piece(cols, off, ln):
     """The rows of one text out of an arena's tables (arena positions -> positions in the text)."""
     pp = np.asarray(cols["pos_plus"]).view(np.uint32)
     pm = np.asarray(cols["pos_minus"]).view(np.uint32)
-    a, b = np.searchsorted(pp, [off, off + ln])
-    c, d = np.searchsorted(pm, [off, off + ln])
+    # (needles in the tables' own dtype: with int64 needles numpy converts the WHOLE table for every call -- 10 ms per
+    # piece on a 14 M-row table, 8 s for the 868 pieces of the sorghum-like genome)
+    bounds = np.array([off, off + ln], dtype=np.uint32)
+    a, b = np.searchsorted(pp, bounds)
+    c, d = np.searchsorted(pm, bounds)
     out = dict(pos_plus=pp[a:b] - np.uint32(off), score_plus=np.asarray(cols["score_plus"])[a:b],
                pos_minus=pm[c:d] - np.uint32(off), score_minus=np.asarray(cols["score_minus"])[c:d])
     if "ot_plus" in cols:
