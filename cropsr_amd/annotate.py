@@ -141,7 +141,11 @@ class Annotation:
             nat.lib().crp_annotation_destroy(self._h)
             self._h = None
 
-    __del__ = close
+    def __del__(self):
+        try:  # (at interpreter exit the module globals may already be gone)
+            self.close()
+        except Exception:
+            pass
 
 
 class Request:
