@@ -10,6 +10,8 @@
  *           -> crp_arena_* + crp_scan_score + crp_fetch_hits
  *   seam 2  CROPSR.py:285-313, called at :461  rs1_score(ndarray[n,30] uint8)
  *           -> ndarray[n] float64      -> crp_score_30mers
+ *   seam 3  (opt-in) CROPSR.py:77-95 parses the GFF, :375 drops the table, :466-468 write '' into `features`: the join
+ *           those lines stop short of -> crp_annotation_build / _track (host) + crp_annotate_set_track / _lookup (GPU)
  *
  * The binding a CROPSR maintainer would add (ctypes) is shown in INTEGRATION.md.
  *

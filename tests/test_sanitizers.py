@@ -1,5 +1,5 @@
 """Host-side native code under sanitizers (CPU build only; the GPU pool has no ASan).
-The formatter and the FASTA loader are compiled from source with g++, each with a small driver."""
+The formatter, the FASTA loader and the annotation builder are compiled from source with g++, each with a small driver."""
 import os
 import shutil
 import subprocess
@@ -35,3 +35,10 @@ def test_formatter_under_sanitizers(flags, tmp_path):
 def test_fasta_loader_fuzz_under_sanitizers(flags, piece, tmp_path):
     """3000 random inputs with 1-, 7- and 64-byte pieces against a serial restatement."""
     _build_and_run(flags, tmp_path, "fasta_driver", "crp_fasta.cpp", defines=["-DCRP_FASTA_CHUNK_BYTES=%d" % piece])
+
+
+def test_annotation_builder_fuzz_under_sanitizers(tmp_path):
+    """400 random GFF files (soups and well-formed ones with overlapping / nested / degenerate rows, odd attributes, CRLF,
+    annotation_info) through crp_annotation_build / _track under ASan + UBSan: the label set of every coordinate and of every
+    sampled arena position equals a direct loop over the rows."""
+    _build_and_run("address,undefined", tmp_path, "annotation_driver", "crp_annotation.cpp")
