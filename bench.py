@@ -220,16 +220,21 @@ def strong_scaling_block(args, eng, group, use_rccl, fence, reduce):
         builder.add(views[q][0])
     arena = builder.seal()
     layout = [(q, 0, int(arena.offsets[j]), int(arena.lengths[j])) for j, q in enumerate(mine)]
-    shifts = {q: views[q][1] for q in mine}
     del views
     t_gen = time.perf_counter() - t_gen
 
     def gatherv(n_plus, n_minus):
+        """The exchange proper: on RCCL the tables land in rank 0's HBM (what is timed); their copy to rank 0's host for the
+        stitch-and-digest check is fetch_gathered(), outside the timed region.  The host transport IS a copy to the host."""
         if use_rccl:
-            counts = eng.gather_hits(arena, 0)
-            return [[eng.gathered_fetch(r, counts)] for r in range(world)] if rank == 0 else None
+            return eng.gather_hits(arena, 0)
         cols = arena.fetch(n_plus, n_minus)
         return parallel.gather_host(group, [dict(zip(parallel.COLUMNS, (cols[0], cols[2], cols[3], cols[5])))], 0)
+
+    def fetch_gathered(result):
+        if not use_rccl or rank != 0:
+            return result
+        return [[eng.gathered_fetch(r, result)] for r in range(world)]
 
     n_plus, n_minus = arena.scan_score_device(20)
     scored = arena.count_scored()
@@ -263,6 +268,7 @@ def strong_scaling_block(args, eng, group, use_rccl, fence, reduce):
     gathered = gatherv(n_plus, n_minus)
     fence()
     dt_gather = reduce([time.perf_counter() - tg], "max")[0]
+    gathered = fetch_gathered(gathered)
     hits_all, scored_all = reduce([n_plus + n_minus, scored], "sum")
     out = {"workload": wl.name, "scaling": "strong", "genomes": 1, "steps": steps, "pieces": len(pieces),
            "contigs_cut": int(sum(1 for k in range(len(lengths)) if sum(1 for p in pieces if p[0] == k) > 1)),
@@ -292,7 +298,6 @@ def strong_scaling_block(args, eng, group, use_rccl, fence, reduce):
         del gathered, per_piece
     if check:
         # the N = 1 scan of the same genome on rank 0's GPU (the other ranks wait at the fence)
-        t1 = None
         if rank == 0:
             ref = ref_builder.seal()
             rp, rm = ref.scan_score_device(20)
