@@ -789,6 +789,15 @@ def main():
     _engine.leave_if_comm_stuck(0)  # (a communicator bootstrap that never returned left a thread inside RCCL)
 
 
+def _leave(status):
+    """Every error exit of a process that may have opened the GPU: if a communicator bootstrap never returned
+    (Engine.comm_init), a helper thread still sits inside RCCL and a normal tear-down may wait for it -- os._exit then."""
+    eng_mod = sys.modules.get("cropsr_amd.engine")
+    if eng_mod is not None:
+        eng_mod.leave_if_comm_stuck(status)
+    sys.exit(status)
+
+
 if __name__ == "__main__":
     try:
         main()
@@ -800,6 +809,6 @@ if __name__ == "__main__":
         if g is not None and g.world > 1:
             if isinstance(e, rendezvous.RankError):  # every rank has this error: leave together
                 g.close()
-                sys.exit(1)
+                _leave(1)
             g.abort("%s: %s" % (type(e).__name__, e))
-        sys.exit(1)
+        _leave(1)
