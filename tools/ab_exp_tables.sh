@@ -1,3 +1,9 @@
+# A/B of the "chain tables from global memory" experiment (profiles/EXPERIMENTS.md, round 4).  The three libraries come from a
+# scratch copy of cropsr_amd/csrc with profiles/r04/tables_from_global_experiment.patch applied:
+#   make OUT=../lib_x1.so EXTRA=-DCRP_EXP_TABLES_GLOBAL                                  (same tables, read from global memory)
+#   CRP_TABLE_BITS="fC=11,fG=10" make OUT=../lib_x2.so EXTRA=-DCRP_EXP_TABLES_GLOBAL CRP_TABLE_BITS="fC=11,fG=10"
+#   CRP_TABLE_BITS="fC=11,fG=10,sG=11" make OUT=../lib_x3.so ...                          (after removing the generated .inc files)
+# GPU box, repo root: bash tools/ab_exp_tables.sh -- smoke() on each build (bit-exactness), then three interleaved bench rounds.
 set -e
 out=gpurun_out/r04/exp_tables
 mkdir -p $out
