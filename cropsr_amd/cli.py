@@ -474,14 +474,16 @@ def run(args, backend=None, out=sys.stdout, group=None):
             print("formatting genome", file=out)
             print(f"Genome file {args.f} successfully formatted", file=out)
     table = fasta.table_from_bytes(data)  # == fasta.contig_table(text).items(), without printing the genome
+    stages["read_fasta_s"] = time.perf_counter() - t_stage
     request, request_err = None, None
     if annotating:
+        t_wait = time.perf_counter()
         try:
             request = annotation_request(data, table)
         except Exception as e:  # (single process: raised below, after the reference's own GFF import had its say)
             request_err = e
+        stages["annotation_build_wait_s"] = time.perf_counter() - t_wait  # what the run waits for the helper thread's build
     del data
-    stages["read_fasta_s"] = time.perf_counter() - t_stage
     if verbose:
         print("The genome was successfully converted to a dictionary", file=out)
     t_wait = time.perf_counter()
