@@ -153,12 +153,20 @@ class Request:
     comes from, where the text starts inside that contig's string, and `dec`."""
 
     def __init__(self, annotation, names, dec, starts=None):
-        self.annotation, self.names, self.dec = annotation, list(names), int(dec)
+        """annotation: an Annotation, or a callable that returns one when it is first needed (the CLI builds it on a helper
+        thread and the join only needs it once the scan is done)."""
+        self._annotation, self.names, self.dec = annotation, list(names), int(dec)
         self.starts = [0] * len(self.names) if starts is None else [int(s) for s in starts]
+
+    @property
+    def annotation(self):
+        if callable(self._annotation):
+            self._annotation = self._annotation()
+        return self._annotation
 
     def pieces(self, which, starts):
         """The same request for texts that are pieces of the contigs: which[k] = contig index of text k."""
-        return Request(self.annotation, [self.names[q] for q in which], self.dec, starts)
+        return Request(lambda: self.annotation, [self.names[q] for q in which], self.dec, starts)
 
     def track(self, layout):
         """layout: [(text index, arena offset, length)] of ONE arena in arena order -> (points, ids)."""

@@ -401,7 +401,8 @@ def run(args, backend=None, out=sys.stdout, group=None):
         """annotate.Request for the contig strings of `table` (every rank builds the same one)."""
         from . import annotate
         formatted = 2 * fasta.count_byte(data, b">") != fasta.count_byte(data, b"\n") + 1  # CROPSR.py:61: dec = 1
-        return annotate.Request(early_annot.get(), [annotate.contig_name(k) for k, _ in table], 1 if formatted else 0)
+        # (the Annotation itself is collected from its helper thread when the join first needs it: after the scan)
+        return annotate.Request(early_annot.get, [annotate.contig_name(k) for k, _ in table], 1 if formatted else 0)
 
     if group is not None and group.rank != 0:
         # Ranks other than 0 of a multi-GPU run: read the same FASTA, scan their share of the contigs,
@@ -477,12 +478,10 @@ def run(args, backend=None, out=sys.stdout, group=None):
     stages["read_fasta_s"] = time.perf_counter() - t_stage
     request, request_err = None, None
     if annotating:
-        t_wait = time.perf_counter()
         try:
             request = annotation_request(data, table)
         except Exception as e:  # (single process: raised below, after the reference's own GFF import had its say)
             request_err = e
-        stages["annotation_build_wait_s"] = time.perf_counter() - t_wait  # what the run waits for the helper thread's build
     del data
     if verbose:
         print("The genome was successfully converted to a dictionary", file=out)
