@@ -56,12 +56,17 @@ class _Stopped(Exception):
         self.signum = signum
 
 
-def _die_with_parent():
-    """preexec_fn of a rank (between fork and exec, so before anything could touch a GPU): SIGTERM when the launcher dies."""
-    try:
-        ctypes.CDLL(None, use_errno=True).prctl(1, int(signal.SIGTERM), 0, 0, 0)  # PR_SET_PDEATHSIG
-    except Exception:  # not Linux: the handlers below are all there is
-        pass
+def _die_with_parent(launcher_pid):
+    """preexec_fn of a rank (between fork and exec, so before anything could touch a GPU): SIGTERM when the launcher dies --
+    and if it died between the fork and this call (the signal would never come), leave at once."""
+    def arm():
+        try:
+            ctypes.CDLL(None, use_errno=True).prctl(1, int(signal.SIGTERM), 0, 0, 0)  # PR_SET_PDEATHSIG
+        except Exception:  # not Linux: the handlers below are all there is
+            return
+        if os.getppid() != launcher_pid:
+            os._exit(128 + int(signal.SIGTERM))
+    return arm
 
 
 def spawn_ranks(argv, world, timeout_s=None, grace_s=20.0, poll_s=0.05, env=None):
@@ -84,7 +89,7 @@ def spawn_ranks(argv, world, timeout_s=None, grace_s=20.0, poll_s=0.05, env=None
                 pass
     try:
         for r in range(world):
-            procs.append(subprocess.Popen(list(argv), env=rank_env(r, world, key, env), preexec_fn=_die_with_parent))
+            procs.append(subprocess.Popen(list(argv), env=rank_env(r, world, key, env), preexec_fn=_die_with_parent(os.getpid())))
         deadline = None if timeout_s is None else time.monotonic() + timeout_s
         status, first_fail_at, seen = 0, None, set()
         while True:
