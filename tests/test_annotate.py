@@ -305,11 +305,14 @@ def test_gpu_annotate_lookup_small_genomes(oracle, tmp_path):
     ids equal to the oracle's numpy join; a second scan invalidates the ids; calls out of order are state errors."""
     from cropsr_amd import Engine, annotate, _native as nat
     from oracle import annotate_oracle
-    rng = np.random.default_rng(2024)
+    from conftest import fuzz_settings
+    trials, seed, tick = fuzz_settings(6, 2024)  # (CROPSR_FUZZ_TRIALS / _SEED / _PROGRESS: a soak on the GPU box)
+    rng = np.random.default_rng(seed)
     alpha = np.frombuffer(b"ACGTACGTACGTacgtNGGCC", dtype=np.uint8)
     eng = Engine(0)
     try:
-        for trial in range(6):
+        for trial in range(trials):
+            tick("annotate", trial)
             dec = trial % 2
             lens = [int(rng.integers(2000, 9000)), 5, 0, int(rng.integers(300, 4000)), 31, int(rng.integers(40000, 90000))]
             names = ["c%d" % k for k in range(len(lens))]
