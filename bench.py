@@ -85,6 +85,10 @@ def parse_args():
                          "the digest the stitched tables are compared with)")
     ap.add_argument("--offtarget-steps", type=int, default=5,
                     help="timed steps of the off-target seed scan (0 = skip that block)")
+    ap.add_argument("--annotate-steps", type=int, default=5,
+                    help="N = 1: timed look-ups of the opt-in annotation join (crp_annotate_lookup) over the same resident hit "
+                         "tables, with a seeded synthetic Phytozome-style GFF for the workload (0 = skip that block)")
+    ap.add_argument("--annotate-genes", type=int, default=50000, help="gene models of that GFF at --scale 1")
     ap.add_argument("--offtarget-seeds-from-planes", action="store_true",
                     help="off-target block: the seed stage reads the planes itself (ot_seed_kernel) instead of taking the "
                          "seed words from the scan")
@@ -765,8 +769,67 @@ def main():
             ot = {"error": repr(e)[:300]}
         unguard()
 
+    # ---- the opt-in annotation join (BASELINE.json configs[2], [3] name a GFF) on the same resident tables
+    ann_block = None
+    if args.annotate_steps > 0 and world == 1:
+        try:
+            import shutil
+            import tempfile
+            import bench_workload as bw
+            from cropsr_amd import annotate
+            tmp = tempfile.mkdtemp(prefix="cropsr_bench_gff_")
+            try:
+                gff, info_path = os.path.join(tmp, "genes.gff3"), os.path.join(tmp, "annotation_info.txt")
+                n_genes = max(50, int(args.annotate_genes * (args.scale if args.workload == "switchgrass" else 1.0)))
+                gff_rows = bw.synthetic_annotation(genomes[0], gff, info_path, n_genes=n_genes)
+                t_b = time.perf_counter()
+                ann = annotate.Annotation(gff, info_path)
+                t_b = time.perf_counter() - t_b
+                gff_bytes = os.path.getsize(gff)
+            finally:
+                shutil.rmtree(tmp, ignore_errors=True)
+            names = [genomes[all_specs[i][0]].specs[all_specs[i][1]].name for i in mine]
+            req = annotate.Request(ann, names, 1)
+            t_t = time.perf_counter()
+            points, ids = req.track([(j, int(arena.offsets[j]), int(arena.lengths[j])) for j in range(len(mine))])
+            arena.annotate_set_track(points, ids)
+            t_t = time.perf_counter() - t_t
+            arena.scan_score_device(20, want_pre=False)  # (the look-up needs the tables of the arena's LAST scan)
+            for _ in range(3):
+                arena.annotate_lookup(n_plus, n_minus, fetch=False)
+            eng.profile(2)
+            eng.profile_read(reset=True)
+            t_l = time.perf_counter()
+            for _ in range(args.annotate_steps):
+                arena.annotate_lookup(n_plus, n_minus, fetch=False)
+            t_l = (time.perf_counter() - t_l) / args.annotate_steps
+            pa = eng.profile_read(reset=True)["annotate"]
+            eng.profile(0)
+            feat = arena.annotate_lookup(n_plus, n_minus)
+            import numpy as _np
+            n_feat = int((feat[0] != annotate.NO_FEATURE).sum() + (feat[1] != annotate.NO_FEATURE).sum())
+            k_ms = pa["ms"] / max(1, pa["launches"])
+            algo = 16.0 * (n_plus + n_minus)  # 4 B position + 8 B score in, 4 B label-set id out per hit
+            ann_block = {"metric": "hits annotated/sec", "value": (n_plus + n_minus) / t_l, "unit": "hits/s",
+                         "steps": args.annotate_steps, "ms_per_lookup": t_l * 1e3, "kernel_ms": k_ms,
+                         "gff": {"gene_rows": gff_rows[0], "cds_rows": gff_rows[1], "bytes": gff_bytes, "data": "synthetic, seeded"},
+                         "label_sets": len(ann.strings), "track_points": int(points.size), "hits_with_a_feature": n_feat,
+                         "host_build_s": t_b, "track_layout_upload_s": t_t,
+                         "roofline": {"bound": "hbm", "kernel": "annot_lookup_kernel (both tables, one launch)",
+                                      "achieved": algo / (k_ms * 1e-3) / 1e9 if k_ms else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                      "frac": (algo / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if k_ms else None,
+                                      "algorithmic_bytes_per_launch": int(algo), "traffic": None},
+                         "parity": "unpinned: the reference parses the GFF and never joins it (oracle: oracle/annotate_oracle.py)"}
+            ann.close()
+        except Exception as e:
+            import traceback
+            traceback.print_exc()
+            ann_block = {"error": repr(e)[:300]}
+
     if rank == 0:
         line = build_line(gather_info, ot, strong)
+        if ann_block is not None:
+            line["annotate"] = ann_block
         if world == 1 and args.cpu_sample_bases > 0:
             from oracle import oracle as _o
             _o.lib()

@@ -840,6 +840,8 @@ def test_bench_line_contract():
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert "traffic_source" in r and d["config"]["chain_timeouts"] == 0 and d["config"]["launches_per_step"] == 1
+    a = d["annotate"]  # the opt-in annotation join over the same resident tables (synthetic GFF)
+    assert a["roofline"]["frac"] > 0 and a["hits_with_a_feature"] > 0 and a["gff"]["gene_rows"] > 0 and a["kernel_ms"] > 0
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and "sample" in c
     assert c["all_cores"]["cores"] >= 1 and c["all_cores"]["value"] > 0
