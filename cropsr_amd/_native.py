@@ -59,6 +59,21 @@ SIGNATURES = {
     "crp_gather_hits": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, u64p]),
     "crp_gathered_fetch": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, u32p, f64p, u32p, u32p, f64p, u32p]),
     "crp_gathered_fetch_features": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, u32p, u32p]),
+    "crp_plan_shares": (ctypes.c_int, [u64p, ctypes.c_uint64, ctypes.c_int, ctypes.c_uint64, u64p, ctypes.c_uint64, u64p]),
+    "crp_node_init": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_int), voidpp]),
+    "crp_node_destroy": (ctypes.c_int, [ctypes.c_void_p]),
+    "crp_node_last_error": (ctypes.c_char_p, [ctypes.c_void_p]),
+    "crp_node_size": (ctypes.c_int, [ctypes.c_void_p]),
+    "crp_node_ctx": (ctypes.c_void_p, [ctypes.c_void_p, ctypes.c_int]),
+    "crp_node_arena": (ctypes.c_void_p, [ctypes.c_void_p, ctypes.c_int]),
+    "crp_node_load": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), u64p, ctypes.c_uint64]),
+    "crp_node_plan": (ctypes.c_int, [ctypes.c_void_p, u64p, ctypes.c_uint64, u64p]),
+    "crp_node_scan_score": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, u64p, u64p]),
+    "crp_node_gather": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]),
+    "crp_node_counts": (ctypes.c_int, [ctypes.c_void_p, u64p, u64p, u64p]),
+    "crp_node_fetch": (ctypes.c_int, [ctypes.c_void_p, u32p, f64p, u32p, f64p]),
+    "crp_node_tables_device": (ctypes.c_int, [ctypes.c_void_p, voidpp, voidpp, voidpp, voidpp]),
+    "crp_node_gather_stats": (ctypes.c_int, [ctypes.c_void_p, f64p, f64p, u64p, ctypes.POINTER(ctypes.c_int)]),
     "crp_annotation_build": (ctypes.c_int, [u8p, ctypes.c_uint64, u8p, ctypes.c_uint64, voidpp]),
     "crp_annotation_destroy": (ctypes.c_int, [ctypes.c_void_p]),
     "crp_annotation_stats": (ctypes.c_int, [ctypes.c_void_p, u64p, u64p, u64p, u64p, u64p]),
@@ -90,17 +105,20 @@ CRP_OK = 0
 ORDER_BODY4, ORDER_TAIL2, ORDER_DOT1 = 0, 1, 2
 OPT_TWO_PASS, OPT_CHAIN_TIMEOUT_US, OPT_TILE_GEOMETRY = 1, 2, 3
 GEOMETRIES = {"auto": 0, "large": 1, "small": 2}
-Q_CHAIN_TIMEOUTS, Q_TWO_PASS_ACTIVE, Q_COMM_WORLD, Q_COMM_RANK, Q_HBM_FREE, Q_HBM_TOTAL = 1, 2, 3, 4, 5, 6
+Q_CHAIN_TIMEOUTS, Q_TWO_PASS_ACTIVE, Q_COMM_WORLD, Q_COMM_RANK, Q_HBM_FREE, Q_HBM_TOTAL, Q_GATHER_BYTES = 1, 2, 3, 4, 5, 6, 7
 KINDS = ("count", "tile_scan", "emit_score", "ot_seed", "ot_ball", "ot_lookup", "gatherv", "ot_reduce",
          "annotate")  # CRP_K_*
 REDUCE_SUM, REDUCE_MAX = 0, 1
 COMM_ID_BYTES = 128
-GATHER_OFFTARGET, GATHER_PRE, GATHER_FEATURES = 1, 2, 4
+GATHER_OFFTARGET, GATHER_PRE, GATHER_FEATURES, GATHER_POS16 = 1, 2, 4, 8
+NODE_PEER_COPY = 16
+TRANSPORTS = {0: "none (one device)", 1: "RCCL (in-library, one process)", 2: "device-to-device copies"}
+HALO = 128
 NO_FEATURE = 0xFFFFFFFF
 SCAN_PRE, SCAN_SEEDS = 1, 2
 OT_SEEDS = 1 << 24
 OT_NOT_A_SITE, OT_NOT_OWNED = 0xFFFFFFFF, 0xFFFFFFFE
-ABI_VERSION = 4
+ABI_VERSION = 5
 CRP_ERR_NO_DEVICE = -2
 CRP_ERR_CAPACITY = -6
 CRP_ERR_IO = -8

@@ -727,55 +727,66 @@ static int scan_two_pass(crp_arena *a, const crp::Planes &pl, uint64_t eff_words
     return CRP_OK;
 }
 
-// one launch: table offsets come from a chained scan inside the emit kernel.  The
-// tables are sized from the previous scan of this arena (hit counts are a
-// property of the sealed arena) or, the first time, from a density guess; a scan
-// that finds more hits than fit writes nothing out of bounds and is repeated once
-// with the exact sizes.
-// One launch: offsets from the chained scan inside the emit kernel.  Returns CRP_ERR_STATE with
-// *chain_failed = true when a look-back timed out (the caller then runs the three-launch sequence).
-static int scan_single_pass(crp_arena *a, const crp::Planes &pl, uint64_t eff_words, int guide_len, ScanWant want,
-                            uint64_t n[2], bool *chain_failed)
+// One launch: table offsets come from a chained scan inside the emit kernel.  The tables are sized from the
+// previous scan of this arena (hit counts are a property of the sealed arena) or, the first time, from a density
+// guess; a scan that finds more hits than fit writes nothing out of bounds and is repeated once with the exact
+// sizes.  The launch and its collection are two steps so that a caller with several devices (crp_node.cpp) can
+// queue the launch on every device before it waits for any of them.
+static int single_launch(crp_arena *a, const crp::Planes &pl, uint64_t eff_words, int guide_len, ScanWant want,
+                         const uint64_t rows[2], crp::HitTables *out)
 {
     crp_ctx *ctx = a->ctx;
-    *chain_failed = false;
-    uint64_t rows[2] = {std::max<uint64_t>(a->tab_cap[0], a->n_chars / 8 + 1024),
-                        std::max<uint64_t>(a->tab_cap[1], a->n_chars / 8 + 1024)};
-    for (int attempt = 0; attempt < 2; ++attempt) {
-        int rc = reserve_tables(a, rows, want);
-        if (rc != CRP_OK) return rc;
-        const crp::HitTables out = table_args(a, want);
-        uint64_t *cur = a->d_chain[a->chain_cur], *next = a->d_chain[a->chain_cur ^ 1];
-        a->h_totals[0] = a->h_totals[1] = a->h_totals[2] = 0;
-        prof_begin(ctx, 2);
-        CRP_HIP(ctx, crp::launch_emit_chained(ctx->stream, a->geo, pl, eff_words, guide_len, cur, next, out, ctx->mute_tile,
-                                                  ctx->chain_timeout_ticks));
-        prof_end(ctx, 2);
-        // header: fail << 32, total '+', total '-' -- the kernel also writes it to h_totals (pinned)
-        CRP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        a->chain_cur ^= 1;  // the kernel left the other buffer zeroed
-        if (a->h_totals[0] >> 32) {  // fail flag: a look-back spin ran out; neither buffer can be trusted now
-            for (int b = 0; b < 2; ++b)
-                CRP_HIP(ctx, hipMemsetAsync(a->d_chain[b], 0, crp::chain_bytes(a->n_tiles), ctx->stream));
-            int rc2 = chain_headers_point_at_host(a);
-            if (rc2 != CRP_OK) return rc2;
-            *chain_failed = true;
-            return CRP_ERR_STATE;
-        }
-        prof_collect(ctx, 2);
-        n[0] = a->h_totals[1];
-        n[1] = a->h_totals[2];
-        if (n[0] <= out.cap_plus && n[1] <= out.cap_minus) return CRP_OK;
-        rows[0] = n[0];
-        rows[1] = n[1];
-    }
-    ctx->last_error = "emit kernel: tables still too small after resizing";
-    return CRP_ERR_STATE;
+    int rc = reserve_tables(a, rows, want);
+    if (rc != CRP_OK) return rc;
+    *out = table_args(a, want);
+    uint64_t *cur = a->d_chain[a->chain_cur], *next = a->d_chain[a->chain_cur ^ 1];
+    a->h_totals[0] = a->h_totals[1] = a->h_totals[2] = 0;
+    prof_begin(ctx, 2);
+    CRP_HIP(ctx, crp::launch_emit_chained(ctx->stream, a->geo, pl, eff_words, guide_len, cur, next, *out, ctx->mute_tile,
+                                          ctx->chain_timeout_ticks));
+    prof_end(ctx, 2);
+    return CRP_OK;
 }
 
-int crp_scan_score(crp_arena *a, int guide_len, int flags, uint64_t *n_plus, uint64_t *n_minus)
+// Waits for single_launch's kernel.  CRP_OK with *too_small = true: the tables held fewer rows than n[] (nothing was
+// written out of bounds).  CRP_ERR_STATE with *chain_failed = true: a look-back timed out (the caller then runs the
+// three-launch sequence).
+static int single_collect(crp_arena *a, const crp::HitTables &out, uint64_t n[2], bool *chain_failed, bool *too_small)
 {
-    crp::Range roctx_range("crp: scan + score");
+    crp_ctx *ctx = a->ctx;
+    *chain_failed = *too_small = false;
+    // header: fail << 32, total '+', total '-' -- the kernel also writes it to h_totals (pinned)
+    CRP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    a->chain_cur ^= 1;  // the kernel left the other buffer zeroed
+    if (a->h_totals[0] >> 32) {  // fail flag: a look-back spin ran out; neither buffer can be trusted now
+        for (int b = 0; b < 2; ++b)
+            CRP_HIP(ctx, hipMemsetAsync(a->d_chain[b], 0, crp::chain_bytes(a->n_tiles), ctx->stream));
+        int rc2 = chain_headers_point_at_host(a);
+        if (rc2 != CRP_OK) return rc2;
+        *chain_failed = true;
+        return CRP_ERR_STATE;
+    }
+    prof_collect(ctx, 2);
+    n[0] = a->h_totals[1];
+    n[1] = a->h_totals[2];
+    *too_small = n[0] > out.cap_plus || n[1] > out.cap_minus;
+    return CRP_OK;
+}
+
+static ScanWant scan_want(int guide_len, int flags)
+{
+    // seed words come out of the l = 20 kernel only; for other lengths the off-target step derives them itself
+    return ScanWant{(flags & CRP_SCAN_PRE) != 0, (flags & CRP_SCAN_SEEDS) != 0 && guide_len == 20};
+}
+
+}  // extern "C"
+
+namespace crp {
+
+// First half of crp_scan_score: validates, and in the single-launch mode queues the kernel on the context's stream
+// without waiting for it.  (Three-launch mode: nothing is queued; scan_finish runs the whole sequence.)
+int scan_begin(crp_arena *a, int guide_len, int flags)
+{
     if (!a || (flags & ~(CRP_SCAN_PRE | CRP_SCAN_SEEDS))) return CRP_ERR_INVALID;
     if (!a->sealed) return CRP_ERR_STATE;
     if (guide_len < 0 || guide_len > 50) return CRP_ERR_UNSUPPORTED;
@@ -784,17 +795,50 @@ int crp_scan_score(crp_arena *a, int guide_len, int flags, uint64_t *n_plus, uin
     a->have_hits = false;
     a->have_raw = false;
     a->have_feat = false;
-    // seed words come out of the l = 20 kernel only; for other lengths the off-target step derives them itself
-    const ScanWant want{(flags & CRP_SCAN_PRE) != 0, (flags & CRP_SCAN_SEEDS) != 0 && guide_len == 20};
+    a->scan_pending = 0;
+    a->pend_guide_len = guide_len;
+    a->pend_flags = flags;
+    if (ctx->two_pass || ctx->two_pass_latched) {
+        a->scan_pending = 2;
+        return CRP_OK;
+    }
+    const ScanWant want = scan_want(guide_len, flags);
+    const uint64_t eff_words = (uint64_t)a->n_tiles * (uint64_t)crp::tile_words(a->geo);
+    crp::Planes pl{{a->d_plane[0], a->d_plane[1], a->d_plane[2], a->d_plane[3]}};
+    const uint64_t rows[2] = {std::max<uint64_t>(a->tab_cap[0], a->n_chars / 8 + 1024),
+                              std::max<uint64_t>(a->tab_cap[1], a->n_chars / 8 + 1024)};
+    const int rc = single_launch(a, pl, eff_words, guide_len, want, rows, &a->pend_out);
+    if (rc != CRP_OK) return rc;
+    a->scan_pending = 1;
+    return CRP_OK;
+}
+
+int scan_finish(crp_arena *a, uint64_t *n_plus, uint64_t *n_minus)
+{
+    if (!a) return CRP_ERR_INVALID;
+    if (!a->scan_pending) return CRP_ERR_STATE;
+    crp_ctx *ctx = a->ctx;
+    CRP_HIP(ctx, hipSetDevice(ctx->device));
+    const int guide_len = a->pend_guide_len;
+    const ScanWant want = scan_want(guide_len, a->pend_flags);
     const uint64_t eff_words = (uint64_t)a->n_tiles * (uint64_t)crp::tile_words(a->geo);
     crp::Planes pl{{a->d_plane[0], a->d_plane[1], a->d_plane[2], a->d_plane[3]}};
     uint64_t n[2] = {0, 0};
     int rc;
-    if (ctx->two_pass || ctx->two_pass_latched) {
+    if (a->scan_pending == 2) {
         rc = scan_two_pass(a, pl, eff_words, guide_len, want, n);
     } else {
-        bool chain_failed = false;
-        rc = scan_single_pass(a, pl, eff_words, guide_len, want, n, &chain_failed);
+        bool chain_failed = false, too_small = false;
+        rc = single_collect(a, a->pend_out, n, &chain_failed, &too_small);
+        if (rc == CRP_OK && too_small) {  // once more, with the exact sizes
+            const uint64_t rows[2] = {n[0], n[1]};
+            rc = single_launch(a, pl, eff_words, guide_len, want, rows, &a->pend_out);
+            if (rc == CRP_OK) rc = single_collect(a, a->pend_out, n, &chain_failed, &too_small);
+            if (rc == CRP_OK && too_small) {
+                ctx->last_error = "emit kernel: tables still too small after resizing";
+                rc = CRP_ERR_STATE;
+            }
+        }
         if (chain_failed) {
             // A workgroup waited longer than CRP_OPT_CHAIN_TIMEOUT_US for a predecessor's counts (a
             // shared or pre-empted GPU can do that; a wrong assumption about dispatch order would
@@ -809,6 +853,7 @@ int crp_scan_score(crp_arena *a, int guide_len, int flags, uint64_t *n_plus, uin
             ctx->timeout_streak = 0;
         }
     }
+    a->scan_pending = 0;
     if (rc != CRP_OK) return rc;
     a->n_hits[0] = n[0];
     a->n_hits[1] = n[1];
@@ -818,6 +863,18 @@ int crp_scan_score(crp_arena *a, int guide_len, int flags, uint64_t *n_plus, uin
     if (n_plus) *n_plus = n[0];
     if (n_minus) *n_minus = n[1];
     return CRP_OK;
+}
+
+}  // namespace crp
+
+extern "C" {
+
+int crp_scan_score(crp_arena *a, int guide_len, int flags, uint64_t *n_plus, uint64_t *n_minus)
+{
+    crp::Range roctx_range("crp: scan + score");
+    const int rc = crp::scan_begin(a, guide_len, flags);
+    if (rc != CRP_OK) return rc;
+    return crp::scan_finish(a, n_plus, n_minus);
 }
 
 int crp_fetch_hits(crp_arena *a, uint32_t *pos_plus, double *pre_plus, double *score_plus, uint32_t *pos_minus,
@@ -952,6 +1009,7 @@ int crp_query(const crp_ctx *ctx, int what, int64_t *value)
         case CRP_Q_TWO_PASS_ACTIVE: *value = (ctx->two_pass || ctx->two_pass_latched) ? 1 : 0; return CRP_OK;
         case CRP_Q_COMM_WORLD: *value = crp::comm_world(ctx); return CRP_OK;
         case CRP_Q_COMM_RANK: *value = crp::comm_rank(ctx); return CRP_OK;
+        case CRP_Q_GATHER_BYTES: *value = (int64_t)crp::comm_gather_bytes(ctx); return CRP_OK;
         case CRP_Q_HBM_FREE:
         case CRP_Q_HBM_TOTAL: {
             size_t free_b = 0, total_b = 0;

@@ -21,34 +21,17 @@
 #include <string>
 #include <vector>
 
-#include <rccl/rccl.h>
-
 #include "crp_internal.h"
+#include "crp_rccl.h"
 #include "crp_roctx.h"
 
-namespace {
+namespace crp {
 
-struct Rccl {
-    void *handle = nullptr;
-    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
-    decltype(&ncclCommInitRank) CommInitRank = nullptr;
-    decltype(&ncclCommDestroy) CommDestroy = nullptr;
-    decltype(&ncclCommAbort) CommAbort = nullptr;
-    decltype(&ncclAllGather) AllGather = nullptr;
-    decltype(&ncclAllReduce) AllReduce = nullptr;
-    decltype(&ncclSend) Send = nullptr;
-    decltype(&ncclRecv) Recv = nullptr;
-    decltype(&ncclGroupStart) GroupStart = nullptr;
-    decltype(&ncclGroupEnd) GroupEnd = nullptr;
-    decltype(&ncclGetErrorString) GetErrorString = nullptr;
-    std::string error;
-};
-
-Rccl g_rccl;
-std::once_flag g_rccl_once;
+static Rccl g_rccl;
+static std::once_flag g_rccl_once;
 
 template <class F>
-bool bind(void *h, const char *name, F &fn)
+static bool bind(void *h, const char *name, F &fn)
 {
     fn = reinterpret_cast<F>(dlsym(h, name));
     return fn != nullptr;
@@ -67,6 +50,7 @@ const Rccl *rccl()
         }
         Rccl &r = g_rccl;
         const bool ok = bind(h, "ncclGetUniqueId", r.GetUniqueId) && bind(h, "ncclCommInitRank", r.CommInitRank) &&
+                        bind(h, "ncclCommInitAll", r.CommInitAll) &&
                         bind(h, "ncclCommDestroy", r.CommDestroy) && bind(h, "ncclCommAbort", r.CommAbort) &&
                         bind(h, "ncclAllGather", r.AllGather) && bind(h, "ncclAllReduce", r.AllReduce) &&
                         bind(h, "ncclSend", r.Send) && bind(h, "ncclRecv", r.Recv) &&
@@ -81,13 +65,18 @@ const Rccl *rccl()
     return g_rccl.handle ? &g_rccl : nullptr;
 }
 
-}  // namespace
+const std::string &rccl_load_error() { return g_rccl.error; }
+
+}  // namespace crp
+
+using crp::rccl;
+using crp::Rccl;
 
 struct crp_comm {
     ncclComm_t comm = nullptr;
     int rank = 0, world = 0;
     // scratch in HBM: counts (2 per rank) and small reductions
-    uint64_t *d_counts = nullptr;  // 3 * world {n_plus, n_minus, status} + world (second agreement round)
+    uint64_t *d_counts = nullptr;  // 4 * world {n_plus, n_minus, status, position buckets} + world (second agreement round)
     double *d_small = nullptr;     // 64 doubles in, 64 out
     std::vector<uint64_t> counts;  // last gather: {n_plus, n_minus} per rank
     std::vector<uint64_t> raw;     // host copy of d_counts
@@ -99,6 +88,12 @@ struct crp_comm {
     uint4 *d_got[2] = {nullptr, nullptr};  // CRP_GATHER_OFFTARGET: per-hit counts
     uint32_t *d_gfeat[2] = {nullptr, nullptr};  // CRP_GATHER_FEATURES: per-hit label-set ids
     uint64_t gpos_cap[2] = {0, 0}, gscore_cap[2] = {0, 0}, got_cap[2] = {0, 0}, gfeat_cap[2] = {0, 0};
+    // CRP_GATHER_POS16 (crp_gather.hip): a peer's packed positions and bucket starts; at the root the staging area they
+    // arrive in, peer after peer (every peer's rows at a multiple of 8)
+    uint16_t *d_lo16[2] = {nullptr, nullptr}, *d_glo16[2] = {nullptr, nullptr};
+    uint32_t *d_bstart[2] = {nullptr, nullptr}, *d_gbstart[2] = {nullptr, nullptr};
+    uint64_t lo16_cap[2] = {0, 0}, bstart_cap[2] = {0, 0}, glo16_cap[2] = {0, 0}, gbstart_cap[2] = {0, 0};
+    uint64_t bytes_to_root = 0;  // of the last gather: what this rank sent (peer) or received (root)
     int gflags = 0;
     std::vector<uint64_t> goff[2];  // element offset of every rank's slice (root's own slice: unused)
     int groot = -1;
@@ -129,6 +124,10 @@ void comm_release(crp_ctx *ctx)
         (void)hipFree(c->d_gscore[s]);
         (void)hipFree(c->d_got[s]);
         (void)hipFree(c->d_gfeat[s]);
+        (void)hipFree(c->d_lo16[s]);
+        (void)hipFree(c->d_glo16[s]);
+        (void)hipFree(c->d_bstart[s]);
+        (void)hipFree(c->d_gbstart[s]);
     }
     delete c;
     ctx->comm = nullptr;
@@ -145,6 +144,7 @@ void comm_forget_arena(crp_ctx *ctx, const crp_arena *a)
 
 int comm_world(const crp_ctx *ctx) { return ctx->comm ? ctx->comm->world : 0; }
 int comm_rank(const crp_ctx *ctx) { return ctx->comm ? ctx->comm->rank : 0; }
+uint64_t comm_gather_bytes(const crp_ctx *ctx) { return ctx->comm ? ctx->comm->bytes_to_root : 0; }
 
 // used by crp_offtarget.hip: in-place sum of n uint32 over all ranks (no-op without a communicator)
 int comm_allreduce_u32(crp_ctx *ctx, uint32_t *d_buf, uint64_t n)
@@ -177,7 +177,7 @@ int crp_comm_init(crp_ctx *ctx, const uint8_t id[CRP_COMM_ID_BYTES], int rank, i
     if (ctx->comm) return CRP_ERR_STATE;
     const Rccl *r = rccl();
     if (!r) {
-        ctx->last_error = g_rccl.error;
+        ctx->last_error = crp::rccl_load_error();
         return CRP_ERR_COMM;
     }
     CRP_HIP(ctx, hipSetDevice(ctx->device));
@@ -195,7 +195,7 @@ int crp_comm_init(crp_ctx *ctx, const uint8_t id[CRP_COMM_ID_BYTES], int rank, i
         crp::comm_release(ctx);
         return CRP_ERR_COMM;
     }
-    hipError_t e = hipMalloc(reinterpret_cast<void **>(&c->d_counts), 4 * (size_t)world * sizeof(uint64_t));
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&c->d_counts), 5 * (size_t)world * sizeof(uint64_t));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->d_small), 128 * sizeof(double));
     if (e != hipSuccess) {
         ctx->last_error = std::string("communicator scratch: ") + hipGetErrorString(e);
@@ -203,7 +203,7 @@ int crp_comm_init(crp_ctx *ctx, const uint8_t id[CRP_COMM_ID_BYTES], int rank, i
         return CRP_ERR_NOMEM;
     }
     c->counts.assign(2 * (size_t)world, 0);
-    c->raw.assign(4 * (size_t)world, 0);
+    c->raw.assign(5 * (size_t)world, 0);
     if (const char *e = std::getenv("CRP_TEST_GATHER_FAIL")) c->test_fail = std::atoi(e);
     return CRP_OK;
 }
@@ -258,11 +258,12 @@ int crp_gather_hits(crp_ctx *ctx, crp_arena *a, int root, int flags, uint64_t *c
     crp_comm *c = ctx->comm;
     if (!c) return CRP_ERR_STATE;
     // (arguments that are the same on every rank by contract: a bad one fails everywhere alike)
-    if (root < 0 || root >= c->world || (flags & ~(CRP_GATHER_OFFTARGET | CRP_GATHER_PRE | CRP_GATHER_FEATURES)))
+    if (root < 0 || root >= c->world || (flags & ~(CRP_GATHER_OFFTARGET | CRP_GATHER_PRE | CRP_GATHER_FEATURES | CRP_GATHER_POS16)))
         return CRP_ERR_INVALID;
     const bool send_pre = (flags & CRP_GATHER_PRE) != 0;
     const bool with_ot = (flags & CRP_GATHER_OFFTARGET) != 0;
     const bool with_feat = (flags & CRP_GATHER_FEATURES) != 0;
+    const bool pos16 = (flags & CRP_GATHER_POS16) != 0;
     // What can differ from rank to rank -- the state of this rank's arena, the root's allocation -- is never
     // answered with an early return: a rank that left here alone would leave its peers inside a collective
     // that cannot complete.  Each rank's status travels WITH its counts, and everyone acts on all of them.
@@ -276,29 +277,46 @@ int crp_gather_hits(crp_ctx *ctx, crp_arena *a, int root, int flags, uint64_t *c
     CRP_HIP(ctx, hipSetDevice(ctx->device));
     c->have_gather = false;
     const bool ok_local = local == CRP_OK;
-    const uint64_t mine[3] = {ok_local && a ? a->n_hits[0] : 0, ok_local && a ? a->n_hits[1] : 0, (uint64_t)(-local)};
+    const uint32_t my_buckets = ok_local && a ? crp::pos16_buckets_for(a->padded_words) : 0;
+    const uint64_t mine[4] = {ok_local && a ? a->n_hits[0] : 0, ok_local && a ? a->n_hits[1] : 0, (uint64_t)(-local), my_buckets};
     const size_t W = (size_t)c->world;
     // 1. everyone learns every rank's two counts and its status
-    CRP_HIP(ctx, hipMemcpyAsync(c->d_counts + 3 * c->rank, mine, sizeof mine, hipMemcpyHostToDevice, ctx->stream));
-    CRP_NCCL(ctx, r->AllGather(c->d_counts + 3 * c->rank, c->d_counts, 3, ncclUint64, c->comm, ctx->stream));
-    CRP_HIP(ctx, hipMemcpyAsync(c->raw.data(), c->d_counts, 3 * W * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    CRP_HIP(ctx, hipMemcpyAsync(c->d_counts + 4 * c->rank, mine, sizeof mine, hipMemcpyHostToDevice, ctx->stream));
+    CRP_NCCL(ctx, r->AllGather(c->d_counts + 4 * c->rank, c->d_counts, 4, ncclUint64, c->comm, ctx->stream));
+    CRP_HIP(ctx, hipMemcpyAsync(c->raw.data(), c->d_counts, 4 * W * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
     CRP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<uint32_t> buckets(W);
     for (size_t p = 0; p < W; ++p) {
-        c->counts[2 * p] = c->raw[3 * p];
-        c->counts[2 * p + 1] = c->raw[3 * p + 1];
+        c->counts[2 * p] = c->raw[4 * p];
+        c->counts[2 * p + 1] = c->raw[4 * p + 1];
+        buckets[p] = (uint32_t)c->raw[4 * p + 3];
     }
     if (counts_all) std::memcpy(counts_all, c->counts.data(), 2 * W * sizeof(uint64_t));
-    int rc = agreed_status(ctx, c, c->raw.data() + 2, 3, local, "before the exchange (its arena has no tables to send)");
+    int rc = agreed_status(ctx, c, c->raw.data() + 2, 4, local, "before the exchange (its arena has no tables to send)");
     if (rc != CRP_OK) return rc;
     // 2. the root sizes its receive buffers; whether that worked is agreed on as well (one more word per rank)
     int alloc = CRP_OK;
+    std::vector<uint64_t> soff[2], boff[2];  // CRP_GATHER_POS16: every peer's place in the root's staging area
     if (c->rank == root) {
         for (int s = 0; s < 2 && alloc == CRP_OK; ++s) {
             c->goff[s].assign(W, 0);
-            uint64_t total = 0;
+            soff[s].assign(W, 0);
+            boff[s].assign(W, 0);
+            uint64_t total = 0, lo_total = 0, b_total = 0;
             for (int p = 0; p < c->world; ++p) {
                 c->goff[s][(size_t)p] = total;
-                if (p != root) total += c->counts[2 * (size_t)p + s];
+                soff[s][(size_t)p] = lo_total;
+                boff[s][(size_t)p] = b_total;
+                if (p == root) continue;
+                total += c->counts[2 * (size_t)p + s];
+                lo_total += (c->counts[2 * (size_t)p + s] + 7) & ~(uint64_t)7;
+                b_total += buckets[(size_t)p];
+            }
+            if (pos16 && lo_total) {
+                alloc = crp::grow(ctx, reinterpret_cast<void **>(&c->d_glo16[s]), &c->glo16_cap[s], lo_total, sizeof(uint16_t));
+                if (alloc == CRP_OK)
+                    alloc = crp::grow(ctx, reinterpret_cast<void **>(&c->d_gbstart[s]), &c->gbstart_cap[s], b_total, sizeof(uint32_t));
+                if (alloc != CRP_OK) break;
             }
             alloc = crp::grow(ctx, reinterpret_cast<void **>(&c->d_gpos[s]), &c->gpos_cap[s], total, sizeof(uint32_t));
             if (alloc == CRP_OK)
@@ -308,13 +326,21 @@ int crp_gather_hits(crp_ctx *ctx, crp_arena *a, int root, int flags, uint64_t *c
             if (alloc == CRP_OK && with_feat)
                 alloc = crp::grow(ctx, reinterpret_cast<void **>(&c->d_gfeat[s]), &c->gfeat_cap[s], total, sizeof(uint32_t));
         }
+    } else if (pos16 && a) {  // a peer's packed positions
+        for (int s = 0; s < 2 && alloc == CRP_OK; ++s) {
+            alloc = crp::grow(ctx, reinterpret_cast<void **>(&c->d_lo16[s]), &c->lo16_cap[s], (mine[s] + 7) & ~(uint64_t)7, sizeof(uint16_t));
+            if (alloc == CRP_OK)
+                alloc = crp::grow(ctx, reinterpret_cast<void **>(&c->d_bstart[s]), &c->bstart_cap[s], my_buckets, sizeof(uint32_t));
+        }
+    }
+    if (c->rank == root) {
         if (c->test_fail == 1) {  // test hook: as if the receive buffers did not fit
             alloc = CRP_ERR_NOMEM;
             ctx->last_error = "gatherv receive buffers: out of memory (injected by CRP_TEST_GATHER_FAIL)";
         }
     }
     const uint64_t word = (uint64_t)(-alloc);
-    uint64_t *d_status = c->d_counts + 3 * W;
+    uint64_t *d_status = c->d_counts + 4 * W;
     CRP_HIP(ctx, hipMemcpyAsync(d_status + c->rank, &word, sizeof word, hipMemcpyHostToDevice, ctx->stream));
     CRP_NCCL(ctx, r->AllGather(d_status + c->rank, d_status, 1, ncclUint64, c->comm, ctx->stream));
     CRP_HIP(ctx, hipMemcpyAsync(c->raw.data(), d_status, W * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -323,6 +349,12 @@ int crp_gather_hits(crp_ctx *ctx, crp_arena *a, int root, int flags, uint64_t *c
     if (rc != CRP_OK) return rc;
     // 3. the tables: grouped point-to-point, peers -> root
     crp::prof_begin(ctx, CRP_K_GATHER);
+    uint64_t moved = 0;
+    if (pos16 && c->rank != root && a)  // (on the stream the sends are queued on: packed before they read)
+        for (int s = 0; s < 2; ++s) {
+            CRP_HIP(ctx, crp::launch_pos16_buckets(ctx->stream, a->d_pos[s], mine[s], 0, mine[s], c->d_bstart[s], my_buckets));
+            CRP_HIP(ctx, crp::launch_pos16_pack(ctx->stream, a->d_pos[s], mine[s], c->d_lo16[s]));
+        }
     CRP_NCCL(ctx, r->GroupStart());
     ncclResult_t st = ncclSuccess;
     if (c->rank == root) {
@@ -331,7 +363,14 @@ int crp_gather_hits(crp_ctx *ctx, crp_arena *a, int root, int flags, uint64_t *c
             for (int s = 0; s < 2 && st == ncclSuccess; ++s) {
                 const uint64_t n = c->counts[2 * (size_t)p + s];
                 if (!n) continue;
-                st = r->Recv(c->d_gpos[s] + c->goff[s][(size_t)p], n, ncclUint32, p, c->comm, ctx->stream);
+                moved += n * ((pos16 ? 2 : 4) + 8 + (with_ot ? 16 : 0) + (with_feat ? 4 : 0)) + (pos16 ? 4ull * buckets[(size_t)p] : 0);
+                if (pos16) {
+                    st = r->Recv(c->d_glo16[s] + soff[s][(size_t)p], 2 * n, ncclUint8, p, c->comm, ctx->stream);
+                    if (st == ncclSuccess)
+                        st = r->Recv(c->d_gbstart[s] + boff[s][(size_t)p], buckets[(size_t)p], ncclUint32, p, c->comm, ctx->stream);
+                } else {
+                    st = r->Recv(c->d_gpos[s] + c->goff[s][(size_t)p], n, ncclUint32, p, c->comm, ctx->stream);
+                }
                 if (st == ncclSuccess)
                     st = r->Recv(c->d_gscore[s] + c->goff[s][(size_t)p], n, ncclDouble, p, c->comm, ctx->stream);
                 if (st == ncclSuccess && with_ot)
@@ -343,7 +382,13 @@ int crp_gather_hits(crp_ctx *ctx, crp_arena *a, int root, int flags, uint64_t *c
     } else {
         for (int s = 0; s < 2 && st == ncclSuccess; ++s) {
             if (!mine[s]) continue;
-            st = r->Send(a->d_pos[s], mine[s], ncclUint32, root, c->comm, ctx->stream);
+            moved += mine[s] * ((pos16 ? 2 : 4) + 8 + (with_ot ? 16 : 0) + (with_feat ? 4 : 0)) + (pos16 ? 4ull * my_buckets : 0);
+            if (pos16) {
+                st = r->Send(c->d_lo16[s], 2 * mine[s], ncclUint8, root, c->comm, ctx->stream);
+                if (st == ncclSuccess) st = r->Send(c->d_bstart[s], my_buckets, ncclUint32, root, c->comm, ctx->stream);
+            } else {
+                st = r->Send(a->d_pos[s], mine[s], ncclUint32, root, c->comm, ctx->stream);
+            }
             if (st == ncclSuccess)
                 st = r->Send(send_pre ? a->d_pre[s] : a->d_score[s], mine[s], ncclDouble, root, c->comm, ctx->stream);
             if (st == ncclSuccess && with_ot) st = r->Send(a->d_ot_cnt[s], 4 * mine[s], ncclUint32, root, c->comm, ctx->stream);
@@ -351,6 +396,13 @@ int crp_gather_hits(crp_ctx *ctx, crp_arena *a, int root, int flags, uint64_t *c
         }
     }
     const ncclResult_t st_end = r->GroupEnd();
+    if (pos16 && c->rank == root && st == ncclSuccess && st_end == ncclSuccess)  // packed -> the root's position tables
+        for (int p = 0; p < c->world; ++p)
+            for (int s = 0; s < 2 && p != root; ++s) {
+                const uint64_t n = c->counts[2 * (size_t)p + s];
+                CRP_HIP(ctx, crp::launch_pos16_expand(ctx->stream, c->d_glo16[s] + soff[s][(size_t)p], n, c->d_gbstart[s] + boff[s][(size_t)p],
+                                                      buckets[(size_t)p], crp::PieceMap{nullptr, nullptr, 0}, c->d_gpos[s] + c->goff[s][(size_t)p]));
+            }
     crp::prof_end(ctx, CRP_K_GATHER);
     if (st != ncclSuccess || st_end != ncclSuccess) {
         // not agreed on: the communicator is in an unknown state and the peers may be inside the exchange --
@@ -361,6 +413,7 @@ int crp_gather_hits(crp_ctx *ctx, crp_arena *a, int root, int flags, uint64_t *c
     // the sends read the arena's tables: they must have left before the caller may scan or destroy it
     CRP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     crp::prof_collect(ctx, CRP_K_GATHER);
+    c->bytes_to_root = moved;
     c->groot = root;
     c->gflags = flags;
     c->garena = a;

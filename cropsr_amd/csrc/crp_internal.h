@@ -85,6 +85,10 @@ struct crp_arena {
     uint64_t pre_cap[2] = {0, 0};
     uint64_t n_hits[2] = {0, 0};
     bool have_hits = false, have_pre = false;
+    // a scan whose launch has been queued and not yet collected (crp::scan_begin / scan_finish): 0 none, 1 the single
+    // launch is on the stream, 2 three-launch mode (scan_finish runs the whole sequence)
+    int scan_pending = 0, pend_guide_len = 0, pend_flags = 0;
+    crp::HitTables pend_out = {};
     // off-target: raw seed words written by the scan itself (CRP_SCAN_SEEDS; same order and capacity as the hit tables)
     uint32_t *d_ot_raw[2] = {nullptr, nullptr};
     uint64_t raw_cap[2] = {0, 0};
@@ -153,10 +157,34 @@ void parallel_copy(void *dst, const void *src, size_t n, int threads);
 // grow-only device buffer: *p holds at least `need` elements of `elem` bytes afterwards
 int grow(crp_ctx *ctx, void **p, uint64_t *cap, uint64_t need, size_t elem);
 
+// crp_scan_score in two halves (crp_api.cpp): scan_begin queues the single-launch scan on the context's stream and returns,
+// scan_finish waits for it, repeats it where it must (tables too small, look-back time-out) and publishes the tables --
+// a caller with several devices queues all of them before it waits for any (crp_node.cpp)
+int scan_begin(crp_arena *a, int guide_len, int flags);
+int scan_finish(crp_arena *a, uint64_t *n_plus, uint64_t *n_minus);
+
+// crp_gather.hip: the kernels either side of the gatherv (ownership cuts, 16-bit position packing, rebasing at the root)
+struct PieceMap {
+    const uint32_t *begin;  // device: arena position each piece's OWNED range begins at, ascending
+    const uint32_t *sub;    // device: what to subtract from a position inside that piece (mod 2^32)
+    uint32_t n;             // 0: positions pass unchanged
+};
+constexpr int POS16_SHIFT = 16;
+inline uint32_t pos16_buckets_for(uint64_t padded_words) { return (uint32_t)((padded_words * 64) >> POS16_SHIFT) + 1; }
+hipError_t launch_lower_bound(hipStream_t s, const uint32_t *pos, uint64_t n, const uint32_t *needles, uint32_t n_needles,
+                              uint32_t *out);
+hipError_t launch_pos16_buckets(hipStream_t s, const uint32_t *pos, uint64_t n, uint64_t first, uint64_t last, uint32_t *bstart,
+                                uint32_t n_buckets);
+hipError_t launch_pos16_pack(hipStream_t s, const uint32_t *pos, uint64_t n, uint16_t *lo16);
+hipError_t launch_pos16_expand(hipStream_t s, const uint16_t *lo16, uint64_t n, const uint32_t *bstart, uint32_t n_buckets,
+                               const PieceMap &map, uint32_t *out);
+hipError_t launch_pos_rebase(hipStream_t s, const uint32_t *pos, uint64_t n, const PieceMap &map, uint32_t *out);
+
 void comm_release(crp_ctx *ctx);  // crp_comm.cpp; called by crp_destroy
 void comm_forget_arena(crp_ctx *ctx, const crp_arena *a);
 int comm_allreduce_u32(crp_ctx *ctx, uint32_t *d_buf, uint64_t n);  // in-place sum over the ranks; no-op without a communicator
 int comm_world(const crp_ctx *ctx);  // 0 without a communicator
 int comm_rank(const crp_ctx *ctx);
+uint64_t comm_gather_bytes(const crp_ctx *ctx);  // bytes this rank sent to (peer) or received as (root) the root in the last crp_gather_hits
 
 }  // namespace crp

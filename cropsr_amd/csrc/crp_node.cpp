@@ -1,0 +1,794 @@
+// crp_node.cpp -- ONE process over N GPUs: the node handle of the C ABI (include/cropsr_hip.h, crp_node_*).
+//
+// The reference is one process with one contig loop (CROPSR.py:333 main, :409 the loop).  SURVEY.md section 8(b) asks
+// for a handle that lets that one process reach the whole node: "multi-GPU fan-out happens inside the library (one
+// stream per device), not via Python threads".  This file is that handle:
+//
+//   crp_plan_shares      the cut: contigs, in order, dealt to the devices as contiguous equal shares (host code)
+//   crp_node_load        one host thread per device uploads its share (pieces with CRP_HALO characters of context)
+//   crp_node_scan_score  the scan is QUEUED on every device's stream, then collected: N kernels run side by side
+//   crp_node_gather      the path's one exchange.  Per device a tiny kernel finds the OWNED rows of its tables (a
+//                        hit belongs to the piece that contains its match index; with contiguous shares the owned
+//                        rows of a device are one run per strand), the peers pack their positions to 16 bits
+//                        (CRP_GATHER_POS16), the rows cross xGMI -- RCCL in one process: ncclCommInitAll, then per peer
+//                        ncclSend and at the root ncclRecv inside ONE group, every peer->root transfer on its own
+//                        point-to-point link; or device-to-device copies the root pulls on one stream per peer -- and
+//                        the root expands and rebases them into ONE table per strand, contig order, positions local
+//                        to the contig string: the reference's own order (CROPSR.py:417-434), bit for bit what a
+//                        single GPU produces.
+//
+// The one-process-per-GPU path (crp_comm.cpp) is unchanged and shares the kernels (crp_gather.hip).
+#include <algorithm>
+#include <array>
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "crp_internal.h"
+#include "crp_rccl.h"
+#include "crp_roctx.h"
+
+namespace {
+
+struct NodePiece {
+    uint64_t contig, start, end;  // the piece [start, end) of contig string `contig`
+    int dev;                      // logical device
+    uint64_t text_lo, text_len;   // the characters uploaded for it: [text_lo, text_lo + text_len) of the contig (piece + halos)
+    uint64_t arena_off;           // arena offset of the text's first character on that device
+};
+
+struct NodeDev {
+    int device = -1;
+    crp_ctx *ctx = nullptr;
+    crp_arena *arena = nullptr;
+    std::vector<uint32_t> pieces;  // indices into crp_node::pieces, arena order (= contig order)
+    // ownership cuts: two needles per piece (begin and end of its owned arena positions), searched in both tables
+    uint32_t *d_needles = nullptr, *d_bounds = nullptr;
+    uint64_t needles_cap = 0, bounds_cap = 0;
+    uint32_t *h_bounds = nullptr;  // pinned, 2 strands x needles
+    uint64_t h_bounds_cap = 0;
+    // sender side of CRP_GATHER_POS16
+    uint16_t *d_lo16[2] = {nullptr, nullptr};
+    uint32_t *d_bstart[2] = {nullptr, nullptr};
+    uint64_t lo16_cap[2] = {0, 0}, bstart_cap[2] = {0, 0};
+    uint32_t n_buckets = 0;
+    hipEvent_t ready = nullptr;  // everything this device contributes to the current gather is in place
+    // the current gather: owned rows [first, last) of each table, and where they go in the root's tables
+    uint64_t first[2] = {0, 0}, last[2] = {0, 0}, foff[2] = {0, 0};
+};
+
+inline uint64_t round_up8(uint64_t x) { return (x + 7) & ~(uint64_t)7; }
+
+// the cut (same as cropsr_amd/parallel.py split_evenly, which the multi-process path uses)
+void plan_shares(const uint64_t *lens, uint64_t n, int world, uint64_t min_piece, std::vector<std::array<uint64_t, 4>> &out)
+{
+    out.clear();
+    int64_t total = 0;
+    for (uint64_t k = 0; k < n; ++k) total += (int64_t)lens[k];
+    std::vector<int64_t> bounds((size_t)world);
+    for (int r = 0; r < world; ++r) bounds[(size_t)r] = (int64_t)(((unsigned __int128)(r + 1) * (unsigned __int128)total) / (unsigned)world);
+    const int64_t minp = (int64_t)min_piece;
+    int r = 0;
+    int64_t acc = 0;
+    for (uint64_t k = 0; k < n; ++k) {
+        const int64_t len = (int64_t)lens[k];
+        int64_t start = 0;
+        for (;;) {
+            const int64_t rest = len - start, room = bounds[(size_t)r] - acc;
+            if (r == world - 1 || rest <= room) {
+                out.push_back({k, (uint64_t)start, (uint64_t)len, (uint64_t)r});
+                acc += rest;
+                break;
+            }
+            if (room >= minp && rest - room >= minp) {  // cut at the boundary
+                out.push_back({k, (uint64_t)start, (uint64_t)(start + room), (uint64_t)r});
+                acc += room;
+                start += room;
+                r += 1;
+            } else if (2 * room >= rest) {  // a sliver would be left over: the rest of the contig stays here
+                out.push_back({k, (uint64_t)start, (uint64_t)len, (uint64_t)r});
+                acc += rest;
+                break;
+            } else {  // a sliver would be cut off: the next device takes the contig from here
+                r += 1;
+            }
+        }
+        while (r < world - 1 && acc >= bounds[(size_t)r]) r += 1;
+    }
+}
+
+double ms_since(std::chrono::steady_clock::time_point t0)
+{
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+
+}  // namespace
+
+struct crp_node {
+    std::vector<NodeDev> dev;
+    std::vector<NodePiece> pieces;
+    uint64_t n_contigs = 0;
+    bool loaded = false;
+    bool duplicates = false;  // a device listed twice: RCCL cannot be used
+    int transport_env = 0;    // CRP_NODE_TRANSPORT: 0 unset, CRP_TRANSPORT_*
+    // RCCL, one communicator per logical device, created by the first gather that uses it
+    std::vector<ncclComm_t> comms;
+    bool comms_tried = false;
+    std::string comms_error;
+    // root side of the last gather
+    int root = -1;        // the device the buffers below live on
+    uint32_t *d_fpos[2] = {nullptr, nullptr};
+    double *d_fscore[2] = {nullptr, nullptr};
+    uint64_t fpos_cap[2] = {0, 0}, fscore_cap[2] = {0, 0};
+    uint16_t *d_slo16[2] = {nullptr, nullptr};   // staging: the peers' packed positions, peer by peer (each at a multiple of 8)
+    uint32_t *d_sbstart[2] = {nullptr, nullptr};  // and their bucket starts
+    uint64_t slo16_cap[2] = {0, 0}, sbstart_cap[2] = {0, 0};
+    uint32_t *d_map = nullptr;  // every device's piece map {begin[], sub[]}, device after device
+    uint64_t map_cap = 0;
+    std::vector<uint32_t> h_map;
+    std::vector<uint64_t> map_off;  // per device: offset of its begin[] in d_map (sub[] follows)
+    std::vector<hipStream_t> pull;  // root's streams for the device-to-device transport, one per peer
+    std::vector<hipEvent_t> pulled;
+    std::vector<uint64_t> contig_counts;  // 2 per contig
+    uint64_t total[2] = {0, 0};
+    bool have_gather = false;
+    double ms_total = 0, ms_exchange = 0;
+    uint64_t bytes_to_root = 0;
+    int transport = 0;
+    std::string last_error;
+};
+
+#define NODE_HIP(node, call)                                                                 \
+    do {                                                                                     \
+        hipError_t e__ = (call);                                                             \
+        if (e__ != hipSuccess) {                                                             \
+            (node)->last_error = std::string(#call) + ": " + hipGetErrorString(e__);         \
+            return e__ == hipErrorOutOfMemory ? CRP_ERR_NOMEM : CRP_ERR_HIP;                 \
+        }                                                                                    \
+    } while (0)
+
+namespace {
+
+// a status from a per-device call: its context's text becomes the node's
+int dev_fail(crp_node *node, int k, int rc, const char *what)
+{
+    if (rc != CRP_OK)
+        node->last_error = std::string(what) + " on logical device " + std::to_string(k) + ": " + crp_strerror(rc) + " [" +
+                           crp_last_error(node->dev[(size_t)k].ctx) + "]";
+    return rc;
+}
+
+void free_root_side(crp_node *node)
+{
+    if (node->root < 0) return;
+    (void)hipSetDevice(node->dev[(size_t)node->root].device);
+    for (int s = 0; s < 2; ++s) {
+        (void)hipFree(node->d_fpos[s]);
+        (void)hipFree(node->d_fscore[s]);
+        (void)hipFree(node->d_slo16[s]);
+        (void)hipFree(node->d_sbstart[s]);
+        node->d_fpos[s] = nullptr;
+        node->d_fscore[s] = nullptr;
+        node->d_slo16[s] = nullptr;
+        node->d_sbstart[s] = nullptr;
+        node->fpos_cap[s] = node->fscore_cap[s] = node->slo16_cap[s] = node->sbstart_cap[s] = 0;
+    }
+    (void)hipFree(node->d_map);
+    node->d_map = nullptr;
+    node->map_cap = 0;
+    for (hipStream_t st : node->pull)
+        if (st) (void)hipStreamDestroy(st);
+    for (hipEvent_t ev : node->pulled)
+        if (ev) (void)hipEventDestroy(ev);
+    node->pull.clear();
+    node->pulled.clear();
+    node->root = -1;
+    node->have_gather = false;
+}
+
+void free_genome(crp_node *node)
+{
+    for (NodeDev &d : node->dev) {
+        if (d.arena) (void)crp_arena_destroy(d.arena);
+        d.arena = nullptr;
+        d.pieces.clear();
+    }
+    node->pieces.clear();
+    node->n_contigs = 0;
+    node->loaded = false;
+    node->have_gather = false;
+}
+
+// upload of one device's share; runs on a thread of its own
+int load_device(crp_node *node, int k, const uint8_t *const *texts)
+{
+    NodeDev &d = node->dev[(size_t)k];
+    if (d.pieces.empty()) return CRP_OK;
+    const size_t np = d.pieces.size();
+    std::vector<const uint8_t *> ptrs(np);
+    std::vector<uint64_t> lens(np), offs(np);
+    uint64_t words = 0;
+    for (size_t j = 0; j < np; ++j) {
+        const NodePiece &p = node->pieces[d.pieces[j]];
+        ptrs[j] = texts[p.contig] + p.text_lo;
+        lens[j] = p.text_len;
+        words += crp_arena_words_for(p.text_len);
+    }
+    int rc = crp_arena_create(d.ctx, crp_arena_words_total(words), &d.arena);
+    if (rc == CRP_OK) rc = crp_arena_add_contigs_ascii(d.arena, ptrs.data(), lens.data(), np, offs.data());
+    if (rc == CRP_OK) rc = crp_arena_seal(d.arena);
+    if (rc != CRP_OK) return rc;
+    for (size_t j = 0; j < np; ++j) node->pieces[d.pieces[j]].arena_off = offs[j];
+    // the ownership needles of this share, resident from now on
+    std::vector<uint32_t> needles(2 * np);
+    for (size_t j = 0; j < np; ++j) {
+        const NodePiece &p = node->pieces[d.pieces[j]];
+        const uint64_t begin = p.arena_off + (p.start - p.text_lo);
+        needles[2 * j] = (uint32_t)begin;
+        needles[2 * j + 1] = (uint32_t)(begin + (p.end - p.start));
+    }
+    crp_ctx *ctx = d.ctx;
+    CRP_HIP(ctx, hipSetDevice(ctx->device));
+    rc = crp::grow(ctx, reinterpret_cast<void **>(&d.d_needles), &d.needles_cap, 2 * np, sizeof(uint32_t));
+    if (rc == CRP_OK) rc = crp::grow(ctx, reinterpret_cast<void **>(&d.d_bounds), &d.bounds_cap, 4 * np, sizeof(uint32_t));
+    if (rc != CRP_OK) return rc;
+    if (d.h_bounds_cap < 4 * np) {
+        if (d.h_bounds) (void)hipHostFree(d.h_bounds);
+        d.h_bounds = nullptr;
+        d.h_bounds_cap = 0;
+        CRP_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&d.h_bounds), 4 * np * sizeof(uint32_t), hipHostMallocDefault));
+        d.h_bounds_cap = 4 * np;
+    }
+    CRP_HIP(ctx, hipMemcpyAsync(d.d_needles, needles.data(), 2 * np * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    CRP_HIP(ctx, hipStreamSynchronize(ctx->stream));  // (`needles` leaves scope)
+    d.n_buckets = crp::pos16_buckets_for(d.arena->padded_words);
+    return CRP_OK;
+}
+
+// RCCL communicators of the node (ncclCommInitAll), once
+bool ensure_comms(crp_node *node)
+{
+    if (!node->comms.empty()) return true;
+    if (node->comms_tried) return false;
+    node->comms_tried = true;
+    const crp::Rccl *r = crp::rccl();
+    if (!r) {
+        node->comms_error = crp::rccl_load_error();
+        return false;
+    }
+    const size_t n = node->dev.size();
+    std::vector<int> ids(n);
+    for (size_t k = 0; k < n; ++k) ids[k] = node->dev[k].device;
+    std::vector<ncclComm_t> comms(n, nullptr);
+    const ncclResult_t st = r->CommInitAll(comms.data(), (int)n, ids.data());
+    if (st != ncclSuccess) {
+        node->comms_error = std::string("ncclCommInitAll: ") + r->GetErrorString(st);
+        return false;
+    }
+    node->comms = comms;
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+int crp_plan_shares(const uint64_t *lens, uint64_t n, int world, uint64_t min_piece, uint64_t *pieces, uint64_t cap,
+                    uint64_t *n_pieces)
+{
+    if ((n && !lens) || world < 1 || !n_pieces || (cap && !pieces)) return CRP_ERR_INVALID;
+    for (uint64_t k = 0; k < n; ++k)
+        if (lens[k] >> 62) return CRP_ERR_INVALID;
+    std::vector<std::array<uint64_t, 4>> out;
+    try {
+        plan_shares(lens, n, world, min_piece ? min_piece : 4096, out);
+    } catch (...) {
+        return CRP_ERR_NOMEM;
+    }
+    *n_pieces = out.size();
+    if (out.size() > cap) return CRP_ERR_CAPACITY;
+    for (size_t q = 0; q < out.size(); ++q) std::memcpy(pieces + 4 * q, out[q].data(), 4 * sizeof(uint64_t));
+    return CRP_OK;
+}
+
+int crp_node_init(int n_devices, const int *device_ids, crp_node **out)
+{
+    if (!out || n_devices < 1 || n_devices > 64 || !device_ids) return CRP_ERR_INVALID;
+    *out = nullptr;
+    crp_node *node = new (std::nothrow) crp_node();
+    if (!node) return CRP_ERR_NOMEM;
+    try {
+        node->dev.resize((size_t)n_devices);
+    } catch (...) {
+        delete node;
+        return CRP_ERR_NOMEM;
+    }
+    for (int k = 0; k < n_devices; ++k) {
+        NodeDev &d = node->dev[(size_t)k];
+        d.device = device_ids[k];
+        for (int j = 0; j < k; ++j)
+            if (device_ids[j] == device_ids[k]) node->duplicates = true;
+        int rc = crp_init(device_ids[k], &d.ctx);
+        if (rc == CRP_OK && hipEventCreateWithFlags(&d.ready, hipEventDisableTiming) != hipSuccess) rc = CRP_ERR_HIP;
+        if (rc != CRP_OK) {
+            crp_node_destroy(node);
+            return rc;
+        }
+    }
+    // the root pulls from (and RCCL's point-to-point kernels write into) its peers' memory: open the doors once
+    for (int a = 0; a < n_devices; ++a)
+        for (int b = 0; b < n_devices; ++b) {
+            const int da = device_ids[a], db = device_ids[b];
+            int can = 0;
+            if (da == db || hipDeviceCanAccessPeer(&can, da, db) != hipSuccess || !can) continue;
+            if (hipSetDevice(da) == hipSuccess) (void)hipDeviceEnablePeerAccess(db, 0);  // (already enabled: fine)
+        }
+    (void)hipGetLastError();
+    if (const char *e = std::getenv("CRP_NODE_TRANSPORT")) {
+        if (!std::strcmp(e, "peer")) node->transport_env = CRP_TRANSPORT_PEER_COPY;
+        else if (!std::strcmp(e, "rccl")) node->transport_env = CRP_TRANSPORT_RCCL;
+    }
+    *out = node;
+    return CRP_OK;
+}
+
+int crp_node_destroy(crp_node *node)
+{
+    if (!node) return CRP_OK;
+    for (NodeDev &d : node->dev)
+        if (d.ctx) (void)crp_synchronize(d.ctx);
+    if (!node->comms.empty() && crp::rccl())
+        for (ncclComm_t c : node->comms)
+            if (c) (void)crp::rccl()->CommDestroy(c);
+    node->comms.clear();
+    free_root_side(node);
+    free_genome(node);
+    for (NodeDev &d : node->dev) {
+        if (!d.ctx) continue;
+        (void)hipSetDevice(d.device);
+        (void)hipFree(d.d_needles);
+        (void)hipFree(d.d_bounds);
+        if (d.h_bounds) (void)hipHostFree(d.h_bounds);
+        for (int s = 0; s < 2; ++s) {
+            (void)hipFree(d.d_lo16[s]);
+            (void)hipFree(d.d_bstart[s]);
+        }
+        if (d.ready) (void)hipEventDestroy(d.ready);
+        (void)crp_destroy(d.ctx);
+    }
+    delete node;
+    return CRP_OK;
+}
+
+const char *crp_node_last_error(const crp_node *node) { return node ? node->last_error.c_str() : ""; }
+
+int crp_node_size(const crp_node *node) { return node ? (int)node->dev.size() : CRP_ERR_INVALID; }
+
+crp_ctx *crp_node_ctx(crp_node *node, int k)
+{
+    return (node && k >= 0 && (size_t)k < node->dev.size()) ? node->dev[(size_t)k].ctx : nullptr;
+}
+
+crp_arena *crp_node_arena(crp_node *node, int k)
+{
+    return (node && k >= 0 && (size_t)k < node->dev.size()) ? node->dev[(size_t)k].arena : nullptr;
+}
+
+int crp_node_load(crp_node *node, const uint8_t *const *texts, const uint64_t *lens, uint64_t n)
+{
+    crp::Range roctx_range("crp: node load (cut + H2D + pack on every device)");
+    if (!node || (n && (!texts || !lens))) return CRP_ERR_INVALID;
+    for (uint64_t k = 0; k < n; ++k)
+        if ((lens[k] && !texts[k]) || lens[k] >> 62) return CRP_ERR_INVALID;
+    free_genome(node);
+    const int world = (int)node->dev.size();
+    try {
+        std::vector<std::array<uint64_t, 4>> cut;
+        plan_shares(lens, n, world, 4096, cut);
+        node->pieces.reserve(cut.size());
+        for (const auto &c : cut) {
+            NodePiece p;
+            p.contig = c[0];
+            p.start = c[1];
+            p.end = c[2];
+            p.dev = (int)c[3];
+            p.text_lo = p.start > CRP_HALO ? p.start - CRP_HALO : 0;
+            p.text_len = std::min<uint64_t>(lens[p.contig], p.end + CRP_HALO) - p.text_lo;
+            p.arena_off = 0;
+            node->dev[(size_t)p.dev].pieces.push_back((uint32_t)node->pieces.size());
+            node->pieces.push_back(p);
+        }
+        node->n_contigs = n;
+        node->contig_counts.assign(2 * n, 0);
+    } catch (...) {
+        free_genome(node);
+        return CRP_ERR_NOMEM;
+    }
+    // one host thread per device: its share crosses its own PCIe link while the others' cross theirs
+    std::vector<int> rcs((size_t)world, CRP_OK);
+    {
+        std::vector<std::thread> pool((size_t)world);
+        for (int k = 1; k < world; ++k) {
+            try {
+                pool[(size_t)k] = std::thread([node, k, texts, &rcs] {
+                    try {
+                        rcs[(size_t)k] = load_device(node, k, texts);
+                    } catch (...) {
+                        rcs[(size_t)k] = CRP_ERR_NOMEM;
+                    }
+                });
+            } catch (...) {  // no thread to be had: this one does the share
+                try {
+                    rcs[(size_t)k] = load_device(node, k, texts);
+                } catch (...) {
+                    rcs[(size_t)k] = CRP_ERR_NOMEM;
+                }
+            }
+        }
+        try {
+            rcs[0] = load_device(node, 0, texts);
+        } catch (...) {
+            rcs[0] = CRP_ERR_NOMEM;
+        }
+        for (auto &t : pool)
+            if (t.joinable()) t.join();
+    }
+    for (int k = 0; k < world; ++k)
+        if (rcs[(size_t)k] != CRP_OK) {
+            const int rc = dev_fail(node, k, rcs[(size_t)k], "crp_node_load");
+            const std::string keep = node->last_error;
+            free_genome(node);
+            node->last_error = keep;
+            return rc;
+        }
+    node->loaded = true;
+    return CRP_OK;
+}
+
+int crp_node_plan(const crp_node *node, uint64_t *pieces, uint64_t cap, uint64_t *n_pieces)
+{
+    if (!node || !n_pieces || (cap && !pieces)) return CRP_ERR_INVALID;
+    if (!node->loaded) return CRP_ERR_STATE;
+    *n_pieces = node->pieces.size();
+    if (node->pieces.size() > cap) return CRP_ERR_CAPACITY;
+    for (size_t q = 0; q < node->pieces.size(); ++q) {
+        const NodePiece &p = node->pieces[q];
+        const uint64_t row[6] = {p.contig, p.start, p.end, (uint64_t)p.dev, p.arena_off, p.start - p.text_lo};
+        std::memcpy(pieces + 6 * q, row, sizeof row);
+    }
+    return CRP_OK;
+}
+
+int crp_node_scan_score(crp_node *node, int guide_len, int flags, uint64_t *n_plus, uint64_t *n_minus)
+{
+    crp::Range roctx_range("crp: node scan + score (all devices)");
+    if (!node) return CRP_ERR_INVALID;
+    if (!node->loaded) return CRP_ERR_STATE;
+    node->have_gather = false;
+    const int world = (int)node->dev.size();
+    int rc = CRP_OK, begun = 0;
+    // queue the launch on every device ...
+    for (; begun < world && rc == CRP_OK; ++begun) {
+        NodeDev &d = node->dev[(size_t)begun];
+        if (d.arena) rc = dev_fail(node, begun, crp::scan_begin(d.arena, guide_len, flags), "crp_node_scan_score (launch)");
+    }
+    if (rc != CRP_OK) begun -= 1;  // (the one that failed queued nothing)
+    // ... then collect them: the kernels run side by side
+    uint64_t tot[2] = {0, 0};
+    for (int k = 0; k < begun; ++k) {
+        NodeDev &d = node->dev[(size_t)k];
+        if (!d.arena) continue;
+        uint64_t a = 0, b = 0;
+        const int rk = crp::scan_finish(d.arena, &a, &b);
+        if (rk != CRP_OK && rc == CRP_OK) rc = dev_fail(node, k, rk, "crp_node_scan_score");
+        tot[0] += a;
+        tot[1] += b;
+    }
+    if (rc != CRP_OK) return rc;
+    if (n_plus) *n_plus = tot[0];
+    if (n_minus) *n_minus = tot[1];
+    return CRP_OK;
+}
+
+int crp_node_gather(crp_node *node, int root, int flags)
+{
+    crp::Range roctx_range("crp: node gatherv");
+    if (!node || root < 0 || (size_t)root >= node->dev.size() || (flags & ~(CRP_GATHER_PRE | CRP_GATHER_POS16 | CRP_NODE_PEER_COPY)))
+        return CRP_ERR_INVALID;
+    if (!node->loaded) return CRP_ERR_STATE;
+    const bool send_pre = (flags & CRP_GATHER_PRE) != 0, pos16 = (flags & CRP_GATHER_POS16) != 0;
+    const int world = (int)node->dev.size();
+    for (int k = 0; k < world; ++k) {
+        const crp_arena *a = node->dev[(size_t)k].arena;
+        if (a && (!a->have_hits || (send_pre && !a->have_pre))) {
+            node->last_error = "crp_node_gather: logical device " + std::to_string(k) + " has no (matching) tables: scan first";
+            return CRP_ERR_STATE;
+        }
+    }
+    node->have_gather = false;
+    const auto t_call = std::chrono::steady_clock::now();
+
+    // ---- 1. ownership cuts: per device and strand, the index of the first row at or after every needle
+    for (int k = 0; k < world; ++k) {
+        NodeDev &d = node->dev[(size_t)k];
+        if (!d.arena) continue;
+        crp_ctx *ctx = d.ctx;
+        const uint32_t nn = (uint32_t)(2 * d.pieces.size());
+        NODE_HIP(node, hipSetDevice(d.device));
+        for (int s = 0; s < 2; ++s)
+            NODE_HIP(node, crp::launch_lower_bound(ctx->stream, d.arena->d_pos[s], d.arena->n_hits[s], d.d_needles, nn, d.d_bounds + (size_t)s * nn));
+        NODE_HIP(node, hipMemcpyAsync(d.h_bounds, d.d_bounds, 2 * (size_t)nn * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    for (int k = 0; k < world; ++k) {
+        NodeDev &d = node->dev[(size_t)k];
+        if (!d.arena) continue;
+        NODE_HIP(node, hipSetDevice(d.device));
+        NODE_HIP(node, hipStreamSynchronize(d.ctx->stream));
+    }
+    std::fill(node->contig_counts.begin(), node->contig_counts.end(), 0);
+    uint64_t total[2] = {0, 0};
+    for (int k = 0; k < world; ++k) {
+        NodeDev &d = node->dev[(size_t)k];
+        for (int s = 0; s < 2; ++s) d.first[s] = d.last[s] = 0, d.foff[s] = total[s];
+        if (!d.arena) continue;
+        const size_t np = d.pieces.size();
+        for (int s = 0; s < 2; ++s) {
+            const uint32_t *b = d.h_bounds + (size_t)s * 2 * np;
+            d.first[s] = b[0];
+            d.last[s] = b[2 * np - 1];
+            for (size_t j = 0; j < np; ++j) {
+                // contiguous shares: only a device's first piece has a left halo and only its last a right one, so its
+                // owned rows are ONE run of each table
+                if (b[2 * j + 1] < b[2 * j] || (j + 1 < np && b[2 * j + 2] != b[2 * j + 1])) {
+                    node->last_error = "crp_node_gather: the owned rows of logical device " + std::to_string(k) + " are not one run";
+                    return CRP_ERR_STATE;
+                }
+                node->contig_counts[2 * node->pieces[d.pieces[j]].contig + (size_t)s] += b[2 * j + 1] - b[2 * j];
+            }
+            total[s] += d.last[s] - d.first[s];
+        }
+    }
+
+    // ---- 2. transport, and the root's side: final tables, staging, piece maps
+    bool peer_copy = node->duplicates || (flags & CRP_NODE_PEER_COPY) || node->transport_env == CRP_TRANSPORT_PEER_COPY;
+    // (a one-device node has no peer; CRP_NODE_TRANSPORT=rccl still creates its communicator, for tests of the RCCL path)
+    const bool want_comms = !peer_copy && (world > 1 || node->transport_env == CRP_TRANSPORT_RCCL);
+    if (want_comms && !ensure_comms(node)) {
+        if (node->transport_env == CRP_TRANSPORT_RCCL) {
+            node->last_error = "crp_node_gather: RCCL asked for (CRP_NODE_TRANSPORT=rccl) but unavailable: " + node->comms_error;
+            return CRP_ERR_COMM;
+        }
+        peer_copy = true;  // (crp_node_gather_stats reports the transport that ran; comms_error says why)
+        node->last_error = "RCCL unavailable (" + node->comms_error + "): device-to-device copies used";
+    }
+    if (node->root != root) free_root_side(node);
+    node->root = root;
+    NodeDev &R = node->dev[(size_t)root];
+    crp_ctx *rctx = R.ctx;
+    NODE_HIP(node, hipSetDevice(R.device));
+    std::vector<uint64_t> soff[2], boff[2];  // per device: element offsets into the staging buffers
+    for (int s = 0; s < 2; ++s) {
+        soff[s].assign((size_t)world, 0);
+        boff[s].assign((size_t)world, 0);
+        uint64_t lo_total = 0, b_total = 0;
+        for (int k = 0; k < world; ++k) {
+            const NodeDev &d = node->dev[(size_t)k];
+            if (k == root || !pos16 || !d.arena) continue;
+            soff[s][(size_t)k] = lo_total;
+            boff[s][(size_t)k] = b_total;
+            lo_total += round_up8(d.last[s] - d.first[s]);
+            b_total += d.n_buckets;
+        }
+        int rc = crp::grow(rctx, reinterpret_cast<void **>(&node->d_fpos[s]), &node->fpos_cap[s], total[s], sizeof(uint32_t));
+        if (rc == CRP_OK) rc = crp::grow(rctx, reinterpret_cast<void **>(&node->d_fscore[s]), &node->fscore_cap[s], total[s], sizeof(double));
+        if (rc == CRP_OK && lo_total) rc = crp::grow(rctx, reinterpret_cast<void **>(&node->d_slo16[s]), &node->slo16_cap[s], lo_total, sizeof(uint16_t));
+        if (rc == CRP_OK && b_total) rc = crp::grow(rctx, reinterpret_cast<void **>(&node->d_sbstart[s]), &node->sbstart_cap[s], b_total, sizeof(uint32_t));
+        if (rc != CRP_OK) return dev_fail(node, root, rc, "crp_node_gather (root's tables)");
+    }
+    {   // piece maps: begin[] and sub[] per device, one upload
+        node->map_off.assign((size_t)world, 0);
+        node->h_map.clear();
+        for (int k = 0; k < world; ++k) {
+            const NodeDev &d = node->dev[(size_t)k];
+            node->map_off[(size_t)k] = node->h_map.size();
+            for (uint32_t q : d.pieces) {
+                const NodePiece &p = node->pieces[q];
+                node->h_map.push_back((uint32_t)(p.arena_off + (p.start - p.text_lo)));
+            }
+            for (uint32_t q : d.pieces) {
+                const NodePiece &p = node->pieces[q];
+                node->h_map.push_back((uint32_t)(p.arena_off + (p.start - p.text_lo) - p.start));  // (mod 2^32)
+            }
+        }
+        int rc = crp::grow(rctx, reinterpret_cast<void **>(&node->d_map), &node->map_cap, node->h_map.size(), sizeof(uint32_t));
+        if (rc != CRP_OK) return dev_fail(node, root, rc, "crp_node_gather (piece maps)");
+        if (!node->h_map.empty())
+            NODE_HIP(node, hipMemcpyAsync(node->d_map, node->h_map.data(), node->h_map.size() * sizeof(uint32_t), hipMemcpyHostToDevice,
+                                          rctx->stream));
+    }
+    auto map_of = [&](int k) {
+        const size_t np = node->dev[(size_t)k].pieces.size();
+        return crp::PieceMap{node->d_map + node->map_off[(size_t)k], node->d_map + node->map_off[(size_t)k] + np, (uint32_t)np};
+    };
+    if (peer_copy && node->pull.size() != (size_t)world) {
+        node->pull.assign((size_t)world, nullptr);
+        node->pulled.assign((size_t)world, nullptr);
+        for (int k = 0; k < world; ++k) {
+            if (k == root) continue;
+            NODE_HIP(node, hipStreamCreateWithFlags(&node->pull[(size_t)k], hipStreamNonBlocking));
+            NODE_HIP(node, hipEventCreateWithFlags(&node->pulled[(size_t)k], hipEventDisableTiming));
+        }
+    }
+    NODE_HIP(node, hipStreamSynchronize(rctx->stream));  // (the maps are in place; the exchange is timed from here)
+    const auto t_x = std::chrono::steady_clock::now();
+
+    // ---- 3. the peers' side: pack the positions of the owned rows
+    for (int k = 0; k < world; ++k) {
+        NodeDev &d = node->dev[(size_t)k];
+        if (k == root || !d.arena) continue;
+        crp_ctx *ctx = d.ctx;
+        NODE_HIP(node, hipSetDevice(d.device));
+        if (pos16)
+            for (int s = 0; s < 2; ++s) {
+                const uint64_t n = d.last[s] - d.first[s];
+                int rc = crp::grow(ctx, reinterpret_cast<void **>(&d.d_lo16[s]), &d.lo16_cap[s], round_up8(n), sizeof(uint16_t));
+                if (rc == CRP_OK) rc = crp::grow(ctx, reinterpret_cast<void **>(&d.d_bstart[s]), &d.bstart_cap[s], d.n_buckets, sizeof(uint32_t));
+                if (rc != CRP_OK) return dev_fail(node, k, rc, "crp_node_gather (packed positions)");
+                NODE_HIP(node, crp::launch_pos16_buckets(ctx->stream, d.arena->d_pos[s], d.arena->n_hits[s], d.first[s], d.last[s],
+                                                         d.d_bstart[s], d.n_buckets));
+                NODE_HIP(node, crp::launch_pos16_pack(ctx->stream, d.arena->d_pos[s] + d.first[s], n, d.d_lo16[s]));
+            }
+        if (peer_copy) NODE_HIP(node, hipEventRecord(d.ready, ctx->stream));
+    }
+
+    // ---- 4. the exchange
+    uint64_t moved = 0;
+    const crp::Rccl *r = (want_comms && !peer_copy) ? crp::rccl() : nullptr;
+    ncclResult_t st = ncclSuccess, st_end = ncclSuccess;
+    if (r) st = r->GroupStart();
+    for (int k = 0; k < world && st == ncclSuccess; ++k) {
+        NodeDev &d = node->dev[(size_t)k];
+        if (k == root || !d.arena) continue;
+        if (!r) {  // this peer's pull stream starts once the peer's side is in place
+            NODE_HIP(node, hipSetDevice(R.device));
+            NODE_HIP(node, hipStreamWaitEvent(node->pull[(size_t)k], d.ready, 0));
+        }
+        for (int s = 0; s < 2 && st == ncclSuccess; ++s) {
+            const uint64_t n = d.last[s] - d.first[s];
+            if (!n) continue;
+            // three columns at most: packed positions + bucket starts (or raw positions), and the f64 column
+            struct Col {
+                const void *src;
+                void *dst;
+                uint64_t bytes;
+            } cols[3];
+            int nc = 0;
+            if (pos16) {
+                cols[nc++] = Col{d.d_lo16[s], node->d_slo16[s] + soff[s][(size_t)k], n * sizeof(uint16_t)};
+                cols[nc++] = Col{d.d_bstart[s], node->d_sbstart[s] + boff[s][(size_t)k], (uint64_t)d.n_buckets * sizeof(uint32_t)};
+            } else {
+                cols[nc++] = Col{d.arena->d_pos[s] + d.first[s], node->d_fpos[s] + d.foff[s], n * sizeof(uint32_t)};
+            }
+            cols[nc++] = Col{(send_pre ? d.arena->d_pre[s] : d.arena->d_score[s]) + d.first[s], node->d_fscore[s] + d.foff[s], n * sizeof(double)};
+            for (int c = 0; c < nc && st == ncclSuccess; ++c) {
+                moved += cols[c].bytes;
+                if (r) {
+                    st = r->Send(cols[c].src, cols[c].bytes, ncclUint8, root, node->comms[(size_t)k], d.ctx->stream);
+                    if (st == ncclSuccess) st = r->Recv(cols[c].dst, cols[c].bytes, ncclUint8, k, node->comms[(size_t)root], rctx->stream);
+                } else {
+                    hipStream_t ps = node->pull[(size_t)k];
+                    if (d.device == R.device)
+                        NODE_HIP(node, hipMemcpyAsync(cols[c].dst, cols[c].src, cols[c].bytes, hipMemcpyDeviceToDevice, ps));
+                    else
+                        NODE_HIP(node, hipMemcpyPeerAsync(cols[c].dst, R.device, cols[c].src, d.device, cols[c].bytes, ps));
+                }
+            }
+        }
+        if (!r) {  // the root's stream goes on once this peer's rows have landed
+            NODE_HIP(node, hipEventRecord(node->pulled[(size_t)k], node->pull[(size_t)k]));
+            NODE_HIP(node, hipStreamWaitEvent(rctx->stream, node->pulled[(size_t)k], 0));
+        }
+    }
+    if (r) st_end = r->GroupEnd();
+    if (st != ncclSuccess || st_end != ncclSuccess) {
+        node->last_error = std::string("crp_node_gather send/recv: ") + r->GetErrorString(st != ncclSuccess ? st : st_end);
+        return CRP_ERR_COMM;
+    }
+
+    // ---- 5. the root's side: expand / rebase into the final tables (its own rows never cross a link)
+    NODE_HIP(node, hipSetDevice(R.device));
+    for (int k = 0; k < world; ++k) {
+        NodeDev &d = node->dev[(size_t)k];
+        if (!d.arena) continue;
+        for (int s = 0; s < 2; ++s) {
+            const uint64_t n = d.last[s] - d.first[s];
+            if (!n) continue;
+            uint32_t *out = node->d_fpos[s] + d.foff[s];
+            if (k == root) {
+                NODE_HIP(node, crp::launch_pos_rebase(rctx->stream, d.arena->d_pos[s] + d.first[s], n, map_of(k), out));
+                NODE_HIP(node, hipMemcpyAsync(node->d_fscore[s] + d.foff[s], (send_pre ? d.arena->d_pre[s] : d.arena->d_score[s]) + d.first[s],
+                                              n * sizeof(double), hipMemcpyDeviceToDevice, rctx->stream));
+            } else if (pos16) {
+                NODE_HIP(node, crp::launch_pos16_expand(rctx->stream, node->d_slo16[s] + soff[s][(size_t)k], n,
+                                                        node->d_sbstart[s] + boff[s][(size_t)k], d.n_buckets, map_of(k), out));
+            } else {
+                NODE_HIP(node, crp::launch_pos_rebase(rctx->stream, out, n, map_of(k), out));  // in place: a thread rewrites the rows it read
+            }
+        }
+    }
+    NODE_HIP(node, hipStreamSynchronize(rctx->stream));
+    for (int k = 0; k < world; ++k) {  // the sends read the peers' tables: they must have left before the next scan
+        NodeDev &d = node->dev[(size_t)k];
+        if (k == root || !d.arena) continue;
+        NODE_HIP(node, hipSetDevice(d.device));
+        NODE_HIP(node, hipStreamSynchronize(d.ctx->stream));
+    }
+    node->ms_exchange = ms_since(t_x);
+    node->ms_total = ms_since(t_call);
+    node->bytes_to_root = moved;
+    node->transport = r ? CRP_TRANSPORT_RCCL : (world == 1 ? 0 : CRP_TRANSPORT_PEER_COPY);
+    node->total[0] = total[0];
+    node->total[1] = total[1];
+    node->have_gather = true;
+    return CRP_OK;
+}
+
+int crp_node_counts(const crp_node *node, uint64_t *per_contig, uint64_t *n_plus, uint64_t *n_minus)
+{
+    if (!node) return CRP_ERR_INVALID;
+    if (!node->have_gather) return CRP_ERR_STATE;
+    if (per_contig && !node->contig_counts.empty())
+        std::memcpy(per_contig, node->contig_counts.data(), node->contig_counts.size() * sizeof(uint64_t));
+    if (n_plus) *n_plus = node->total[0];
+    if (n_minus) *n_minus = node->total[1];
+    return CRP_OK;
+}
+
+int crp_node_fetch(crp_node *node, uint32_t *pos_plus, double *score_plus, uint32_t *pos_minus, double *score_minus)
+{
+    crp::Range roctx_range("crp: node D2H tables");
+    if (!node) return CRP_ERR_INVALID;
+    if (!node->have_gather) return CRP_ERR_STATE;
+    crp_ctx *ctx = node->dev[(size_t)node->root].ctx;
+    NODE_HIP(node, hipSetDevice(ctx->device));
+    uint32_t *hp[2] = {pos_plus, pos_minus};
+    double *hs[2] = {score_plus, score_minus};
+    for (int s = 0; s < 2; ++s) {
+        const uint64_t n = node->total[s];
+        if (!n) continue;
+        int rc = CRP_OK;
+        if (hp[s]) rc = crp::staged_d2h(ctx, hp[s], node->d_fpos[s], n * sizeof(uint32_t));
+        if (rc == CRP_OK && hs[s]) rc = crp::staged_d2h(ctx, hs[s], node->d_fscore[s], n * sizeof(double));
+        if (rc != CRP_OK) return dev_fail(node, node->root, rc, "crp_node_fetch");
+    }
+    NODE_HIP(node, hipStreamSynchronize(ctx->stream));
+    return CRP_OK;
+}
+
+int crp_node_tables_device(crp_node *node, void **pos_plus, void **score_plus, void **pos_minus, void **score_minus)
+{
+    if (!node) return CRP_ERR_INVALID;
+    if (!node->have_gather) return CRP_ERR_STATE;
+    if (pos_plus) *pos_plus = node->d_fpos[0];
+    if (score_plus) *score_plus = node->d_fscore[0];
+    if (pos_minus) *pos_minus = node->d_fpos[1];
+    if (score_minus) *score_minus = node->d_fscore[1];
+    return CRP_OK;
+}
+
+int crp_node_gather_stats(const crp_node *node, double *ms_total, double *ms_exchange, uint64_t *bytes_to_root, int *transport)
+{
+    if (!node) return CRP_ERR_INVALID;
+    if (!node->have_gather) return CRP_ERR_STATE;
+    if (ms_total) *ms_total = node->ms_total;
+    if (ms_exchange) *ms_exchange = node->ms_exchange;
+    if (bytes_to_root) *bytes_to_root = node->bytes_to_root;
+    if (transport) *transport = node->transport;
+    return CRP_OK;
+}
+
+}  // extern "C"

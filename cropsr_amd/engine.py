@@ -475,17 +475,25 @@ class Engine:
                   "crp_comm_allreduce_f64", self._ctx)
         return list(a)
 
-    def gather_hits(self, arena, root=0, offtarget=False, pre=False, features=False):
+    def gather_hits(self, arena, root=0, offtarget=False, pre=False, features=False, pos16=True):
         """The gatherv of the path (crp_gather_hits): every rank's tables of `arena` (None: empty) into
-        root's HBM.  pre=True: the f64 column is the pre-sigmoid sum instead of the score.  Returns
-        the (world, 2) counts every rank contributed."""
+        root's HBM.  pre=True: the f64 column is the pre-sigmoid sum instead of the score.  pos16 (the same on every
+        rank): positions cross the links as 16 bits per hit + one word per 65 536 arena positions (CRP_GATHER_POS16:
+        exact; 10 B per hit instead of 12).  Returns the (world, 2) counts every rank contributed."""
         world = self.query()["comm_world"]
         counts = np.zeros((world, 2), dtype=np.uint64)
-        flags = (nat.GATHER_OFFTARGET if offtarget else 0) | (nat.GATHER_PRE if pre else 0) | (nat.GATHER_FEATURES if features else 0)
+        flags = ((nat.GATHER_OFFTARGET if offtarget else 0) | (nat.GATHER_PRE if pre else 0) | (nat.GATHER_FEATURES if features else 0) |
+                 (nat.GATHER_POS16 if pos16 else 0))
         nat.check(nat.lib().crp_gather_hits(self._ctx, arena._h if arena is not None else None, int(root),
                                             flags, counts.ctypes.data_as(nat.u64p)),
                   "crp_gather_hits", self._ctx)
         return counts
+
+    def gather_bytes(self):
+        """Bytes this rank sent to the root (a peer) or received from all peers (the root) in the last gather_hits."""
+        v = ctypes.c_int64()
+        nat.check(nat.lib().crp_query(self._ctx, nat.Q_GATHER_BYTES, ctypes.byref(v)), "crp_query", self._ctx)
+        return int(v.value)
 
     def gathered_fetch(self, rank, counts, offtarget=False, features=False):
         """Root: host copies of what `rank` contributed to the last gather_hits -> column dict."""

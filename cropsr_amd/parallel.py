@@ -161,9 +161,28 @@ def _table_keys(offtarget, features=False):
     return COLUMNS + (("ot_plus", "ot_minus") if offtarget else ()) + (("feat_plus", "feat_minus") if features else ())
 
 
-def gather_host(group, arenas_cols, dst=0, offtarget=False, features=False):
+def pack_pos16(pos):
+    """An ascending uint32 position table as (lo16, bstart): the low 16 bits of every position and, per 65 536 positions,
+    the index of the first entry at or after it -- what crosses the links with CRP_GATHER_POS16 (crp_gather.hip; here in
+    numpy for the socket transport): exact, 2 B per hit + 4 B per 65 536 positions instead of 4 B per hit."""
+    pos = np.ascontiguousarray(pos, dtype=np.uint32)
+    n_buckets = (int(pos[-1]) >> 16) + 1 if pos.size else 1
+    needles = (np.arange(n_buckets, dtype=np.uint64) << np.uint64(16)).astype(np.uint32)  # (the tables' own dtype: no conversion)
+    return pos.astype(np.uint16), np.searchsorted(pos, needles, "left").astype(np.uint32)
+
+
+def unpack_pos16(lo16, bstart):
+    lo16 = np.asarray(lo16, dtype=np.uint16)
+    bstart = np.asarray(bstart, dtype=np.uint32).astype(np.int64)
+    per_bucket = np.diff(np.append(bstart, lo16.size))
+    high = np.repeat(np.arange(bstart.size, dtype=np.uint32) << np.uint32(16), per_bucket)
+    return high | lo16.astype(np.uint32)
+
+
+def gather_host(group, arenas_cols, dst=0, offtarget=False, features=False, pos16=True):
     """gatherv over the control sockets: arenas_cols = this rank's column dicts (numpy), one per
-    arena.  Returns on dst [rank][arena] -> column dict, None elsewhere."""
+    arena.  Returns on dst [rank][arena] -> column dict, None elsewhere.  pos16: the position columns travel
+    packed (pack_pos16), like CRP_GATHER_POS16 on RCCL.  group.bytes_gathered (on dst) = what the peers sent."""
     if dst != 0:
         raise ValueError("the host transport gathers to rank 0")
     keys = _table_keys(offtarget, features)
@@ -171,14 +190,31 @@ def gather_host(group, arenas_cols, dst=0, offtarget=False, features=False):
     if group.rank != dst:
         for cols in arenas_cols:
             for k in keys:
-                group.send_array(cols[k])
+                if pos16 and k.startswith("pos_"):
+                    for part in pack_pos16(cols[k]):
+                        group.send_array(part)
+                else:
+                    group.send_array(cols[k])
         return None
+    moved = 0
+
+    def recv(r, k):
+        nonlocal moved
+        if pos16 and k.startswith("pos_"):
+            lo16, bstart = group.recv_array(r), group.recv_array(r)
+            moved += lo16.nbytes + bstart.nbytes
+            return unpack_pos16(lo16, bstart)
+        a = group.recv_array(r)
+        moved += a.nbytes
+        return a
+
     out = []
     for r in range(group.world):
         if r == dst:
             out.append([{k: np.asarray(cols[k]) for k in keys} for cols in arenas_cols])
         else:
-            out.append([{k: group.recv_array(r) for k in keys} for _ in range(n_arenas[r])])
+            out.append([{k: recv(r, k) for k in keys} for _ in range(n_arenas[r])])
+    group.bytes_gathered = moved
     return out
 
 

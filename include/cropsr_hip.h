@@ -19,8 +19,10 @@
  *   - plain C types only; every function returns 0 (CRP_OK) or a negative
  *     crp_status; nothing throws, aborts or prints.
  *   - the caller owns every host buffer; the library owns every device buffer.
- *   - one crp_ctx per process and GPU (one process per GPU); calls on one
- *     handle are serialised by the caller.
+ *   - one crp_ctx per GPU; calls on one handle are serialised by the caller.  Two ways to the whole node: one
+ *     process per GPU, each with its own crp_ctx and an RCCL communicator across them (crp_comm_*), or ONE process
+ *     with a crp_node over N devices (crp_node_*: the fan-out, the cut of the genome and the gatherv happen inside
+ *     the library) -- what the single-process reference script binds.
  *   - there is NO CPU fallback: without a usable HIP device crp_init fails.
  *
  * Coordinates.  A contig is handed over as the exact character string the
@@ -40,7 +42,7 @@
 extern "C" {
 #endif
 
-#define CRP_ABI_VERSION 4
+#define CRP_ABI_VERSION 5
 
 typedef enum crp_status {
     CRP_OK = 0,
@@ -268,6 +270,11 @@ int crp_comm_allreduce_f64(crp_ctx *ctx, double *values, int n, int op);
 /* CRP_GATHER_FEATURES: also gathers the per-hit label-set ids of the annotation join (crp_annotate_lookup must
  * have run on `arena` since its last scan; else CRP_ERR_STATE, agreed on like the others). */
 #define CRP_GATHER_FEATURES 4
+/* CRP_GATHER_POS16: positions cross the links as 16 bits per hit plus one uint32 per 65 536 arena positions (the index of
+ * the first hit at or after it) instead of 32 bits per hit -- tables are ascending, so this is exact and needs no escape:
+ * 10 B per hit instead of 12.  A small kernel packs on the peers, another expands into the root's table
+ * (crp_gather.hip); what crp_gathered_fetch returns is bit for bit the same. */
+#define CRP_GATHER_POS16 8
 int crp_gather_hits(crp_ctx *ctx, crp_arena *arena, int root, int flags, uint64_t *counts_all);
 /* Root only: copy the tables rank `rank` contributed to the last crp_gather_hits to host arrays
  * (sizes from counts_all; ot_*: 4 x uint32 per hit; any pointer may be NULL). */
@@ -276,6 +283,67 @@ int crp_gathered_fetch(crp_ctx *ctx, int rank, uint32_t *pos_plus, double *score
 
 /* Root only, after a crp_gather_hits with CRP_GATHER_FEATURES: the ids rank `rank` contributed (uint32 per hit). */
 int crp_gathered_fetch_features(crp_ctx *ctx, int rank, uint32_t *feat_plus, uint32_t *feat_minus);
+
+/* ---- multi-GPU: ONE process over N GPUs, the node handle -------------------- */
+/* The reference is one process with one contig loop (CROPSR.py:333, :409).  A crp_node lets that one process drive N
+ * GPUs through one handle: crp_node_load cuts the genome into N contiguous equal shares (a contig that straddles a
+ * share boundary is cut there; every piece carries CRP_HALO characters of context either side, a hit belongs to the
+ * piece that contains its match index) and uploads every share to its device; crp_node_scan_score queues the scan on
+ * every device before it waits for any; crp_node_gather is the path's one exchange, the gatherv of the per-device tables
+ * to a root device -- RCCL in one process (ncclCommInitAll; per peer ncclSend, at the root ncclRecv, all inside one
+ * ncclGroupStart / ncclGroupEnd) or, where RCCL cannot run (the same device listed twice: rehearsals on one GPU) or is
+ * not wanted, device-to-device copies the root pulls over its own streams, one per peer.  The root ends up with ONE
+ * table per strand, in contig order, positions LOCAL to their contig string: exactly the regex match indices the
+ * reference iterates over, bit for bit what one GPU alone produces.  The per-device crp_ctx / crp_arena stay
+ * reachable (crp_node_ctx / crp_node_arena) for crp_configure, crp_profile_*, crp_device_info and the like. */
+#define CRP_HALO 128
+typedef struct crp_node crp_node;
+/* Host side (no GPU needed): the cut.  lens[0..n): contig string lengths, in order.  Device r gets the characters
+ * [r, r + 1) * total / world of the concatenation; a contig that straddles a boundary is cut there unless one side
+ * would be shorter than min_piece (0: 4096) -- then it stays whole on the side that holds most of it.  pieces: 4 x uint64
+ * per piece {contig, start, end, device}, in contig order; CRP_ERR_CAPACITY with the needed count in *n_pieces when cap
+ * (in pieces) is too small.  At most n + world - 1 pieces. */
+int crp_plan_shares(const uint64_t *lens, uint64_t n, int world, uint64_t min_piece, uint64_t *pieces, uint64_t cap,
+                    uint64_t *n_pieces);
+/* Opens the listed HIP devices (indices as this process sees them; the same index may appear more than once: each
+ * entry is a logical device with a context of its own). */
+int crp_node_init(int n_devices, const int *device_ids, crp_node **out);
+int crp_node_destroy(crp_node *node);
+/* Text of the last failure on the node or on one of its devices. */
+const char *crp_node_last_error(const crp_node *node);
+int crp_node_size(const crp_node *node);           /* number of logical devices (negative status on a NULL handle) */
+crp_ctx *crp_node_ctx(crp_node *node, int k);      /* logical device k's context (NULL: out of range) */
+crp_arena *crp_node_arena(crp_node *node, int k);  /* its arena after crp_node_load (NULL: none -- the device got no piece) */
+/* The genome: n contig strings, in order (the strings CROPSR.py:409 iterates over).  Cuts (crp_plan_shares), uploads
+ * share r to device r (one host thread per device), seals.  The caller's strings are read, not kept.  A second call
+ * replaces the genome. */
+int crp_node_load(crp_node *node, const uint8_t *const *texts, const uint64_t *lens, uint64_t n);
+/* The cut that was made: 6 x uint64 per piece {contig, start, end, device, arena offset of the piece's text on that
+ * device, index of `start` inside that text (the left halo's length)}.  Same capacity protocol as crp_plan_shares. */
+int crp_node_plan(const crp_node *node, uint64_t *pieces, uint64_t cap, uint64_t *n_pieces);
+/* crp_scan_score on every device at once (same guide_len / flags).  *n_plus / *n_minus (may be NULL): rows of all
+ * devices' tables together, INCLUDING the few hits inside halos (at most 2 x CRP_HALO positions per device); the
+ * exact totals come from crp_node_gather. */
+int crp_node_scan_score(crp_node *node, int guide_len, int flags, uint64_t *n_plus, uint64_t *n_minus);
+/* The gatherv: every device's OWNED rows to logical device `root`.  flags: CRP_GATHER_PRE (the f64 column is the
+ * pre-sigmoid sum), CRP_GATHER_POS16 (10 B per hit on the links instead of 12, see above),
+ * CRP_NODE_PEER_COPY (device-to-device copies instead of RCCL for this call; always the case when a device is
+ * listed twice, or when the environment says CRP_NODE_TRANSPORT=peer). */
+#define CRP_NODE_PEER_COPY 16
+int crp_node_gather(crp_node *node, int root, int flags);
+/* After crp_node_gather: kept hits per contig and strand (2 x n contigs: {plus, minus}) and in all; any pointer may
+ * be NULL. */
+int crp_node_counts(const crp_node *node, uint64_t *per_contig, uint64_t *n_plus, uint64_t *n_minus);
+/* The gathered tables to host arrays (n_plus / n_minus rows; contig order, ascending inside a contig, positions local
+ * to the contig string; any pointer may be NULL), and their addresses in the root's HBM (valid until the next
+ * crp_node_gather / crp_node_load). */
+int crp_node_fetch(crp_node *node, uint32_t *pos_plus, double *score_plus, uint32_t *pos_minus, double *score_minus);
+int crp_node_tables_device(crp_node *node, void **pos_plus, void **score_plus, void **pos_minus, void **score_minus);
+/* The last crp_node_gather in numbers: wall time of the whole call and of its exchange step alone (ms), bytes that
+ * crossed from peers to the root, transport used (1 RCCL, 2 device-to-device copies).  Any pointer may be NULL. */
+#define CRP_TRANSPORT_RCCL 1
+#define CRP_TRANSPORT_PEER_COPY 2
+int crp_node_gather_stats(const crp_node *node, double *ms_total, double *ms_exchange, uint64_t *bytes_to_root, int *transport);
 
 /* ---- annotation join (opt-in; a no-op in the reference) -------------------- */
 /* BASELINE.json configs[2], [3] name a GFF and a Phytozome annotation_info file.  The reference parses the GFF
@@ -398,6 +466,7 @@ int crp_configure(crp_ctx *ctx, int option, int64_t value);
 #define CRP_Q_COMM_RANK 4
 #define CRP_Q_HBM_FREE 5         /* bytes of device memory free right now, as hipMemGetInfo sees the whole device (all processes) */
 #define CRP_Q_HBM_TOTAL 6
+#define CRP_Q_GATHER_BYTES 7     /* last crp_gather_hits: bytes this rank sent to the root (a peer) or received from all peers (the root) */
 int crp_query(const crp_ctx *ctx, int what, int64_t *value);
 /* Identifies the build: a hash of the library's sources taken by the Makefile ("unknown" otherwise).
  * profiles/traffic.json carries the id of the build it was measured on; bench.py refuses another. */

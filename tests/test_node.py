@@ -1,0 +1,286 @@
+"""The single-process node handle (crp_node_*): ONE process, N logical devices, the cut, the fan-out
+and the gatherv inside the library.  The reference is one process with one contig loop (CROPSR.py:333, :409); what the
+node returns must be, contig by contig, exactly what that loop appends -- i.e. what one GPU alone returns and what the
+oracle says.
+
+CPU part (no GPU): the cut itself (crp_plan_shares) against the Python statement of the same rule that the
+process-per-GPU path uses (parallel.split_evenly), and the properties crp_node_gather relies on.
+GPU part: on the one-GPU box the N devices are the same physical GPU listed N times ({0, 0, 0, 0}); RCCL refuses
+duplicate devices, so the exchange runs as the library's device-to-device copies there -- the same stand-in role the
+host transport plays for the process-per-GPU path -- and RCCL itself is exercised with a one-device node
+(ncclCommInitAll with world 1).
+"""
+import hashlib
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint8)
+
+
+# ------------------------------------------------------------------ the cut (host code)
+def _random_lengths(rng):
+    kind = int(rng.integers(0, 4))
+    n = int(rng.integers(0, 40))
+    if kind == 0:
+        return [int(v) for v in rng.integers(0, 50_000, n)]
+    if kind == 1:  # a few chromosomes and many scaffolds
+        return [int(v) for v in rng.integers(1_000_000, 9_000_000, max(1, n // 6))] + [int(v) for v in rng.integers(1, 30_000, n)]
+    if kind == 2:  # one contig
+        return [int(rng.integers(0, 5_000_000))]
+    return [int(v) for v in np.exp(rng.uniform(0, 16, n)).astype(np.int64)]
+
+
+def test_plan_shares_equals_split_evenly():
+    """crp_plan_shares (C++, what crp_node_load cuts by) == parallel.split_evenly (what sharded_scan cuts by)."""
+    from cropsr_amd import node, parallel
+    rng = np.random.default_rng(5)
+    n_cut = 0
+    for trial in range(400):
+        lengths = _random_lengths(rng)
+        world = int(rng.integers(1, 10))
+        min_piece = int(rng.choice([0, 1, 64, 4096, 100_000]))
+        got = node.plan_shares(lengths, world, min_piece)
+        pieces, owner = parallel.split_evenly(lengths, world, min_piece if min_piece else 4096)
+        assert got == [(k, s, e, o) for (k, s, e), o in zip(pieces, owner)], (trial, lengths, world, min_piece)
+        n_cut += len(got) - len(lengths)
+    assert n_cut > 300  # (the trials did cut contigs)
+
+
+def test_plan_shares_properties():
+    """What crp_node_gather relies on: the pieces cover every contig exactly once in order; owners never decrease; only
+    the FIRST piece of a device can start inside a contig and only its LAST can end inside one (so the owned rows of a
+    device's tables are one run); at most world - 1 cuts; shares equal to within min_piece."""
+    from cropsr_amd import node
+    rng = np.random.default_rng(6)
+    for trial in range(300):
+        lengths = _random_lengths(rng)
+        world = int(rng.integers(1, 10))
+        plan = node.plan_shares(lengths, world)
+        assert [p[0] for p in plan] == sorted(p[0] for p in plan)
+        assert [p[3] for p in plan] == sorted(p[3] for p in plan) and all(0 <= p[3] < world for p in plan)
+        for k, n in enumerate(lengths):
+            mine = [p for p in plan if p[0] == k]
+            assert mine and mine[0][1] == 0 and mine[-1][2] == n
+            assert all(a[2] == b[1] for a, b in zip(mine, mine[1:]))
+        assert len(plan) <= len(lengths) + world - 1
+        for r in range(world):
+            own = [p for p in plan if p[3] == r]
+            for j, (k, s, e, _) in enumerate(own):
+                assert s == 0 or j == 0, (trial, r, own)
+                assert e == lengths[k] or j == len(own) - 1, (trial, r, own)
+        total = sum(lengths)
+        if total >= world * 3 * 4096 and max(lengths) >= 4096 * 4 and len(lengths) < 4:
+            shares = [sum(e - s for _, s, e, o in plan if o == r) for r in range(world)]
+            assert max(shares) - min(shares) <= 2 * 4096 + world, (trial, shares)
+
+
+def test_plan_shares_capacity_protocol_and_bad_arguments():
+    import ctypes
+    from cropsr_amd import _native as nat
+    L = nat.lib()
+    lens = np.array([100_000, 50_000], dtype=np.uint64)
+    n = ctypes.c_uint64()
+    assert L.crp_plan_shares(lens.ctypes.data_as(nat.u64p), 2, 4, 0, None, 0, ctypes.byref(n)) == nat.CRP_ERR_CAPACITY
+    assert n.value == 5
+    out = np.zeros((5, 4), dtype=np.uint64)
+    assert L.crp_plan_shares(lens.ctypes.data_as(nat.u64p), 2, 4, 0, out.ctypes.data_as(nat.u64p), 5, ctypes.byref(n)) == 0
+    assert L.crp_plan_shares(lens.ctypes.data_as(nat.u64p), 2, 0, 0, out.ctypes.data_as(nat.u64p), 5, ctypes.byref(n)) == -1
+    assert L.crp_plan_shares(None, 2, 2, 0, out.ctypes.data_as(nat.u64p), 5, ctypes.byref(n)) == -1
+    assert L.crp_node_size(None) == -1 and not L.crp_node_ctx(None, 0) and L.crp_node_destroy(None) == 0
+    assert L.crp_node_gather(None, 0, 0) == -1 and L.crp_node_last_error(None) == b""
+
+
+def test_pos16_host_transport_round_trip():
+    """The 16-bit position packing of the exchange as the host transport (sockets) does it in numpy: exact for any
+    ascending table, including empty buckets, runs longer than 65 536 positions without a hit, and the table's ends."""
+    from cropsr_amd import parallel
+    rng = np.random.default_rng(9)
+    cases = [np.empty(0, np.uint32), np.array([0], np.uint32), np.array([65535, 65536, 65537, 1 << 20, (1 << 31) - 1], np.uint32)]
+    for _ in range(30):
+        n = int(rng.integers(1, 20000))
+        span = int(rng.choice([1000, 70_000, 10_000_000, (1 << 31) - 1]))
+        cases.append(np.unique(rng.integers(0, span, n)).astype(np.uint32))
+    for pos in cases:
+        lo16, bstart = parallel.pack_pos16(pos)
+        assert lo16.dtype == np.uint16 and bstart.dtype == np.uint32 and lo16.size == pos.size
+        back = parallel.unpack_pos16(lo16, bstart)
+        assert back.dtype == np.uint32 and (back == pos).all()
+
+
+# ------------------------------------------------------------------ GPU
+ALPHA = np.frombuffer(b"ACGTACGTACGTGGCCacgtN", dtype=np.uint8)
+
+
+def _genome(rng, lengths):
+    out = []
+    for k, n in enumerate(lengths):
+        tail = b"')]" if k == len(lengths) - 1 else b"'),"
+        out.append(b"'" + rng.choice(ALPHA, int(n)).tobytes() + tail)
+    return out
+
+
+def _check_against_oracle(hits, contigs, oracle, l, ctx, pre=False):
+    total = 0
+    for k, c in enumerate(contigs):
+        want = oracle.scan_score(c, l)
+        got = hits.contig(k)
+        for strand in ("plus", "minus"):
+            assert got["pos_" + strand].shape == want["pos_" + strand].shape, (ctx, k, strand)
+            assert (got["pos_" + strand] == want["pos_" + strand]).all(), (ctx, k, strand)
+            col = "pre_" if pre else "score_"
+            assert (bits(got["score_" + strand]) == bits(want[col + strand])).all(), (ctx, k, strand, col)
+            total += want["pos_" + strand].size
+    assert hits.n_plus + hits.n_minus == total, ctx
+    return total
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [1, 2, 3, 4, 7])
+def test_node_logical_devices_vs_oracle(oracle, world):
+    """Small genomes (contigs shorter than, around and far longer than a share; empty contigs; many scaffolds between
+    chromosomes) over `world` logical devices on GPU 0, every option of the exchange: positions packed to 16 bits or
+    raw, the pre-sigmoid column, another root -- each contig's rows == the oracle's, bit for bit."""
+    from cropsr_amd import node as nd
+    rng = np.random.default_rng(100 + world)
+    genomes = [
+        [300_000, 5, 0, 70_000, 9_000, 123_457, 64, 1, 40_000],
+        [1_500_000],
+        [2_000, 3_000] + [int(v) for v in rng.integers(1, 6_000, 60)] + [400_000],
+        [10, 20, 30],
+        [],
+    ]
+    with nd.Node([0] * world) as node:
+        assert node.size == world
+        for g, lengths in enumerate(genomes):
+            contigs = _genome(rng, lengths)
+            node.load(contigs)
+            plan = node.plan()
+            assert [(p["contig"], p["start"], p["end"], p["device"]) for p in plan] == nd.plan_shares([len(c) for c in contigs], world)
+            for l, kw in ((20, {}), (20, {"pos16": False}), (20, {"pre": True}), (20, {"root": world - 1}), (23, {}), (7, {"pos16": False, "root": world // 2})):
+                hits = node.scan(l, **kw)
+                _check_against_oracle(hits, contigs, oracle, l, (world, g, l, kw), pre=kw.get("pre", False))
+                st = node.gather_stats()
+                assert st["transport"] == ("device-to-device copies" if world > 1 else "none (one device)")
+            # what crossed to the root: 10 B per hit packed (+ the bucket starts), 12 B raw
+            node.scan_score_device(20)
+            raw = node.gather(0, pos16=False)["bytes_to_root"]
+            packed = node.gather(0, pos16=True)["bytes_to_root"]
+            if raw > 100_000:
+                assert packed < raw * 0.87, (raw, packed)
+
+
+@pytest.mark.gpu
+def test_node_equals_single_engine_tables(oracle):
+    """The same genome through Engine.arena (one GPU, the N = 1 path) and through a 4-device node: per contig the very
+    same bytes; and scanning twice / gathering twice changes nothing."""
+    from cropsr_amd import Engine, node as nd
+    rng = np.random.default_rng(77)
+    contigs = _genome(rng, [900_000, 40_000, 350_000, 7, 650_000, 12_000])
+    with Engine(0) as eng:
+        arena = eng.arena(contigs)
+        one = arena.scan_score(20, want_pre=False)
+        want = [one.contig(k) for k in range(len(contigs))]
+        arena.close()
+    with nd.Node([0, 0, 0, 0]) as node:
+        node.load(contigs)
+        digests = set()
+        for rep in range(3):
+            hits = node.scan(20, pos16=rep != 1)
+            d = hashlib.sha256()
+            for k in range(len(contigs)):
+                got = hits.contig(k)
+                for key in ("pos_plus", "score_plus", "pos_minus", "score_minus"):
+                    assert (bits(got[key]) == bits(want[k][key])).all(), (rep, k, key)
+                    d.update(bits(got[key]).tobytes())
+            digests.add(d.hexdigest())
+        assert len(digests) == 1
+        # a gather without a fresh scan is a state the library accepts (the tables are still there); one before any scan is not
+        node.load(contigs)
+        with pytest.raises(Exception) as e:
+            node.gather(0)
+        assert "scan first" in str(e.value)
+        with pytest.raises(Exception):
+            node.fetch()
+
+
+@pytest.mark.gpu
+@pytest.mark.slow
+def test_node_tair10_like_four_logical_devices(oracle):
+    """VERDICT r04 #1's acceptance test: the TAIR10-like genome (BASELINE.json configs[2] stand-in, 119.7 Mb, 7 contigs:
+    every chromosome straddles a share boundary or fills most of a share) over the node handle on {0, 0, 0, 0} ==
+    the N = 1 tables of the same genome == the oracle, every one of the 7.7 M hits, by SHA-256 per contig."""
+    from concurrent.futures import ThreadPoolExecutor
+    import bench_workload as bw
+    from cropsr_amd import Engine, node as nd
+
+    def digest(h):
+        d = hashlib.sha256()
+        for key in ("pos_plus", "score_plus", "pos_minus", "score_minus"):
+            d.update(np.ascontiguousarray(h[key]).tobytes())
+        return d.hexdigest()
+
+    wl = bw.tair10_like()
+    strings = [wl.contig_string(k) for k in range(len(wl.specs))]
+    threads = max(2, min(16, len(os.sched_getaffinity(0))))
+    with ThreadPoolExecutor(threads) as pool:
+        want = [pool.submit(lambda t=s: digest(oracle.scan_score(t, 20))) for s in strings]
+        with Engine(0) as eng:
+            arena = eng.arena(strings)
+            one = arena.scan_score(20, want_pre=False)
+            n1 = [digest(one.contig(k)) for k in range(len(strings))]
+            n1_hits = one.n_plus + one.n_minus
+            arena.close()
+        with nd.Node([0, 0, 0, 0]) as node:
+            node.load(strings)
+            plan = node.plan()
+            assert len(plan) == len(strings) + 3  # three cuts
+            hits = node.scan(20)
+            got = [digest(hits.contig(k)) for k in range(len(strings))]
+            stats = node.gather_stats()
+            per_dev = [node.arena_stats(k) for k in range(4)]
+        want = [f.result() for f in want]
+    assert got == n1, [k for k in range(len(strings)) if got[k] != n1[k]]
+    assert got == want, [k for k in range(len(strings)) if got[k] != want[k]]
+    assert hits.n_plus + hits.n_minus == n1_hits > 7_000_000
+    chars = [d["n_chars"] for d in per_dev]
+    assert max(chars) - min(chars) < 10_000  # equal shares
+    print("node tair10-like on 4 logical devices: %d hits, %d B to the root (%.2f B per peer hit), exchange %.2f ms, %s"
+          % (n1_hits, stats["bytes_to_root"], stats["bytes_to_root"] / (n1_hits * 0.75), stats["ms_exchange"], stats["transport"]))
+
+
+def _node_rccl_world1(out_path):
+    """A one-device node with CRP_NODE_TRANSPORT=rccl: ncclCommInitAll (world 1) and an empty send/recv group on the real
+    RCCL, in a process of its own (RCCL's teardown belongs to that process)."""
+    os.environ["CRP_NODE_TRANSPORT"] = "rccl"
+    import json
+    from cropsr_amd import node as nd
+    from oracle import oracle as orc
+    rng = np.random.default_rng(3)
+    contigs = _genome(rng, [200_000, 3_000])
+    with nd.Node([0]) as node:
+        node.load(contigs)
+        hits = node.scan(20)
+        st = node.gather_stats()
+        n = _check_against_oracle(hits, contigs, orc, 20, "rccl world 1")
+    with open(out_path, "w") as f:
+        json.dump({"hits": n, "transport": st["transport"], "bytes_to_root": st["bytes_to_root"]}, f)
+
+
+@pytest.mark.gpu
+def test_node_on_rccl_with_one_device(tmp_path):
+    import json
+    out = tmp_path / "node_rccl.json"
+    code = "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_node; test_node._node_rccl_world1(%r)" % (
+        ROOT, os.path.join(ROOT, "tests"), str(out))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    d = json.loads(out.read_text())
+    assert d["hits"] > 10_000 and d["transport"].startswith("RCCL") and d["bytes_to_root"] == 0
