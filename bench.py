@@ -59,7 +59,19 @@ def parse_args():
     ap.add_argument("--preheat-ms", type=float, default=60.0,
                     help="untimed steps go on after the W warm-up steps until this much time has passed since the first "
                          "of them (GPU clocks back at steady state); 0 = exactly W")
-    ap.add_argument("--workload", default="switchgrass", choices=["switchgrass", "tair10", "ecoli"])
+    ap.add_argument("--workload", default="switchgrass", choices=["switchgrass", "tair10", "ecoli", "sorghum"])
+    ap.add_argument("--fasta", default=None, metavar="PATH",
+                    help="a REAL genome instead of the synthetic stand-in (SURVEY.md 8d: \"real FASTA may be substituted on the GPU box "
+                         "if present\"): read through cropsr_amd.fasta exactly as the CLI reads it, same arena builder; the line then "
+                         "says data: real and names the file.  At N > 1 every rank's genome is this file")
+    ap.add_argument("--gff", default=None, metavar="PATH",
+                    help="with --fasta: the GFF3 the annotate block joins (default: the block is skipped for a real genome)")
+    ap.add_argument("--phytozome", default=None, metavar="PATH", help="with --gff: the Phytozome annotation_info file")
+    ap.add_argument("--single-process", action="store_true",
+                    help="--gpus N through the library's node handle (crp_node_*): ONE process, no launcher, no sockets -- the cut, "
+                         "the fan-out over the N devices and the gatherv happen inside libcropsr_hip.so")
+    ap.add_argument("--devices", default=None, metavar="LIST",
+                    help="--single-process: the HIP devices to use, e.g. 0,1,2,3 (default 0..N-1; with --share-gpu0: device 0, N times)")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the switchgrass-like genome (debug)")
     ap.add_argument("--geometry", default="auto", choices=["auto", "large", "small"],
                     help="tile shape of the scan (CRP_OPT_TILE_GEOMETRY); auto = by the arena's size: large for the >= 1 Gb genome")
@@ -98,13 +110,64 @@ def parse_args():
     return ap.parse_args()
 
 
-def make_workload(name, genome, scale):
+class FastaWorkload:
+    """A real genome as a workload (--fasta): the contig table the reference builds from the file (cropsr_amd.fasta, the
+    CLI's own loader: CROPSR.py:54-74 with cropsr_functions.py:190-229), contig strings as they are scanned."""
+
+    class Spec:
+        def __init__(self, name, length):
+            self.name, self.length = name, length
+
+    def __init__(self, path):
+        import numpy as np
+        from cropsr_amd import annotate, fasta
+        table = fasta.load_bytes(path)
+        self.path = path
+        self._strings = [np.frombuffer(v, dtype=np.uint8) for _, v in table]
+        self.keys = [k for k, _ in table]
+        self.dec = 0 if (self.keys and self.keys[0].startswith(">")) else 1  # re-formatted path: one decoration character in front
+        self.decoration = 4 * self.dec
+        self.specs = [self.Spec(annotate.contig_name(k), max(0, int(v.size) - self.decoration)) for k, v in zip(self.keys, self._strings)]
+        self.name = "%s (%d contigs, %d bases)" % (os.path.basename(path), len(self.specs), sum(s.length for s in self.specs))
+
+    def contig_string(self, k):
+        return self._strings[k]
+
+    def string_length(self, k):
+        return int(self._strings[k].size)
+
+
+_FASTA_CACHE = {}
+
+
+def make_workload(args, genome):
+    """Genome number `genome` of the run's workload: the seeded stand-in (bench_workload.py), or --fasta's file."""
     import bench_workload as bw
-    if name == "switchgrass":
-        return bw.switchgrass_like(genome, scale)
-    if name == "tair10":
-        return bw.tair10_like()
-    return bw.ecoli_like()
+    if args.fasta:
+        if args.fasta not in _FASTA_CACHE:
+            _FASTA_CACHE[args.fasta] = FastaWorkload(args.fasta)
+        return _FASTA_CACHE[args.fasta]
+    if args.workload == "switchgrass":
+        wl = bw.switchgrass_like(genome, args.scale)
+    elif args.workload == "tair10":
+        wl = bw.tair10_like()
+    elif args.workload == "sorghum":
+        wl = bw.sorghum_like()
+    else:
+        wl = bw.ecoli_like()
+    wl.string_length = lambda k, wl=wl: wl.specs[k].length + 4  # + decoration (SURVEY.md A.1)
+    wl.decoration = 4
+    return wl
+
+
+def algorithmic_bytes(n_chars, hits, composition, n_contigs):
+    """B_in = ceil(N / 4) for the 2-bit codes + 2 * ceil(N / 8) for the upper-case and acgt bit-planes --
+    the planes "omit[ted] for inputs that are entirely uppercase ACGT, i.e. cfg 2" -- and B_out = 12 * H.  "Entirely
+    upper-case ACGT" is measured, not assumed: crp_arena_composition counts the characters of the resident arena, and the
+    only others allowed are the <= 4 decoration characters cropsr_functions.py:221-229 leaves around every contig.
+    Returns (bytes, planes_counted)."""
+    planes = composition is None or composition["n_other"] > 4 * n_contigs
+    return (n_chars + 3) // 4 + (2 * ((n_chars + 7) // 8) if planes else 0) + 12 * hits, planes
 
 
 def _cpu_leg(fp, sample_string, n_bases, threads, seconds):
@@ -201,8 +264,8 @@ def strong_scaling_block(args, eng, group, use_rccl, fence, reduce):
     rank, world = group.rank, group.world
     steps = args.strong_steps or args.steps
     check = not args.no_strong_check
-    wl = make_workload(args.workload, 0, args.scale)
-    lengths = [s.length + 4 for s in wl.specs]
+    wl = make_workload(args, 0)
+    lengths = [wl.string_length(k) for k in range(len(wl.specs))]
     plan = parallel.strong_plan(lengths, world)
     pieces, mine = plan["pieces"], plan["by_rank"][rank]
     wanted = {}
@@ -272,12 +335,14 @@ def strong_scaling_block(args, eng, group, use_rccl, fence, reduce):
     gathered = gatherv(n_plus, n_minus)
     fence()
     dt_gather = reduce([time.perf_counter() - tg], "max")[0]
+    bytes_to_root = (eng.gather_bytes() if use_rccl else int(getattr(group, "bytes_gathered", 0))) if rank == 0 else 0
     gathered = fetch_gathered(gathered)
     hits_all, scored_all = reduce([n_plus + n_minus, scored], "sum")
     out = {"workload": wl.name, "scaling": "strong", "genomes": 1, "steps": steps, "pieces": len(pieces),
            "contigs_cut": int(sum(1 for k in range(len(lengths)) if sum(1 for p in pieces if p[0] == k) > 1)),
            "halo": parallel.HALO, "ms_scan_max_rank": dt_scan * 1e3, "ms_gatherv": dt_gather * 1e3,
            "gatherv_transport": "RCCL (in-library)" if use_rccl else "host-socket",
+           "bytes_to_root": bytes_to_root, "positions": "16 bits per hit + one word per 65 536 arena positions (CRP_GATHER_POS16)",
            "value": None, "unit": "gRNAs/s", "per_rank": per_rank, "setup_s": t_gen}
     # an owned hit is a hit of the whole contig; halo hits are counted by their owner only -- the unit is taken from the
     # stitched tables when the check runs, else from the sum over ranks minus nothing (halo hits are < 0.001 % of it)
@@ -345,8 +410,289 @@ def load_offtarget_traffic(build_id, workload):
     return tj
 
 
+def main_single_process(args):
+    """--gpus N --single-process: the same measurement through the library's node handle (crp_node_*) -- ONE
+    process, no launcher, no sockets, no bootstrap.  Weak headline: N genomes (seeds 0..N-1) as ONE contig list, cut by the
+    library into N contiguous equal shares; a step = crp_node_scan_score (the scan queued on every device, then
+    collected).  The path's one exchange, crp_node_gather, runs after the timed steps and is reported on its own, with and
+    without the 16-bit position packing, on RCCL and as device-to-device copies.  `strong`: ONE genome over the N devices,
+    stitched tables compared contig by contig (SHA-256) with an N = 1 scan of the same genome on device 0."""
+    import threading
+    from concurrent.futures import ThreadPoolExecutor
+    import numpy as np
+    from cropsr_amd import Engine, node as nd
+    from cropsr_amd import _native as nat
+    world = args.gpus
+    if args.devices:
+        devices = [int(d) for d in args.devices.split(",")]
+        if len(devices) != world:
+            raise SystemExit("--devices lists %d devices, --gpus says %d" % (len(devices), world))
+    else:
+        devices = [0] * world if args.share_gpu0 else list(range(world))
+    node = nd.Node(devices)  # raises without libcropsr_hip.so / GPUs: no fallback
+    node.configure(two_pass=True if args.two_pass else None, geometry=None if args.geometry == "auto" else args.geometry)
+    build_id = nat.lib().crp_build_id().decode()
+    info = node.device_info(0)
+    is_real = bool(args.fasta)
+
+    def strings_of(wl):
+        return [wl.contig_string(k) for k in range(len(wl.specs))]
+
+    # ---- weak workload: `world` genomes, generated side by side (numpy releases the GIL), ONE contig list
+    t_gen = time.perf_counter()
+    genomes = [make_workload(args, g) for g in range(world)]
+    if is_real:
+        per_genome = [strings_of(genomes[0])] * world
+    else:
+        with ThreadPoolExecutor(max(1, min(world, (os.cpu_count() or 2) // 2))) as pool:
+            per_genome = list(pool.map(strings_of, genomes))
+    strings = [s for g in per_genome for s in g]
+    bases_all = sum(spec.length for wl in genomes for spec in wl.specs)
+    t_gen = time.perf_counter() - t_gen
+    sample = bytes(strings[0][:args.cpu_sample_bases + 1]).decode("ascii", "replace") if strings else ""
+    t_upload = time.perf_counter()
+    node.load(strings)  # cut + one host thread per device: H2D + pack
+    t_upload = time.perf_counter() - t_upload
+    n_strings = len(strings)
+    del strings, per_genome
+
+    watch = {"timer": None, "fired": False, "lock": threading.Lock()}
+    partial = {}
+
+    def guard(stage, line_fn):
+        """RCCL has no time-out: if the stage does not come back within --collective-timeout seconds, print the line with what
+        has been measured so far and leave non-zero."""
+        if world == 1 or args.collective_timeout <= 0:
+            return
+
+        def fire():
+            with watch["lock"]:
+                if watch["timer"] is None:
+                    return
+                watch["fired"] = True
+            try:
+                print(json.dumps(line_fn("%s did not return within %.0f s" % (stage, args.collective_timeout))), flush=True)
+            finally:
+                os._exit(1)
+        watch["timer"] = threading.Timer(args.collective_timeout, fire)
+        watch["timer"].daemon = True
+        watch["timer"].start()
+
+    def unguard():
+        with watch["lock"]:
+            if watch["timer"] is not None:
+                watch["timer"].cancel()
+                watch["timer"] = None
+        if watch["fired"]:
+            threading.Event().wait()
+
+    # ---- the timed steps: no exchange inside
+    node.scan_score_device(20)  # first scan: sizes the tables
+    dev_counts = [node.device_counts(k) for k in range(world)]
+    stats = [node.arena_stats(k) for k in range(world)]
+    comp0 = node.arena_composition(0)
+    t_pre = time.perf_counter()
+    n_warm = max(1, args.warmup)
+    for _ in range(n_warm):
+        node.scan_score_device(20)
+    spent = time.perf_counter() - t_pre
+    extra = int(max(0.0, args.preheat_ms * 1e-3 - spent) / max(spent / n_warm, 1e-6) + 0.999)
+    for _ in range(extra):
+        node.scan_score_device(20)
+    n_warm += extra
+    node.profile(1)
+    for k in range(world):
+        node.profile_read(k, reset=True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        node.scan_score_device(20)  # returns when every device's stream has drained
+    dt = time.perf_counter() - t0
+    prof = [node.profile_read(k, reset=True)["emit_score"] for k in range(world)]
+    node.profile(0)
+    kernel_ms = [p["ms"] / max(1, p["launches"]) for p in prof]
+    # units until the gather has counted them exactly: rows with a real score in every device's own tables (a hit inside a
+    # halo is in two of them: < 0.001 %)
+    scored_all = sum(c["n_scored"] for c in dev_counts if c)
+    hits_all = sum(c["n_plus"] + c["n_minus"] for c in dev_counts if c)
+
+    def build_line(gather_info=None, strong=None, error=None):
+        c0, s0 = dev_counts[0], stats[0]
+        hits0 = (c0["n_plus"] + c0["n_minus"]) if c0 else 0
+        n_chars0 = s0["n_chars"] if s0 else 0
+        algo_bytes, planes_counted = algorithmic_bytes(n_chars0, hits0, comp0, s0["n_texts"] if s0 else 0)
+        achieved = algo_bytes / (kernel_ms[0] * 1e-3) / 1e9 if kernel_ms[0] else None
+        facts, facts_src = load_profile_facts(build_id, genomes[0].name)
+        line = {
+            "metric": "gRNAs scored/sec", "value": partial.get("scored_all", scored_all) * args.steps / dt, "unit": "gRNAs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "untimed_steps_before": n_warm,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "real" if is_real else "synthetic",
+            "config": {"workload": genomes[0].name, "genomes": world, "contigs_per_genome": len(genomes[0].specs),
+                       "bases_total": int(bases_all), "kept_hits_total": int(partial.get("hits_all", hits_all)), "guide_len": 20,
+                       "tile_geometry": s0["geometry"] if s0 else None, "tiles_per_launch": s0["n_tiles"] if s0 else 0,
+                       "launches_per_step": 3 if args.two_pass else 1,
+                       "parallelism": "ONE process, node handle (crp_node_*): %d contig strings cut by the library into %d contiguous "
+                                      "equal shares (halo %d) over devices %s; gatherv to device %d once, after the steps"
+                                      % (n_strings, world, nat.HALO, devices, devices[0]),
+                       "device": info["name"].strip(), "library_build": build_id},
+            "bases_per_s": bases_all * args.steps / dt,
+            "per_rank": [{"rank": k, "device": devices[k], "kernel_ms": kernel_ms[k],
+                          "characters_with_halos": stats[k]["n_chars"] if stats[k] else 0,
+                          "tiles": stats[k]["n_tiles"] if stats[k] else 0,
+                          "kept_hits_incl_halos": (dev_counts[k]["n_plus"] + dev_counts[k]["n_minus"]) if dev_counts[k] else 0}
+                         for k in range(world)],
+            "roofline": {"bound": "hbm", "kernel": "emit_kernel, single launch (masks + chained tile offsets + compact + score), device 0's",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS if achieved else None,
+                         "traffic": facts.get("hbm_bytes_per_launch") if (facts and world == 1) else None,
+                         "traffic_source": facts_src if world == 1 else "profiles/traffic.json is an N = 1 measurement",
+                         "algorithmic_bytes_per_launch": int(algo_bytes),
+                         "algorithmic_bytes": "ceil(N/4) + 2*ceil(N/8) + 12*H" if planes_counted else "ceil(N/4) + 12*H",
+                         "kernel_ms": kernel_ms[0]},
+            "setup_s": {"generate": t_gen, "cut_upload_pack_all_devices": t_upload},
+        }
+        if gather_info is not None:
+            line["gatherv_ok"] = "s" in gather_info
+            if "s" in gather_info:
+                line["value_with_final_gatherv"] = partial.get("scored_all", scored_all) / (dt / args.steps + gather_info["s"])
+                line["ms_scan_plus_gatherv"] = (dt / args.steps + gather_info["s"]) * 1e3
+            line["gatherv"] = gather_info
+        if strong is not None:
+            line["strong"] = strong
+        if error:
+            line["error"] = error
+        return line
+
+    def time_gather(**kw):
+        node.gather(0, **kw)  # warm-up: buffers sized, RCCL's point-to-point channels set up
+        reps = []
+        for _ in range(3):
+            st = node.gather(0, **kw)
+            reps.append(st)
+        best = min(reps, key=lambda r: r["ms_total"])
+        return {"ms": best["ms_total"], "ms_exchange": best["ms_exchange"], "bytes_to_root": best["bytes_to_root"],
+                "transport": best["transport"], "ms_all": [round(r["ms_total"], 4) for r in reps], "note": best["note"]}
+
+    # ---- the path's one exchange
+    gather_info = None
+    if world > 1 and not args.no_gather:
+        guard("crp_node_gather", lambda why: build_line({"error": why}))
+        try:
+            packed = time_gather(pos16=True)
+            raw = time_gather(pos16=False)
+            gather_info = {"s": packed["ms"] * 1e-3, "transport": packed["transport"], "bytes_to_root": packed["bytes_to_root"],
+                           "GB_per_s_into_root": packed["bytes_to_root"] / (packed["ms_exchange"] * 1e-3) / 1e9 if packed["ms_exchange"] else None,
+                           "positions": "16 bits per hit + one word per 65 536 arena positions (CRP_GATHER_POS16)",
+                           "pos16": packed, "raw_u32_positions": raw}
+            if packed["transport"].startswith("RCCL"):
+                gather_info["device_to_device_copies"] = time_gather(pos16=True, peer_copy=True)
+            node.gather(0)
+            _, gp, gm = node.counts()
+            partial["hits_all"] = gp + gm
+            partial["scored_all"] = node.count_scored()
+        except Exception as e:
+            gather_info = {"error": repr(e)[:300]}
+        unguard()
+    elif world == 1:
+        node.gather(0)
+        _, gp, gm = node.counts()
+        partial["hits_all"], partial["scored_all"] = gp + gm, node.count_scored()
+
+    # ---- strong scaling: ONE genome over the N devices, checked against device 0 alone
+    strong = None
+    if world > 1 and not args.no_strong and not (gather_info and "error" in gather_info):
+        guard("strong-scaling block", lambda why: build_line(gather_info, {"error": why}))
+        try:
+            steps = args.strong_steps or args.steps
+            wl = genomes[0]
+            one = strings_of(wl)
+            t_up = time.perf_counter()
+            node.load(one)
+            t_up = time.perf_counter() - t_up
+            node.scan_score_device(20)
+            for _ in range(n_warm):
+                node.scan_score_device(20)
+            node.profile(1)
+            for k in range(world):
+                node.profile_read(k, reset=True)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                node.scan_score_device(20)
+            dt_scan = (time.perf_counter() - t0) / steps
+            sprof = [node.profile_read(k, reset=True)["emit_score"] for k in range(world)]
+            node.profile(0)
+            g = time_gather(pos16=True)
+            g_raw = time_gather(pos16=False)
+            node.gather(0)
+            dt_gather = g["ms"] * 1e-3
+            n_scored = node.count_scored()
+            hits = node.fetch()
+            plan = node.plan()
+            strong = {"workload": wl.name, "scaling": "strong", "genomes": 1, "steps": steps, "pieces": len(plan),
+                      "contigs_cut": len(plan) - len(one), "halo": nat.HALO,
+                      "ms_scan_max_rank": dt_scan * 1e3, "ms_gatherv": g["ms"], "gatherv_transport": g["transport"],
+                      "bytes_to_root": g["bytes_to_root"], "gatherv": g, "gatherv_raw_u32_positions": g_raw,
+                      "kept_hits": hits.n_plus + hits.n_minus, "gRNAs_scored": int(n_scored), "unit": "gRNAs/s",
+                      "value_scan_only": n_scored / dt_scan, "value": n_scored / (dt_scan + dt_gather),
+                      "per_rank": [{"rank": k, "kernel_ms": sprof[k]["ms"] / max(1, sprof[k]["launches"]),
+                                    "characters_with_halos": (node.arena_stats(k) or {}).get("n_chars", 0),
+                                    "tiles": (node.arena_stats(k) or {}).get("n_tiles", 0)} for k in range(world)],
+                      "setup_s": t_up}
+            if not args.no_strong_check:
+                from cropsr_amd.engine import Hits
+                got = table_digests([hits.contig(k) for k in range(len(one))])
+                with Engine(devices[0]) as eng:
+                    builder = eng.arena_builder([s.size for s in one])
+                    for s_ in one:
+                        builder.add(s_)
+                    ref = builder.seal()
+                    rp, rm = ref.scan_score_device(20)
+                    for _ in range(n_warm):
+                        ref.scan_score_device(20)
+                    eng.profile(1)
+                    eng.profile_read(reset=True)
+                    t0 = time.perf_counter()
+                    for _ in range(steps):
+                        ref.scan_score_device(20)
+                    t1 = (time.perf_counter() - t0) / steps
+                    e1 = eng.profile_read(reset=True)["emit_score"]
+                    whole = Hits(ref.offsets, ref.lengths, 20, ref.fetch(rp, rm))
+                    want = table_digests([whole.contig(k) for k in range(len(one))])
+                    ref.close()
+                bad = [k for k in range(len(one)) if want[k] != got[k]]
+                strong["n1"] = {"ms_scan": t1 * 1e3, "kernel_ms": e1["ms"] / max(1, e1["launches"]), "kept_hits": int(rp + rm)}
+                strong["digest_ok"] = not bad
+                if bad:
+                    strong["digest_mismatch_contigs"] = bad[:10]
+                strong["speedup_vs_n1"] = t1 / (dt_scan + dt_gather)
+                strong["efficiency_vs_n1"] = t1 / (dt_scan + dt_gather) / world
+                strong["efficiency_vs_n1_scan_only"] = t1 / dt_scan / world
+            del one, hits
+        except Exception as e:
+            import traceback
+            traceback.print_exc()
+            strong = {"error": repr(e)[:300]}
+        unguard()
+
+    line = build_line(gather_info, strong)
+    if world == 1 and args.cpu_sample_bases > 0:
+        from oracle import oracle as _o
+        _o.lib()
+        line["cpu_baseline"] = cpu_baseline(sample, args.cpu_sample_bases)
+        line["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
+    print(json.dumps(line), flush=True)
+    failed = (bool(gather_info and "error" in gather_info) or
+              bool(strong and ("error" in strong or strong.get("digest_ok") is False)))
+    if failed:
+        sys.stdout.flush()
+        os._exit(1)
+    node.close()
+
+
 def main():
     args = parse_args()
+    if args.single_process:
+        return main_single_process(args)
     from cropsr_amd import launch
     if launch.wanted(args.gpus):
         # `python bench.py --gpus N` with no launcher in the environment: this process -- which has not
@@ -392,9 +738,9 @@ def main():
                              "for fences and the final gatherv: %s\n" % (rank, rccl_error))
 
     # ---- workload: `world` genomes, contigs dealt to ranks by LPT (weak scaling)
-    genomes = [make_workload(args.workload, g, args.scale) for g in range(world)]
+    genomes = [make_workload(args, g) for g in range(world)]
     all_specs = [(g, k) for g in range(world) for k in range(len(genomes[g].specs))]
-    lengths = [genomes[g].specs[k].length + 4 for g, k in all_specs]  # + decoration
+    lengths = [genomes[g].string_length(k) for g, k in all_specs]  # + decoration
     owner = parallel.partition_contigs(lengths, world)
     mine = [i for i, o in enumerate(owner) if o == rank]
     t_gen = time.perf_counter()
@@ -406,7 +752,7 @@ def main():
         g, k = all_specs[i]
         s = genomes[g].contig_string(k)
         if sample is None and rank == 0:
-            sample = s[:args.cpu_sample_bases + 1].tobytes().decode()  # keeps the leading quote
+            sample = bytes(s[:args.cpu_sample_bases + 1]).decode("ascii", "replace")  # keeps the leading quote
         t_up = time.perf_counter()
         builder.add(s)  # characters over PCIe + the ballot pack kernel, synchronous
         t_upload += time.perf_counter() - t_up
@@ -469,16 +815,19 @@ def main():
     # the box's practical HBM ceiling, measured live: the count kernel of the three-launch mode is a pure
     # streaming read of the four planes (0.5 B per character, nothing written but 8 B per tile)
     stream_GBs = None
+    three_launch_side = None  # the count / tile-scan / emit kernels of the three-launch mode, measured apart from the timed steps
     if not args.two_pass:
         eng.configure(two_pass=True)
         for _ in range(5):
             arena.scan_score_device(20, want_pre=False)
         three = eng.profile_read(reset=True)
-        eng.configure(two_pass=False)
-        side["count"], side["tile_scan"] = three["count"], three["tile_scan"]  # (reported as count_kernel_ms / tile_scan_ms)
+        eng.configure(two_pass=False)  # (back to what the run was started with: this branch is the not --two-pass one)
+        three_launch_side = {k: three[k]["ms"] / max(1, three[k]["launches"]) for k in ("count", "tile_scan", "emit_score")}
         cnt = three["count"]
         if cnt["launches"]:
             stream_GBs = (arena.stats()["n_chars"] / 2.0) / (cnt["ms"] / cnt["launches"] * 1e-3) / 1e9
+    else:
+        three_launch_side = {k: side[k]["ms"] / max(1, side[k]["launches"]) for k in ("count", "tile_scan", "emit_score")}
     eng.profile(0)
     # The W warm-up steps run HERE, right before the timed region: the side measurements above (a 0.6 GB
     # device-to-host copy among them) leave the GPU idle long enough for its clocks to drop, and a timed region
@@ -504,7 +853,6 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     prof = eng.profile_read(reset=True)
-    prof["count"], prof["tile_scan"] = side["count"], side["tile_scan"]
     eng.profile(0)
     state = eng.query()
 
@@ -527,27 +875,35 @@ def main():
     build_id = nat.lib().crp_build_id().decode()
     n_chars = arena.stats()["n_chars"]
     tiles = arena.tiles()
+    composition = arena.composition()  # upper-case ACGT vs everything else, counted on the GPU (which planes count)
+    is_real = bool(args.fasta)
 
     def build_line(gather_info, ot, strong=None):
         hits = n_plus + n_minus
-        algo_bytes = (n_chars + 3) // 4 + 2 * ((n_chars + 7) // 8) + 12 * hits  # SURVEY.md 8d, rank 0's launch
+        algo_bytes, planes_counted = algorithmic_bytes(n_chars, hits, composition, len(mine))  # SURVEY.md 8d, rank 0's launch
         emit = prof["emit_score"]
         emit_ms = emit["ms"] / max(1, emit["launches"])
         achieved = algo_bytes / (emit_ms * 1e-3) / 1e9
-        path_ms = sum(prof[k]["ms"] / max(1, prof[k]["launches"]) for k in ("count", "tile_scan", "emit_score"))
         facts, facts_src = load_profile_facts(build_id, genomes[0].name)
         three_launches = bool(args.two_pass or state["two_pass_active"])
+        # the kernels that ran inside the timed steps: one in the single-launch mode, three otherwise -- the
+        # count and tile-scan times of the three-launch mode come from the side run and are reported under `three_launch`
+        path_ms = emit_ms + ((three_launch_side["count"] + three_launch_side["tile_scan"]) if three_launches else 0.0)
         roof = {"bound": "hbm",
                 "kernel": "emit_kernel (scan+compact+score)" if three_launches else
                           "emit_kernel, single launch (masks + chained tile offsets + compact + score)",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": facts.get("hbm_bytes_per_launch") if facts else None, "traffic_source": facts_src,
                 "algorithmic_bytes_per_launch": int(algo_bytes),
+                "algorithmic_bytes": "ceil(N/4) + 2*ceil(N/8) + 12*H" if planes_counted else
+                                     "ceil(N/4) + 12*H (entirely upper-case ACGT input: SURVEY.md 8d leaves the two bit-planes out)",
+                "characters": {"N": int(n_chars), "upper_case_acgt": composition["n_plain"], "other": composition["n_other"]},
                 # a pure streaming read of the same planes on this box (the count kernel): the practical ceiling beside the 8 TB/s spec
                 "measured_stream_read_GBs": stream_GBs,
                 "kernel_ms": emit_ms, "all_kernels_ms": path_ms,
-                "count_kernel_ms": prof["count"]["ms"] / max(1, prof["count"]["launches"]),
-                "tile_scan_ms": prof["tile_scan"]["ms"] / max(1, prof["tile_scan"]["launches"])}
+                # CRP_OPT_TWO_PASS = 1's kernels on the same arena, from a side run outside the timed region
+                "three_launch": {"count_kernel_ms": three_launch_side["count"], "tile_scan_ms": three_launch_side["tile_scan"],
+                                 "emit_kernel_ms": three_launch_side["emit_score"]}}
         if facts and facts.get("valu_insts_per_launch") and facts.get("kernel_cycles_per_launch"):
             # the second, honest ceiling: the kernel is VALU-issue bound (one wave64 VALU instruction
             # holds its SIMD for 4 cycles on average here): issue slots used / issue slots there were
@@ -561,7 +917,7 @@ def main():
             "metric": "gRNAs scored/sec", "value": scored_all * args.steps / dt, "unit": "gRNAs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "untimed_steps_before": n_warm,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f64", "data": "real" if is_real else "synthetic",
             "config": {"workload": genomes[0].name, "genomes": world, "contigs_per_genome": len(genomes[0].specs),
                        "bases_total": int(bases_all), "kept_hits_total": int(hits_all),
                        "guide_len": 20,
@@ -609,8 +965,11 @@ def main():
         if gather_info is not None:
             line["gatherv_ok"] = "s" in gather_info
             if "s" in gather_info:
-                moved = 12.0 * (hits_all - hits)  # bytes that crossed xGMI to rank 0
-                gather_info.update({"bytes_to_root": int(moved), "GB_per_s_into_root": moved / gather_info["s"] / 1e9})
+                # bytes that crossed to rank 0, as the transport counted them: 10 B per hit with the 16-bit position packing
+                # (CRP_GATHER_POS16; 12 B raw) + one word per 65 536 arena positions and table
+                moved = float(gather_info.get("bytes_to_root", 12.0 * (hits_all - hits)))
+                gather_info.update({"bytes_to_root": int(moved), "bytes_if_raw_u32_positions": int(12.0 * (hits_all - hits)),
+                                    "GB_per_s_into_root": moved / gather_info["s"] / 1e9})
                 # the WHOLE job of the path at N ranks = one scan on every rank + the one exchange: this, not
                 # `value` (whose timed steps hold no collective and therefore grow ~N-fold by construction),
                 # is the number to build a scaling curve from
@@ -671,6 +1030,9 @@ def main():
             fence()
             tg = time.perf_counter() - tg
             gather_info = {"s": tg}  # rank 0 finishes last: it waits for every receive
+            if rank == 0:
+                gather_info["bytes_to_root"] = eng.gather_bytes() if use_rccl else int(getattr(group, "bytes_gathered", 0))
+                gather_info["positions"] = "16 bits per hit + one word per 65 536 arena positions (CRP_GATHER_POS16)"
         except Exception as e:  # the bench line is printed even if the exchange fails on this node
             gather_info = {"error": repr(e)[:300]}
         unguard()
@@ -771,7 +1133,7 @@ def main():
 
     # ---- the opt-in annotation join (BASELINE.json configs[2], [3] name a GFF) on the same resident tables
     ann_block = None
-    if args.annotate_steps > 0 and world == 1:
+    if args.annotate_steps > 0 and world == 1 and (not is_real or args.gff):
         try:
             import shutil
             import tempfile
@@ -779,9 +1141,13 @@ def main():
             from cropsr_amd import annotate
             tmp = tempfile.mkdtemp(prefix="cropsr_bench_gff_")
             try:
-                gff, info_path = os.path.join(tmp, "genes.gff3"), os.path.join(tmp, "annotation_info.txt")
-                n_genes = max(50, int(args.annotate_genes * (args.scale if args.workload == "switchgrass" else 1.0)))
-                gff_rows = bw.synthetic_annotation(genomes[0], gff, info_path, n_genes=n_genes)
+                if is_real:  # the user's own annotation beside the user's own genome
+                    gff, info_path = args.gff, args.phytozome
+                    gff_rows = (None, None)
+                else:
+                    gff, info_path = os.path.join(tmp, "genes.gff3"), os.path.join(tmp, "annotation_info.txt")
+                    n_genes = max(50, int(args.annotate_genes * (args.scale if args.workload == "switchgrass" else 1.0)))
+                    gff_rows = bw.synthetic_annotation(genomes[0], gff, info_path, n_genes=n_genes)
                 t_b = time.perf_counter()
                 ann = annotate.Annotation(gff, info_path)
                 t_b = time.perf_counter() - t_b
@@ -789,7 +1155,7 @@ def main():
             finally:
                 shutil.rmtree(tmp, ignore_errors=True)
             names = [genomes[all_specs[i][0]].specs[all_specs[i][1]].name for i in mine]
-            req = annotate.Request(ann, names, 1)
+            req = annotate.Request(ann, names, getattr(genomes[0], "dec", 1))
             t_t = time.perf_counter()
             points, ids = req.track([(j, int(arena.offsets[j]), int(arena.lengths[j])) for j in range(len(mine))])
             arena.annotate_set_track(points, ids)
@@ -812,15 +1178,25 @@ def main():
             algo = 16.0 * (n_plus + n_minus)  # 4 B position + 8 B score in, 4 B label-set id out per hit
             ann_block = {"metric": "hits annotated/sec", "value": (n_plus + n_minus) / t_l, "unit": "hits/s",
                          "steps": args.annotate_steps, "ms_per_lookup": t_l * 1e3, "kernel_ms": k_ms,
-                         "gff": {"gene_rows": gff_rows[0], "cds_rows": gff_rows[1], "bytes": gff_bytes, "data": "synthetic, seeded"},
+                         "gff": {"gene_rows": gff_rows[0], "cds_rows": gff_rows[1], "bytes": gff_bytes,
+                                 "data": os.path.basename(args.gff) if is_real else "synthetic, seeded"},
                          "label_sets": len(ann.strings), "track_points": int(points.size), "hits_with_a_feature": n_feat,
                          "host_build_s": t_b, "track_layout_upload_s": t_t,
                          "roofline": {"bound": "hbm", "kernel": "annot_lookup_kernel (both tables, one launch)",
                                       "achieved": algo / (k_ms * 1e-3) / 1e9 if k_ms else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                       "frac": (algo / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if k_ms else None,
-                                      "algorithmic_bytes_per_launch": int(algo), "traffic": None},
+                                      "algorithmic_bytes_per_launch": int(algo), "traffic": None, "traffic_source": None},
                          "parity": "unpinned: the reference parses the GFF and never joins it (oracle: oracle/annotate_oracle.py)"}
             ann.close()
+            # counter traffic of the look-up kernel per launch (tools/pmc_calibrate.sh -> profiles/offtarget_traffic.json), used
+            # only if it was measured on THIS build, this workload and this block's own tables (same algorithmic bytes)
+            tj = load_offtarget_traffic(build_id, genomes[0].name)
+            if tj and tj.get("annotate_lookup_traffic_bytes_per_launch") and \
+                    tj.get("annotate_lookup_algorithmic_bytes_per_launch") == int(algo):
+                r = ann_block["roofline"]
+                r["traffic"] = tj["annotate_lookup_traffic_bytes_per_launch"]
+                r["traffic_over_algorithmic"] = r["traffic"] / algo
+                r["traffic_source"] = "profiles/offtarget_traffic.json: " + tj.get("correction", "")
         except Exception as e:
             import traceback
             traceback.print_exc()

@@ -38,8 +38,10 @@ SIGNATURES = {
     "crp_arena_seal": (ctypes.c_int, [ctypes.c_void_p]),
     "crp_arena_tiles": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), u64p, u64p]),
     "crp_arena_stats": (ctypes.c_int, [ctypes.c_void_p, u64p, u64p, u64p]),
+    "crp_arena_composition": (ctypes.c_int, [ctypes.c_void_p, u64p, u64p]),
     "crp_scan_score": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, u64p, u64p]),
     "crp_fetch_hits": (ctypes.c_int, [ctypes.c_void_p, u32p, f64p, f64p, u32p, f64p, f64p]),
+    "crp_hits_counts": (ctypes.c_int, [ctypes.c_void_p, u64p, u64p]),
     "crp_hits_device": (ctypes.c_int, [ctypes.c_void_p, voidpp, voidpp, voidpp, voidpp]),
     "crp_score_30mers": (ctypes.c_int, [ctypes.c_void_p, u8p, ctypes.c_uint64, ctypes.c_int, f64p, f64p]),
     "crp_format_rows": (ctypes.c_int, [u8p, ctypes.c_uint64, u8p, ctypes.c_uint64, ctypes.c_int, u32p, u8p, f64p,
@@ -71,6 +73,7 @@ SIGNATURES = {
     "crp_node_scan_score": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, u64p, u64p]),
     "crp_node_gather": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]),
     "crp_node_counts": (ctypes.c_int, [ctypes.c_void_p, u64p, u64p, u64p]),
+    "crp_node_count_scored": (ctypes.c_int, [ctypes.c_void_p, u64p]),
     "crp_node_fetch": (ctypes.c_int, [ctypes.c_void_p, u32p, f64p, u32p, f64p]),
     "crp_node_tables_device": (ctypes.c_int, [ctypes.c_void_p, voidpp, voidpp, voidpp, voidpp]),
     "crp_node_gather_stats": (ctypes.c_int, [ctypes.c_void_p, f64p, f64p, u64p, ctypes.POINTER(ctypes.c_int)]),

@@ -903,6 +903,15 @@ int crp_fetch_hits(crp_arena *a, uint32_t *pos_plus, double *pre_plus, double *s
     return CRP_OK;
 }
 
+int crp_hits_counts(const crp_arena *a, uint64_t *n_plus, uint64_t *n_minus)
+{
+    if (!a) return CRP_ERR_INVALID;
+    if (!a->have_hits) return CRP_ERR_STATE;
+    if (n_plus) *n_plus = a->n_hits[0];
+    if (n_minus) *n_minus = a->n_hits[1];
+    return CRP_OK;
+}
+
 int crp_hits_device(crp_arena *a, void **pos_plus, void **score_plus, void **pos_minus, void **score_minus)
 {
     if (!a) return CRP_ERR_INVALID;
@@ -1038,6 +1047,21 @@ int crp_count_scored(crp_arena *a, uint64_t *n_scored)
     CRP_HIP(ctx, hipMemcpyAsync(ctx->h_scalar, ctx->d_scalar, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
     CRP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     *n_scored = ctx->h_scalar[0];
+    return CRP_OK;
+}
+
+int crp_arena_composition(crp_arena *a, uint64_t *n_plain, uint64_t *n_other)
+{
+    if (!a) return CRP_ERR_INVALID;
+    if (!a->sealed) return CRP_ERR_STATE;
+    crp_ctx *ctx = a->ctx;
+    CRP_HIP(ctx, hipSetDevice(ctx->device));
+    CRP_HIP(ctx, hipMemsetAsync(ctx->d_scalar, 0, sizeof(uint64_t), ctx->stream));
+    CRP_HIP(ctx, crp::launch_count_plain(ctx->stream, a->d_plane[2], a->d_plane[3], a->used_words, ctx->d_scalar));
+    CRP_HIP(ctx, hipMemcpyAsync(ctx->h_scalar, ctx->d_scalar, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    CRP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (n_plain) *n_plain = ctx->h_scalar[0];
+    if (n_other) *n_other = a->n_chars - ctx->h_scalar[0];
     return CRP_OK;
 }
 

@@ -86,6 +86,8 @@ hipError_t launch_emit_chained(hipStream_t s, int geo, const Planes &pl, uint64_
                                uint64_t *chain_next, const HitTables &out, uint32_t mute_tile, uint32_t timeout_ticks);
 // adds the number of entries of score[0..n) that are not -1 to *out (device memory)
 hipError_t launch_count_scored(hipStream_t s, const double *score, uint64_t n, uint64_t *out);
+// adds the number of upper-case A/C/G/T characters of the planes' first n_words words to *out (device memory)
+hipError_t launch_count_plain(hipStream_t s, const uint64_t *up, const uint64_t *ac, uint64_t n_words, uint64_t *out);
 hipError_t launch_score30(hipStream_t s, const uint8_t *rows, uint64_t n, int order, double *pre, double *score);
 hipError_t launch_pack(hipStream_t s, const uint8_t *text, uint64_t len, uint64_t n_words, uint64_t *hi,
                        uint64_t *lo, uint64_t *up, uint64_t *ac);

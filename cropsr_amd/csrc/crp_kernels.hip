@@ -1192,6 +1192,28 @@ hipError_t launch_count_scored(hipStream_t s, const double *score, uint64_t n, u
     return hipGetLastError();
 }
 
+// ------------------------------------------------------- composition of an arena
+// how many characters are upper-case A/C/G/T (bit set in both the `up` and the `ac` plane; void positions have neither)
+__global__ __launch_bounds__(BLOCK) void count_plain_kernel(const uint64_t *__restrict__ up, const uint64_t *__restrict__ ac,
+                                                             uint64_t n_words, unsigned long long *__restrict__ out)
+{
+    uint64_t c = 0;
+    for (uint64_t w = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; w < n_words; w += (uint64_t)gridDim.x * BLOCK)
+        c += (uint64_t)__popcll(up[w] & ac[w]);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, (unsigned long long)c);
+}
+
+hipError_t launch_count_plain(hipStream_t s, const uint64_t *up, const uint64_t *ac, uint64_t n_words, uint64_t *out)
+{
+    if (n_words == 0) return hipSuccess;
+    const uint64_t blocks = (n_words + BLOCK - 1) / BLOCK;
+    hipLaunchKernelGGL(count_plain_kernel, dim3((uint32_t)(blocks < 2048 ? blocks : 2048)), dim3(BLOCK), 0, s, up, ac, n_words,
+                       reinterpret_cast<unsigned long long *>(out));
+    return hipGetLastError();
+}
+
 uint8_t host_classify_char(uint32_t ch) { return classify_char(ch); }
 
 }  // namespace crp

@@ -748,6 +748,20 @@ int crp_node_counts(const crp_node *node, uint64_t *per_contig, uint64_t *n_plus
     return CRP_OK;
 }
 
+int crp_node_count_scored(crp_node *node, uint64_t *n_scored)
+{
+    if (!node || !n_scored) return CRP_ERR_INVALID;
+    if (!node->have_gather) return CRP_ERR_STATE;
+    crp_ctx *ctx = node->dev[(size_t)node->root].ctx;
+    NODE_HIP(node, hipSetDevice(ctx->device));
+    NODE_HIP(node, hipMemsetAsync(ctx->d_scalar, 0, sizeof(uint64_t), ctx->stream));
+    for (int s = 0; s < 2; ++s) NODE_HIP(node, crp::launch_count_scored(ctx->stream, node->d_fscore[s], node->total[s], ctx->d_scalar));
+    NODE_HIP(node, hipMemcpyAsync(ctx->h_scalar, ctx->d_scalar, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    NODE_HIP(node, hipStreamSynchronize(ctx->stream));
+    *n_scored = ctx->h_scalar[0];
+    return CRP_OK;
+}
+
 int crp_node_fetch(crp_node *node, uint32_t *pos_plus, double *score_plus, uint32_t *pos_minus, double *score_minus)
 {
     crp::Range roctx_range("crp: node D2H tables");

@@ -120,6 +120,13 @@ class Arena:
         name = [k for k, v in nat.GEOMETRIES.items() if v == g.value][0]
         return dict(geometry=name, n_tiles=int(n.value), tile_words=int(w.value))
 
+    def composition(self):
+        """dict(n_plain, n_other): upper-case A/C/G/T characters of the arena, and all others (counted on the GPU)."""
+        a, b = ctypes.c_uint64(), ctypes.c_uint64()
+        nat.check(nat.lib().crp_arena_composition(self._h, ctypes.byref(a), ctypes.byref(b)), "crp_arena_composition",
+                  self._engine._ctx)
+        return dict(n_plain=a.value, n_other=b.value)
+
     def scan_score_device(self, guide_len=20, want_pre=False, want_seeds=False):
         """Run the kernels; tables stay in HBM.  Returns (n_plus, n_minus).  want_seeds: the scan also writes the
         seed words the off-target step works on (CRP_SCAN_SEEDS; offtarget_add then skips its own pass over the

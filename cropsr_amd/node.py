@@ -202,6 +202,31 @@ class Node:
                     "crp_node_counts")
         return per, a.value, b.value
 
+    def count_scored(self):
+        """Rows of the gathered tables that carry a real score (counted on the root device)."""
+        n = ctypes.c_uint64()
+        self._check(nat.lib().crp_node_count_scored(self._h, ctypes.byref(n)), "crp_node_count_scored")
+        return n.value
+
+    def device_counts(self, k):
+        """dict(n_plus, n_minus, n_scored) of logical device k's OWN tables (rows inside its halos included), or None."""
+        a = nat.lib().crp_node_arena(self._h, int(k))
+        if not a:
+            return None
+        a = ctypes.c_void_p(a)
+        x, y, z = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
+        nat.check(nat.lib().crp_hits_counts(a, ctypes.byref(x), ctypes.byref(y)), "crp_hits_counts")
+        nat.check(nat.lib().crp_count_scored(a, ctypes.byref(z)), "crp_count_scored")
+        return dict(n_plus=x.value, n_minus=y.value, n_scored=z.value)
+
+    def arena_composition(self, k):
+        a = nat.lib().crp_node_arena(self._h, int(k))
+        if not a:
+            return None
+        x, y = ctypes.c_uint64(), ctypes.c_uint64()
+        nat.check(nat.lib().crp_arena_composition(ctypes.c_void_p(a), ctypes.byref(x), ctypes.byref(y)), "crp_arena_composition")
+        return dict(n_plain=x.value, n_other=y.value)
+
     def fetch(self, guide_len=20):
         """Host copies of the gathered tables -> NodeHits."""
         per, n_plus, n_minus = self.counts()

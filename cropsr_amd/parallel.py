@@ -262,9 +262,9 @@ def sharded_scan(backend, strings, guide_len, group, dst=0, max_piece=None, offt
     the annotation track of its pieces (Resident.annotate) and the label-set ids travel with the tables; the hit dicts
     then carry feat_plus / feat_minus.
 
-    A rank that fails before the exchange (a share that does not fit its GPU, a HIP error) reports
-    it through group.check, so EVERY rank raises rendezvous.RankError with the same message
-    instead of waiting in a collective."""
+    A rank that fails before the exchange (a share that does not fit its GPU, a HIP error, an annotation
+    that cannot be built or joined) reports it through group.check, so EVERY rank raises rendezvous.RankError
+    with the same message instead of waiting in a collective."""
     rank, world = group.rank, group.world
     plan = strong_plan([len(s) for s in strings], world, max_piece)
     pieces, mine = plan["pieces"], plan["by_rank"][rank]
@@ -284,8 +284,16 @@ def sharded_scan(backend, strings, guide_len, group, dst=0, max_piece=None, offt
                 own[a].append((int(off) + shift, int(off) + shift + pieces[q][2] - pieces[q][1]))
             res.offtarget(group, [sorted(o) for o in own])
         if annotation is not None:
-            # a piece's text starts `shift` characters before the piece (its halo): index of its first character
-            res.annotate(annotation.pieces([pieces[q][0] for q in mine], [pieces[q][1] - shift for q, (_, shift) in zip(mine, views)]))
+            # What can fail on ONE rank here -- the lazy build of the Annotation (a GFF that does not parse), the track of
+            # this rank's pieces, HBM for the track or the ids, a HIP error in the look-up -- is agreed on like the scan's
+            # errors are: a rank that raised alone would leave its peers in the gatherv below.
+            err = None
+            try:
+                # a piece's text starts `shift` characters before the piece (its halo): index of its first character
+                res.annotate(annotation.pieces([pieces[q][0] for q in mine], [pieces[q][1] - shift for q, (_, shift) in zip(mine, views)]))
+            except Exception as e:
+                err = "annotation join: %s: %s" % (type(e).__name__, e)
+            group.check(err)
         layouts = group.all_gather([(q, int(a), int(off), int(ln)) for q, (a, off, ln) in zip(mine, res.layout)])
         gathered = res.gather(group, dst, offtarget, features=True) if annotation is not None else res.gather(group, dst, offtarget)
     finally:

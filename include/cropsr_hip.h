@@ -125,6 +125,12 @@ int crp_arena_tiles(const crp_arena *arena, int *geometry, uint64_t *n_tiles, ui
 /* Totals: contigs, characters, words used. */
 int crp_arena_stats(const crp_arena *arena, uint64_t *n_contigs, uint64_t *n_chars, uint64_t *n_words);
 
+/* What the arena's characters are, counted on the GPU from the planes: upper-case A/C/G/T, and everything else
+ * (lower case, N, IUPAC codes, the decoration characters of cropsr_functions.py:221-229).  An arena whose n_other is
+ * nothing but decoration (<= 4 per contig) is the "entirely upper-case ACGT" input for which SURVEY.md 8(d) leaves the
+ * two 1-bit planes out of the algorithmic bytes (bench.py).  Either pointer may be NULL. */
+int crp_arena_composition(crp_arena *arena, uint64_t *n_plain, uint64_t *n_other);
+
 /* ---- seam 1 + 2 over a whole arena -------------------------------------- */
 /* Scan both strands of every contig, keep what CROPSR.py:419/:430 keep for
  * guide length `guide_len` (0..50; the reference takes any integer: for lengths outside that range scan with the
@@ -147,6 +153,8 @@ int crp_scan_score(crp_arena *arena, int guide_len, int flags,
  * n_minus.  Any pointer may be NULL to skip that column. */
 int crp_fetch_hits(crp_arena *arena, uint32_t *pos_plus, double *pre_plus, double *score_plus,
                    uint32_t *pos_minus, double *pre_minus, double *score_minus);
+/* Rows of the '+' and '-' tables of the last crp_scan_score (what it returned in *n_plus / *n_minus). */
+int crp_hits_counts(const crp_arena *arena, uint64_t *n_plus, uint64_t *n_minus);
 /* Device addresses of the same tables (valid until the next crp_scan_score or
  * crp_arena_destroy) for a device-to-device gather such as RCCL send/recv. */
 int crp_hits_device(crp_arena *arena, void **pos_plus, void **score_plus,
@@ -334,6 +342,8 @@ int crp_node_gather(crp_node *node, int root, int flags);
 /* After crp_node_gather: kept hits per contig and strand (2 x n contigs: {plus, minus}) and in all; any pointer may
  * be NULL. */
 int crp_node_counts(const crp_node *node, uint64_t *per_contig, uint64_t *n_plus, uint64_t *n_minus);
+/* Rows of the gathered tables that carry a real score (not -1), counted on the root: the unit of "gRNAs scored". */
+int crp_node_count_scored(crp_node *node, uint64_t *n_scored);
 /* The gathered tables to host arrays (n_plus / n_minus rows; contig order, ascending inside a contig, positions local
  * to the contig string; any pointer may be NULL), and their addresses in the root's HBM (valid until the next
  * crp_node_gather / crp_node_load). */

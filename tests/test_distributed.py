@@ -110,6 +110,51 @@ def _failing_worker(rank, world, port, out_dir):
     group.close()
 
 
+def _failing_annotate_worker(rank, world, port, out_dir):
+    group = _group(rank, world, port)
+    from conftest import OracleBackend, OracleResident
+    from cropsr_amd import annotate, parallel, rendezvous
+    from oracle import oracle
+
+    class BrokenResident(OracleResident):
+        def annotate(self, request):
+            if group.rank == 2:
+                raise MemoryError("no room for this rank's track")
+            return OracleResident.annotate(self, request)
+
+    class Backend(OracleBackend):
+        def scan_resident(self, texts, l, offtarget=False):
+            return BrokenResident(self.orc, texts, l)
+
+    gff = os.path.join(out_dir, "a.gff")
+    if rank == 0:
+        with open(gff + ".tmp", "w") as f:
+            f.write("##gff-version 3\nc0\tsrc\tgene\t10\t900\t.\t+\t.\tID=g1\n")
+        os.replace(gff + ".tmp", gff)
+    group.barrier()
+    contigs = _make_contigs()
+    ann = annotate.Annotation(gff)
+    req = annotate.Request(ann, ["c%d" % k for k in range(len(contigs))], 1)
+    try:
+        parallel.sharded_scan(Backend(oracle), contigs, 20, group, annotation=req)
+        msg = "no error"
+    except rendezvous.RankError as e:
+        msg = str(e)
+    with open(os.path.join(out_dir, "rank%d.txt" % rank), "w") as f:
+        f.write(msg)
+    ann.close()
+    group.close()
+
+
+def test_a_rank_that_fails_in_the_annotation_join_fails_every_rank(tmp_path):
+    """ADVICE r04: between the scan's agreement and the gatherv every rank joins ITS tables with the annotation; a rank
+    that fails there (here: rank 2 of 3) must not raise alone -- its peers would wait in the exchange.  Every rank raises
+    the same RankError."""
+    assert _spawn(_failing_annotate_worker, 3, str(tmp_path)) == [0, 0, 0]
+    msgs = [(tmp_path / ("rank%d.txt" % r)).read_text() for r in range(3)]
+    assert msgs[0] == msgs[1] == msgs[2] and "rank 2: annotation join: MemoryError: no room for this rank's track" in msgs[0]
+
+
 def test_one_failing_rank_fails_every_rank_with_the_same_message(tmp_path):
     """A rank that cannot scan its share reports it BEFORE the exchange: no rank is left waiting in a
     collective (VERDICT r01 weak #8); all of them raise the same RankError."""

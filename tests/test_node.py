@@ -284,3 +284,70 @@ def test_node_on_rccl_with_one_device(tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
     d = json.loads(out.read_text())
     assert d["hits"] > 10_000 and d["transport"].startswith("RCCL") and d["bytes_to_root"] == 0
+
+
+def _bench(*argv, timeout=900):
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "CROPSR_LAUNCHED")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(argv), capture_output=True, text=True,
+                       timeout=timeout, cwd=ROOT, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_bench_single_process_four_logical_devices():
+    """`bench.py --gpus 4 --single-process`: the same line through the node handle -- ONE process, no launcher, no sockets.
+    On the one-GPU box the four devices are GPU 0 four times (--share-gpu0): four contexts, four arenas, the exchange as
+    device-to-device copies; the strong block's stitched tables equal device 0's own N = 1 scan, contig by contig."""
+    d = _bench("--gpus", "4", "--single-process", "--share-gpu0", "--scale", "0.05", "--steps", "3", "--warmup", "1")
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in d, key
+    assert d["n_gpus"] == 4 and d["scaling"] == "weak" and d["value"] > 0 and d["gatherv_ok"] is True
+    assert "ONE process" in d["config"]["parallelism"] and d["config"]["genomes"] == 4
+    assert [r["rank"] for r in d["per_rank"]] == [0, 1, 2, 3] and all(r["kernel_ms"] > 0 for r in d["per_rank"])
+    chars = [r["characters_with_halos"] for r in d["per_rank"]]
+    assert max(chars) - min(chars) <= 6 * 4096
+    g = d["gatherv"]
+    assert g["transport"] == "device-to-device copies" and 0 < g["bytes_to_root"] < 0.86 * g["raw_u32_positions"]["bytes_to_root"]
+    assert d["value_with_final_gatherv"] < d["value"]
+    st = d["strong"]
+    assert st["digest_ok"] is True and st["genomes"] == 1 and st["contigs_cut"] >= 1 and st["kept_hits"] == st["n1"]["kept_hits"]
+    assert st["bytes_to_root"] > 0 and st["value"] < st["value_scan_only"] and len(st["per_rank"]) == 4
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+
+
+@pytest.mark.gpu
+def test_bench_real_fasta_and_bytes_per_survey_8d(tmp_path):
+    """--fasta: a REAL genome through the bench (SURVEY.md 8d "real FASTA may be substituted"): the reference's own sample
+    (sample_data/sample_genome.fa, committed here gzipped as a fixture) gives its 17 314 kept hits, `data` says real and the
+    workload names the file.  And the bytes of the roofline follow SURVEY.md 8(d) for every input: the two 1-bit planes
+    count for the soft-masked sample and are left out for the entirely upper-case E. coli-like genome (cfg 2)."""
+    import gzip
+    from conftest import GOLDEN
+    fa = tmp_path / "sample_genome.fa"
+    with gzip.open(os.path.join(GOLDEN, "sample_genome.fa.gz"), "rb") as f:
+        fa.write_bytes(f.read())
+    d = _bench("--fasta", str(fa), "--steps", "3", "--warmup", "1", "--cpu-sample-bases", "20000", "--offtarget-steps", "1")
+    assert d["data"] == "real" and d["config"]["kept_hits_total"] == 17314 and d["config"]["workload"].startswith("sample_genome.fa")
+    assert d["config"]["bases_total"] == 230218 and "annotate" not in d and d["cpu_baseline"]["value"] > 0
+    r = d["roofline"]
+    n = r["characters"]["N"]
+    assert n == 230218 + 4 and r["characters"]["other"] > 20000  # 12.9 % lower case
+    assert r["algorithmic_bytes_per_launch"] == (n + 3) // 4 + 2 * ((n + 7) // 8) + 12 * 17314
+    # with its GFF: the annotate block joins the user's own annotation
+    d = _bench("--fasta", str(fa), "--gff", os.path.join(GOLDEN, "sample_head.gff"), "--steps", "2", "--warmup", "1",
+               "--cpu-sample-bases", "0", "--offtarget-steps", "0")
+    assert d["annotate"]["gff"]["data"] == "sample_head.gff" and d["annotate"]["roofline"]["frac"] > 0
+    # cfg 2: upper-case ACGT only
+    d = _bench("--workload", "ecoli", "--steps", "3", "--warmup", "1", "--cpu-sample-bases", "0", "--offtarget-steps", "0",
+               "--annotate-steps", "0")
+    r = d["roofline"]
+    n, h = r["characters"]["N"], d["config"]["kept_hits_total"]
+    assert n == 4641652 + 4 and r["characters"]["other"] == 4
+    assert r["algorithmic_bytes_per_launch"] == (n + 3) // 4 + 12 * h and "12*H" in r["algorithmic_bytes"] and "2*ceil" not in r["algorithmic_bytes"]
+    assert "three_launch" in r and r["all_kernels_ms"] == r["kernel_ms"]

@@ -104,9 +104,14 @@ def main():
                              "streams, strided and random 16-byte gathers, profiles/r04/fetch_calibration.json); writes = "
                              "WRITE_SIZE x 1024 (exact for streaming stores; 32-byte sectors per scattered store)",
                "source": "tools/pmc_calibrate.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"}
-    ann = stages.get("crp::annot_lookup_kernel")
-    if ann:
-        ot_json["annotate_lookup_traffic_bytes_per_launch"] = 2 * ann["FETCH_SIZE_bytes_raw"] + ann["WRITE_SIZE_bytes_raw"]
+    # the annotation look-up: bench.py's own annotate block runs it on the BENCH workload's tables (that is the figure the
+    # bench line's annotate.roofline.traffic quotes); tools/annotate_bench.py runs it on the sorghum-like genome
+    name = "crp::annot_lookup_kernel"
+    if bf.get(name, {}).get("FETCH_SIZE") is not None and bw.get(name, {}).get("WRITE_SIZE") is not None:
+        ot_json["annotate_lookup_traffic_bytes_per_launch"] = 1024 * (2 * bf[name]["FETCH_SIZE"] + bw[name]["WRITE_SIZE"])
+        ot_json["annotate_lookup_algorithmic_bytes_per_launch"] = (bench.get("annotate", {}).get("roofline", {}) or {}).get("algorithmic_bytes_per_launch")
+    if af.get(name, {}).get("FETCH_SIZE") is not None and aw.get(name, {}).get("WRITE_SIZE") is not None:
+        ot_json["annotate_lookup_traffic_bytes_per_launch_sorghum_like"] = 1024 * (2 * af[name]["FETCH_SIZE"] + aw[name]["WRITE_SIZE"])
     with open(os.path.join(out, "offtarget_traffic.json"), "w") as fjson:
         json.dump(ot_json, fjson, indent=1)
     print(json.dumps(ot_json, indent=1))
