@@ -91,6 +91,10 @@ def parse_args():
                          "a 1500 s step time-out of whoever runs the bench, so that the launcher's own 124 path comes first)")
     ap.add_argument("--no-strong", action="store_true",
                     help="N > 1: skip the strong-scaling block (ONE genome cut over the N ranks, BASELINE.json configs[3], [4])")
+    ap.add_argument("--no-node-block", action="store_true",
+                    help="N > 1, one process per GPU: skip rank 0's closing block that drives the SAME N devices through the "
+                         "library's single-process node handle (crp_node_*: ncclCommInitAll + one grouped send/recv, and device-to-"
+                         "device copies) on the strong-scaling genome, while the other ranks wait")
     ap.add_argument("--strong-steps", type=int, default=0, help="timed steps of the strong-scaling block (0 = --steps)")
     ap.add_argument("--no-strong-check", action="store_true",
                     help="strong-scaling block: skip rank 0's N = 1 scan of the whole genome (the efficiency's denominator and "
@@ -272,12 +276,15 @@ def strong_scaling_block(args, eng, group, use_rccl, fence, reduce):
     for q in mine:
         wanted.setdefault(pieces[q][0], []).append(q)
     ref_builder = eng.arena_builder(lengths) if (rank == 0 and check) else None
+    kept_strings = [] if (ref_builder is not None and not args.no_node_block) else None  # (rank 0: for the node block that follows)
     t_gen = time.perf_counter()
     views = {}
     for k in (range(len(lengths)) if ref_builder is not None else sorted(wanted)):
         s = wl.contig_string(k)
         if ref_builder is not None:
             ref_builder.add(s)
+            if kept_strings is not None:
+                kept_strings.append(s)
         for q in wanted.get(k, ()):
             v, shift = parallel.piece_view(s, pieces[q][1], pieces[q][2])
             views[q] = (np.array(v, dtype=np.uint8, copy=True), shift)  # (a copy: the contig itself is released)
@@ -391,6 +398,7 @@ def strong_scaling_block(args, eng, group, use_rccl, fence, reduce):
             out["speedup_vs_n1"] = t1 / (dt_scan + dt_gather)
             out["efficiency_vs_n1"] = t1 / (dt_scan + dt_gather) / world
             out["efficiency_vs_n1_scan_only"] = t1 / dt_scan / world
+            out["_for_node_block"] = (kept_strings, want, dict(out["n1"]))  # (popped by main before the line is built)
             ref.close()
         fence()
     arena.close()
@@ -408,6 +416,94 @@ def load_offtarget_traffic(build_id, workload):
     if tj.get("workload") != workload or tj.get("build_id") != build_id:
         return None
     return tj
+
+
+def node_strong_block(args, node, devices, wl_name, one, n_warm, want=None, n1=None):
+    """ONE genome (`one`: its contig strings) over the devices of `node` (crp_node_*): load (the library cuts it into
+    contiguous equal shares with halos), timed scans, the gatherv with and without the 16-bit position packing -- and as
+    device-to-device copies as well when the default transport was RCCL -- then the stitched tables' SHA-256 per contig
+    against `want` (the digests of an N = 1 scan; computed here on devices[0] if not given)."""
+    from cropsr_amd import Engine
+    from cropsr_amd import _native as nat
+    from cropsr_amd.engine import Hits
+    world = node.size
+    steps = args.strong_steps or args.steps
+
+    def time_gather(**kw):
+        node.gather(0, **kw)  # warm-up: buffers sized, RCCL's point-to-point channels set up
+        reps = [node.gather(0, **kw) for _ in range(3)]
+        best = min(reps, key=lambda r: r["ms_total"])
+        return {"ms": best["ms_total"], "ms_exchange": best["ms_exchange"], "bytes_to_root": best["bytes_to_root"],
+                "transport": best["transport"], "ms_all": [round(r["ms_total"], 4) for r in reps], "note": best["note"]}
+
+    t_up = time.perf_counter()
+    node.load(one)
+    t_up = time.perf_counter() - t_up
+    node.scan_score_device(20)
+    for _ in range(n_warm):
+        node.scan_score_device(20)
+    node.profile(1)
+    for k in range(world):
+        node.profile_read(k, reset=True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        node.scan_score_device(20)
+    dt_scan = (time.perf_counter() - t0) / steps
+    sprof = [node.profile_read(k, reset=True)["emit_score"] for k in range(world)]
+    node.profile(0)
+    g = time_gather(pos16=True)
+    g_raw = time_gather(pos16=False)
+    g_peer = time_gather(pos16=True, peer_copy=True) if g["transport"].startswith("RCCL") else None
+    node.gather(0)
+    dt_gather = g["ms"] * 1e-3
+    n_scored = node.count_scored()
+    hits = node.fetch()
+    plan = node.plan()
+    strong = {"workload": wl_name, "scaling": "strong", "genomes": 1, "steps": steps, "pieces": len(plan),
+              "contigs_cut": len(plan) - len(one), "halo": nat.HALO, "devices": list(devices),
+              "ms_scan_max_rank": dt_scan * 1e3, "ms_gatherv": g["ms"], "gatherv_transport": g["transport"],
+              "bytes_to_root": g["bytes_to_root"], "gatherv": g, "gatherv_raw_u32_positions": g_raw,
+              "kept_hits": hits.n_plus + hits.n_minus, "gRNAs_scored": int(n_scored), "unit": "gRNAs/s",
+              "value_scan_only": n_scored / dt_scan, "value": n_scored / (dt_scan + dt_gather),
+              "per_rank": [{"rank": k, "kernel_ms": sprof[k]["ms"] / max(1, sprof[k]["launches"]),
+                            "characters_with_halos": (node.arena_stats(k) or {}).get("n_chars", 0),
+                            "tiles": (node.arena_stats(k) or {}).get("n_tiles", 0)} for k in range(world)],
+              "setup_s": t_up}
+    if g_peer is not None:
+        strong["gatherv_device_to_device_copies"] = g_peer
+    if not args.no_strong_check:
+        got = table_digests([hits.contig(k) for k in range(len(one))])
+        if want is None:
+            with Engine(devices[0]) as eng:
+                builder = eng.arena_builder([s_.size for s_ in one])
+                for s_ in one:
+                    builder.add(s_)
+                ref = builder.seal()
+                rp, rm = ref.scan_score_device(20)
+                for _ in range(n_warm):
+                    ref.scan_score_device(20)
+                eng.profile(1)
+                eng.profile_read(reset=True)
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    ref.scan_score_device(20)
+                t1 = (time.perf_counter() - t0) / steps
+                e1 = eng.profile_read(reset=True)["emit_score"]
+                whole = Hits(ref.offsets, ref.lengths, 20, ref.fetch(rp, rm))
+                want = table_digests([whole.contig(k) for k in range(len(one))])
+                ref.close()
+            n1 = {"ms_scan": t1 * 1e3, "kernel_ms": e1["ms"] / max(1, e1["launches"]), "kept_hits": int(rp + rm)}
+        bad = [k for k in range(len(one)) if want[k] != got[k]]
+        strong["n1"] = n1
+        strong["digest_ok"] = not bad
+        if bad:
+            strong["digest_mismatch_contigs"] = bad[:10]
+        if n1:
+            t1 = n1["ms_scan"] * 1e-3
+            strong["speedup_vs_n1"] = t1 / (dt_scan + dt_gather)
+            strong["efficiency_vs_n1"] = t1 / (dt_scan + dt_gather) / world
+            strong["efficiency_vs_n1_scan_only"] = t1 / dt_scan / world
+    return strong
 
 
 def main_single_process(args):
@@ -603,71 +699,7 @@ def main_single_process(args):
     if world > 1 and not args.no_strong and not (gather_info and "error" in gather_info):
         guard("strong-scaling block", lambda why: build_line(gather_info, {"error": why}))
         try:
-            steps = args.strong_steps or args.steps
-            wl = genomes[0]
-            one = strings_of(wl)
-            t_up = time.perf_counter()
-            node.load(one)
-            t_up = time.perf_counter() - t_up
-            node.scan_score_device(20)
-            for _ in range(n_warm):
-                node.scan_score_device(20)
-            node.profile(1)
-            for k in range(world):
-                node.profile_read(k, reset=True)
-            t0 = time.perf_counter()
-            for _ in range(steps):
-                node.scan_score_device(20)
-            dt_scan = (time.perf_counter() - t0) / steps
-            sprof = [node.profile_read(k, reset=True)["emit_score"] for k in range(world)]
-            node.profile(0)
-            g = time_gather(pos16=True)
-            g_raw = time_gather(pos16=False)
-            node.gather(0)
-            dt_gather = g["ms"] * 1e-3
-            n_scored = node.count_scored()
-            hits = node.fetch()
-            plan = node.plan()
-            strong = {"workload": wl.name, "scaling": "strong", "genomes": 1, "steps": steps, "pieces": len(plan),
-                      "contigs_cut": len(plan) - len(one), "halo": nat.HALO,
-                      "ms_scan_max_rank": dt_scan * 1e3, "ms_gatherv": g["ms"], "gatherv_transport": g["transport"],
-                      "bytes_to_root": g["bytes_to_root"], "gatherv": g, "gatherv_raw_u32_positions": g_raw,
-                      "kept_hits": hits.n_plus + hits.n_minus, "gRNAs_scored": int(n_scored), "unit": "gRNAs/s",
-                      "value_scan_only": n_scored / dt_scan, "value": n_scored / (dt_scan + dt_gather),
-                      "per_rank": [{"rank": k, "kernel_ms": sprof[k]["ms"] / max(1, sprof[k]["launches"]),
-                                    "characters_with_halos": (node.arena_stats(k) or {}).get("n_chars", 0),
-                                    "tiles": (node.arena_stats(k) or {}).get("n_tiles", 0)} for k in range(world)],
-                      "setup_s": t_up}
-            if not args.no_strong_check:
-                from cropsr_amd.engine import Hits
-                got = table_digests([hits.contig(k) for k in range(len(one))])
-                with Engine(devices[0]) as eng:
-                    builder = eng.arena_builder([s.size for s in one])
-                    for s_ in one:
-                        builder.add(s_)
-                    ref = builder.seal()
-                    rp, rm = ref.scan_score_device(20)
-                    for _ in range(n_warm):
-                        ref.scan_score_device(20)
-                    eng.profile(1)
-                    eng.profile_read(reset=True)
-                    t0 = time.perf_counter()
-                    for _ in range(steps):
-                        ref.scan_score_device(20)
-                    t1 = (time.perf_counter() - t0) / steps
-                    e1 = eng.profile_read(reset=True)["emit_score"]
-                    whole = Hits(ref.offsets, ref.lengths, 20, ref.fetch(rp, rm))
-                    want = table_digests([whole.contig(k) for k in range(len(one))])
-                    ref.close()
-                bad = [k for k in range(len(one)) if want[k] != got[k]]
-                strong["n1"] = {"ms_scan": t1 * 1e3, "kernel_ms": e1["ms"] / max(1, e1["launches"]), "kept_hits": int(rp + rm)}
-                strong["digest_ok"] = not bad
-                if bad:
-                    strong["digest_mismatch_contigs"] = bad[:10]
-                strong["speedup_vs_n1"] = t1 / (dt_scan + dt_gather)
-                strong["efficiency_vs_n1"] = t1 / (dt_scan + dt_gather) / world
-                strong["efficiency_vs_n1_scan_only"] = t1 / dt_scan / world
-            del one, hits
+            strong = node_strong_block(args, node, devices, genomes[0].name, strings_of(genomes[0]), n_warm)
         except Exception as e:
             import traceback
             traceback.print_exc()
@@ -1050,6 +1082,43 @@ def main():
             strong = {"error": repr(e)[:300]}
         unguard()
 
+    # ---- the same N devices through the library's single-process node handle (crp_node_*), on the strong
+    # block's genome: rank 0 opens a node over all of them -- its peers hold their own contexts on them and wait at the
+    # barrier below -- and runs scan + gatherv on RCCL in ONE process (ncclCommInitAll, one grouped send/recv) and as
+    # device-to-device copies, with the same digest check.  It runs on a helper thread: if it does not come back within
+    # --collective-timeout the line says so and the run still ends in order.
+    node_block = None
+    for_node = strong.pop("_for_node_block", None) if isinstance(strong, dict) else None
+    if world > 1 and not args.no_node_block and not args.no_strong:
+        if rank == 0 and for_node and for_node[0]:
+            result = {}
+
+            def run_node_block():
+                try:
+                    from cropsr_amd import node as nd
+                    devices = [0] * world if args.share_gpu0 else list(range(world))
+                    with nd.Node(devices) as node:
+                        node.configure(two_pass=True if args.two_pass else None,
+                                       geometry=None if args.geometry == "auto" else args.geometry)
+                        result["block"] = node_strong_block(args, node, devices, genomes[0].name, for_node[0], max(1, args.warmup),
+                                                            want=for_node[1], n1=for_node[2])
+                except BaseException as e:
+                    import traceback
+                    traceback.print_exc()
+                    result["block"] = {"error": repr(e)[:300]}
+
+            worker = threading.Thread(target=run_node_block, name="node_block", daemon=True)
+            worker.start()
+            worker.join(args.collective_timeout if args.collective_timeout > 0 else None)
+            if worker.is_alive():
+                node_block = {"error": "did not return within %.0f s" % args.collective_timeout}
+                from cropsr_amd import engine as _engine
+                _engine._COMM_STUCK = True  # (a thread of this process sits inside RCCL: leave through os._exit at the end)
+            else:
+                node_block = result.get("block")
+            del for_node
+        group.barrier()
+
     # ---- the opt-in off-target seed scan of cfg 5 on the same resident genome and hit tables
     ot = None
     if args.offtarget_steps > 0 and rccl_error and world > 1:
@@ -1206,6 +1275,8 @@ def main():
         line = build_line(gather_info, ot, strong)
         if ann_block is not None:
             line["annotate"] = ann_block
+        if node_block is not None:
+            line["single_process_node"] = node_block
         if world == 1 and args.cpu_sample_bases > 0:
             from oracle import oracle as _o
             _o.lib()
@@ -1214,7 +1285,8 @@ def main():
         print(json.dumps(line), flush=True)
 
     failed = (bool(gather_info and "error" in gather_info) or bool(ot and "error" in ot) or
-              bool(strong and ("error" in strong or strong.get("digest_ok") is False)))
+              bool(strong and ("error" in strong or strong.get("digest_ok") is False)) or
+              bool(node_block and node_block.get("digest_ok") is False))  # (a node block that could not RUN is reported, not fatal)
     if failed:
         # the communicator is in an unknown state after a failed exchange: no collective teardown,
         # and the run must not be recorded as a clean success

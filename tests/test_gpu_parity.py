@@ -887,6 +887,10 @@ def test_bench_starts_its_own_ranks(launcher):
     assert st["kept_hits"] == st["n1"]["kept_hits"] and 0 < st["efficiency_vs_n1"] <= st["efficiency_vs_n1_scan_only"]
     assert abs(st["per_rank"][0]["bases"] - st["per_rank"][1]["bases"]) < 0.02 * st["per_rank"][0]["bases"]
     assert all(r["tiles"] > 0 and r["kernel_ms"] > 0 for r in st["per_rank"])
+    # rank 0's closing block: the same devices through the single-process node handle, same genome, same digests
+    nb = d["single_process_node"]
+    assert nb["digest_ok"] is True and nb["kept_hits"] == st["kept_hits"] and nb["gatherv_transport"] == "device-to-device copies", nb
+    assert 0 < nb["bytes_to_root"] < nb["gatherv_raw_u32_positions"]["bytes_to_root"] and nb["devices"] == [0, 0]
 
 
 def test_bench_four_ranks_on_the_one_gpu():
@@ -915,6 +919,8 @@ def test_bench_four_ranks_on_the_one_gpu():
     assert st["digest_ok"] is True and len(st["per_rank"]) == 4 and st["kept_hits"] == st["n1"]["kept_hits"], st
     shares = [r["bases"] for r in st["per_rank"]]
     assert max(shares) - min(shares) <= 6 * 4096 * 2
+    nb = d["single_process_node"]
+    assert nb["digest_ok"] is True and nb["kept_hits"] == st["kept_hits"] and len(nb["per_rank"]) == 4, nb
     print("four ranks on one GPU: rendezvous %.2f-%.2f s, device HBM in use %.2f GiB; strong: scan %.3f ms + gatherv %.1f ms"
           % (min(r["rendezvous_s"] for r in d["per_rank"]), max(r["rendezvous_s"] for r in d["per_rank"]),
              max(r["device_hbm_in_use_GiB"] for r in d["per_rank"]), st["ms_scan_max_rank"], st["ms_gatherv"]))
