@@ -48,9 +48,6 @@ enum { GEO_LARGE = 0, GEO_SMALL = 1, GEO_COUNT = 2 };
 int tile_words(int geo);
 constexpr int ARENA_ALIGN_WORDS = 1024;       // arena planes are padded to this many words (a multiple of every geometry's tile)
 static_assert(ARENA_ALIGN_WORDS % GeoLarge::WORDS == 0 && ARENA_ALIGN_WORDS % GeoSmall::WORDS == 0, "tile geometry");
-#ifndef CRP_NT_STORES
-#define CRP_NT_STORES 1  // hit-table stores with the non-temporal hint: -1.5 % at steady clocks
-#endif
 struct Planes {
     const uint64_t *plane[4];  // hi, lo, up, ac
 };

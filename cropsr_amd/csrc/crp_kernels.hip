@@ -517,7 +517,7 @@ struct TileStores {
     __amdgpu_buffer_rsrc_t pos[2], score[2], pre[2], seed[2];
 };
 
-constexpr int STORE_AUX = CRP_NT_STORES ? 2 : 0;  // gfx950 cache policy bits of a buffer store: bit 1 = nt
+constexpr int STORE_AUX = 2;  // gfx950 cache policy bits of a buffer store: bit 1 = nt (hit-table stores are non-temporal: -1.5 % at steady clocks)
 typedef uint32_t u32x2 __attribute__((__vector_size__(2 * sizeof(uint32_t))));
 __device__ __forceinline__ u32x2 f64_words(double v)
 {

@@ -58,14 +58,24 @@ class _Stopped(Exception):
 
 def _die_with_parent(launcher_pid):
     """preexec_fn of a rank (between fork and exec, so before anything could touch a GPU): SIGTERM when the launcher dies --
-    and if it died between the fork and this call (the signal would never come), leave at once."""
+    and if it died between the fork and this call (the signal would never come), leave at once.  libc's prctl is looked up
+    HERE, in the parent: the forked child only calls it (a dlopen between fork and exec is not safe in a process that
+    may have threads -- ADVICE r04)."""
+    try:
+        prctl = ctypes.CDLL(None, use_errno=True).prctl
+    except Exception:  # not Linux: the signal handlers of spawn_ranks are all there is
+        prctl = None
+    sigterm = int(signal.SIGTERM)
+
     def arm():
+        if prctl is None:
+            return
         try:
-            ctypes.CDLL(None, use_errno=True).prctl(1, int(signal.SIGTERM), 0, 0, 0)  # PR_SET_PDEATHSIG
-        except Exception:  # not Linux: the handlers below are all there is
+            prctl(1, sigterm, 0, 0, 0)  # PR_SET_PDEATHSIG
+        except Exception:
             return
         if os.getppid() != launcher_pid:
-            os._exit(128 + int(signal.SIGTERM))
+            os._exit(128 + sigterm)
     return arm
 
 

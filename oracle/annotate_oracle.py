@@ -8,6 +8,8 @@ over every line of the GFF -- so that the product's sweep (csrc/crp_annotation.c
 alone, on the product's own interval tables: what the CPU tests' oracle backend uses in place of the GPU, and
 what the whole-genome digests of the GPU tests are compared with.
 """
+import re
+
 import numpy as np
 
 NO_FEATURE = 0xFFFFFFFF
@@ -19,14 +21,21 @@ def gff_rows(path):
             if line.startswith("#"):
                 continue
             c = line.rstrip("\n").split("\t")
-            if len(c) >= 9 and c[2] in ("gene", "CDS") and c[3].isdigit() and c[4].isdigit():  # rows with unreadable coordinates join nothing
+            if len(c) >= 9 and c[2] in ("gene", "CDS") and _DIGITS(c[3]) and _DIGITS(c[4]):  # rows with unreadable coordinates join nothing
                 yield c[0], c[2], int(c[3]), int(c[4]), c[8]
+
+
+# The definition is stated on ASCII: "stripped" removes blank, tab, newline, carriage return, vertical tab and form feed
+# (not str.strip()'s \x1c-\x1f or Unicode blanks), "digits" are 1 to 18 of 0-9 (not str.isdigit()'s Unicode digits) -- the
+# same as cropsr_amd/csrc/crp_annotation.cpp and tests/native/annotation_driver.cpp.
+_SPACE = " \t\n\r\v\f"
+_DIGITS = re.compile(r"[0-9]{1,18}").fullmatch
 
 
 def label(ftype, attrs, info=None):
     d = {}
     for part in attrs.split(";"):
-        k, _, v = part.strip().partition("=")
+        k, _, v = part.strip(_SPACE).partition("=")
         if k in ("ID", "Name", "Parent") and k not in d:
             d[k] = v
     ident = d.get("ID") or d.get("Name") or d.get("Parent") or "."

@@ -98,7 +98,8 @@ int main()
         std::map<std::string, std::pair<std::string, std::string>> info;
         const bool have_info = round % 3 == 0;
         if (round % 5 == 4) {  // soup: whatever bytes, the builder must survive and agree with the line-by-line definition
-            const char soup[] = "s\t\t\tgene\tCDS\t1\t20\t300\t;ID=Name=Parent=x y\n\n#\r.;=";
+            // (\x1c-\x1f and \v \f: bytes Python's str.strip() drops and the definition's ASCII strip keeps -- ADVICE r04)
+            const char soup[] = "s\t\t\tgene\tCDS\t1\t20\t300\t;ID=Name=Parent=x y\n\n#\r.;=\x1c\x1f\v\f";
             const size_t n = rng() % 600;
             for (size_t k = 0; k < n; ++k) gff += soup[rng() % (sizeof soup - 1)];
         } else {

@@ -7,7 +7,7 @@ run() { # tag lib geometry workload-args...
   tag=$1; lib=$2; g=$3; shift 3
   CROPSR_HIP_LIB=$lib python bench.py "$@" --geometry $g --steps 200 --warmup 20 --offtarget-steps 0 --cpu-sample-bases 0 > $out/$tag.json 2>> $out/err.log
 }
-for g in large medium small; do
+for g in large small; do
   run ecoli_$g "" $g --workload ecoli
   for s in 0.01 0.02 0.04 0.08; do run sg${s}_$g "" $g --scale $s; done
 done
