@@ -71,6 +71,10 @@ SIGNATURES = {
     "crp_node_load": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), u64p, ctypes.c_uint64]),
     "crp_node_plan": (ctypes.c_int, [ctypes.c_void_p, u64p, ctypes.c_uint64, u64p]),
     "crp_node_scan_score": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, u64p, u64p]),
+    "crp_node_offtarget": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, u64p]),
+    "crp_node_annotate": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, u64p, ctypes.c_int]),
+    "crp_node_fetch_offtarget": (ctypes.c_int, [ctypes.c_void_p, u32p, u32p]),
+    "crp_node_fetch_features": (ctypes.c_int, [ctypes.c_void_p, u32p, u32p]),
     "crp_node_gather": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]),
     "crp_node_counts": (ctypes.c_int, [ctypes.c_void_p, u64p, u64p, u64p]),
     "crp_node_count_scored": (ctypes.c_int, [ctypes.c_void_p, u64p]),

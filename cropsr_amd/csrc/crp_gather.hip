@@ -165,6 +165,18 @@ __global__ __launch_bounds__(BLOCK) void pos_rebase_kernel(const uint32_t *__res
     }
 }
 
+// dst[i] += src[i]: the site histograms of the node's devices summed at the root when RCCL cannot run (crp_node.cpp)
+__global__ __launch_bounds__(BLOCK) void add_u32_kernel(uint32_t *__restrict__ dst, const uint32_t *__restrict__ src, uint64_t n4)
+{
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < n4; i += (uint64_t)gridDim.x * BLOCK) {
+        u32x4 a = reinterpret_cast<u32x4 *>(dst)[i];
+        const u32x4 b = reinterpret_cast<const u32x4 *>(src)[i];
+        a += b;
+        reinterpret_cast<u32x4 *>(dst)[i] = a;
+    }
+}
+
 static inline uint32_t blocks_for(uint64_t n, uint64_t per_block) { return (uint32_t)((n + per_block - 1) / per_block); }
 
 hipError_t launch_lower_bound(hipStream_t s, const uint32_t *pos, uint64_t n, const uint32_t *needles, uint32_t n_needles,
@@ -205,6 +217,14 @@ hipError_t launch_pos_rebase(hipStream_t s, const uint32_t *pos, uint64_t n, con
 {
     if (!n) return hipSuccess;
     hipLaunchKernelGGL(pos_rebase_kernel, dim3(blocks_for(n, (uint64_t)BLOCK * G_ROWS)), dim3(BLOCK), 0, s, pos, n, map, out);
+    return hipGetLastError();
+}
+
+// n: a multiple of 4, both arrays 16-byte aligned (the 4^12-entry site histograms)
+hipError_t launch_add_u32(hipStream_t s, uint32_t *dst, const uint32_t *src, uint64_t n)
+{
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(add_u32_kernel, dim3(4096), dim3(BLOCK), 0, s, dst, src, n / 4);
     return hipGetLastError();
 }
 

@@ -179,6 +179,8 @@ hipError_t launch_pos16_pack(hipStream_t s, const uint32_t *pos, uint64_t n, uin
 hipError_t launch_pos16_expand(hipStream_t s, const uint16_t *lo16, uint64_t n, const uint32_t *bstart, uint32_t n_buckets,
                                const PieceMap &map, uint32_t *out);
 hipError_t launch_pos_rebase(hipStream_t s, const uint32_t *pos, uint64_t n, const PieceMap &map, uint32_t *out);
+hipError_t launch_add_u32(hipStream_t s, uint32_t *dst, const uint32_t *src, uint64_t n);  // dst += src (n: a multiple of 4)
+constexpr uint64_t OT_HIST_ENTRIES = 1ull << 24;  // 4^12 seeds (crp_offtarget.hip: OT_SEEDS)
 
 void comm_release(crp_ctx *ctx);  // crp_comm.cpp; called by crp_destroy
 void comm_forget_arena(crp_ctx *ctx, const crp_arena *a);

@@ -124,6 +124,10 @@ struct crp_node {
     uint32_t *d_fpos[2] = {nullptr, nullptr};
     double *d_fscore[2] = {nullptr, nullptr};
     uint64_t fpos_cap[2] = {0, 0}, fscore_cap[2] = {0, 0};
+    uint4 *d_fot[2] = {nullptr, nullptr};        // CRP_GATHER_OFFTARGET: per-hit off-target counts
+    uint32_t *d_ffeat[2] = {nullptr, nullptr};   // CRP_GATHER_FEATURES: per-hit label-set ids
+    uint64_t fot_cap[2] = {0, 0}, ffeat_cap[2] = {0, 0};
+    int gflags = 0;                              // flags of the last gather
     uint16_t *d_slo16[2] = {nullptr, nullptr};   // staging: the peers' packed positions, peer by peer (each at a multiple of 8)
     uint32_t *d_sbstart[2] = {nullptr, nullptr};  // and their bucket starts
     uint64_t slo16_cap[2] = {0, 0}, sbstart_cap[2] = {0, 0};
@@ -171,6 +175,11 @@ void free_root_side(crp_node *node)
         (void)hipFree(node->d_fscore[s]);
         (void)hipFree(node->d_slo16[s]);
         (void)hipFree(node->d_sbstart[s]);
+        (void)hipFree(node->d_fot[s]);
+        (void)hipFree(node->d_ffeat[s]);
+        node->d_fot[s] = nullptr;
+        node->d_ffeat[s] = nullptr;
+        node->fot_cap[s] = node->ffeat_cap[s] = 0;
         node->d_fpos[s] = nullptr;
         node->d_fscore[s] = nullptr;
         node->d_slo16[s] = nullptr;
@@ -274,6 +283,42 @@ bool ensure_comms(crp_node *node)
 }
 
 }  // namespace
+
+// One step on every device that holds an arena, each on a host thread of its own (the per-device calls of the C ABI
+// block on their stream); returns the first failure.
+template <class F>
+static int on_every_device(crp_node *node, const char *what, F step)
+{
+    const int world = (int)node->dev.size();
+    std::vector<int> rcs((size_t)world, CRP_OK);
+    std::vector<std::thread> pool((size_t)world);
+    auto guarded = [&](int k) {
+        try {
+            rcs[(size_t)k] = step(k);
+        } catch (...) {
+            rcs[(size_t)k] = CRP_ERR_NOMEM;
+        }
+    };
+    int first = -1;
+    for (int k = 0; k < world; ++k) {
+        if (!node->dev[(size_t)k].arena) continue;
+        if (first < 0) {
+            first = k;  // (this thread takes the first one itself, below)
+            continue;
+        }
+        try {
+            pool[(size_t)k] = std::thread(guarded, k);
+        } catch (...) {
+            guarded(k);
+        }
+    }
+    if (first >= 0) guarded(first);
+    for (auto &t : pool)
+        if (t.joinable()) t.join();
+    for (int k = 0; k < world; ++k)
+        if (rcs[(size_t)k] != CRP_OK) return dev_fail(node, k, rcs[(size_t)k], what);
+    return CRP_OK;
+}
 
 extern "C" {
 
@@ -497,14 +542,17 @@ int crp_node_scan_score(crp_node *node, int guide_len, int flags, uint64_t *n_pl
 int crp_node_gather(crp_node *node, int root, int flags)
 {
     crp::Range roctx_range("crp: node gatherv");
-    if (!node || root < 0 || (size_t)root >= node->dev.size() || (flags & ~(CRP_GATHER_PRE | CRP_GATHER_POS16 | CRP_NODE_PEER_COPY)))
+    if (!node || root < 0 || (size_t)root >= node->dev.size() ||
+        (flags & ~(CRP_GATHER_PRE | CRP_GATHER_POS16 | CRP_NODE_PEER_COPY | CRP_GATHER_OFFTARGET | CRP_GATHER_FEATURES)))
         return CRP_ERR_INVALID;
     if (!node->loaded) return CRP_ERR_STATE;
     const bool send_pre = (flags & CRP_GATHER_PRE) != 0, pos16 = (flags & CRP_GATHER_POS16) != 0;
+    const bool with_ot = (flags & CRP_GATHER_OFFTARGET) != 0, with_feat = (flags & CRP_GATHER_FEATURES) != 0;
     const int world = (int)node->dev.size();
     for (int k = 0; k < world; ++k) {
         const crp_arena *a = node->dev[(size_t)k].arena;
-        if (a && (!a->have_hits || (send_pre && !a->have_pre))) {
+        if (a && (!a->have_hits || (send_pre && !a->have_pre) || (with_feat && !a->have_feat) ||
+                  (with_ot && (!a->ctx->ot_solved || a->ot_epoch != a->ctx->ot_epoch || !a->d_ot_cnt[0])))) {
             node->last_error = "crp_node_gather: logical device " + std::to_string(k) + " has no (matching) tables: scan first";
             return CRP_ERR_STATE;
         }
@@ -585,6 +633,8 @@ int crp_node_gather(crp_node *node, int root, int flags)
         }
         int rc = crp::grow(rctx, reinterpret_cast<void **>(&node->d_fpos[s]), &node->fpos_cap[s], total[s], sizeof(uint32_t));
         if (rc == CRP_OK) rc = crp::grow(rctx, reinterpret_cast<void **>(&node->d_fscore[s]), &node->fscore_cap[s], total[s], sizeof(double));
+        if (rc == CRP_OK && with_ot) rc = crp::grow(rctx, reinterpret_cast<void **>(&node->d_fot[s]), &node->fot_cap[s], total[s], sizeof(uint4));
+        if (rc == CRP_OK && with_feat) rc = crp::grow(rctx, reinterpret_cast<void **>(&node->d_ffeat[s]), &node->ffeat_cap[s], total[s], sizeof(uint32_t));
         if (rc == CRP_OK && lo_total) rc = crp::grow(rctx, reinterpret_cast<void **>(&node->d_slo16[s]), &node->slo16_cap[s], lo_total, sizeof(uint16_t));
         if (rc == CRP_OK && b_total) rc = crp::grow(rctx, reinterpret_cast<void **>(&node->d_sbstart[s]), &node->sbstart_cap[s], b_total, sizeof(uint32_t));
         if (rc != CRP_OK) return dev_fail(node, root, rc, "crp_node_gather (root's tables)");
@@ -660,12 +710,12 @@ int crp_node_gather(crp_node *node, int root, int flags)
         for (int s = 0; s < 2 && st == ncclSuccess; ++s) {
             const uint64_t n = d.last[s] - d.first[s];
             if (!n) continue;
-            // three columns at most: packed positions + bucket starts (or raw positions), and the f64 column
+            // packed positions + bucket starts (or raw positions), the f64 column, and the two optional ones
             struct Col {
                 const void *src;
                 void *dst;
                 uint64_t bytes;
-            } cols[3];
+            } cols[5];
             int nc = 0;
             if (pos16) {
                 cols[nc++] = Col{d.d_lo16[s], node->d_slo16[s] + soff[s][(size_t)k], n * sizeof(uint16_t)};
@@ -674,6 +724,8 @@ int crp_node_gather(crp_node *node, int root, int flags)
                 cols[nc++] = Col{d.arena->d_pos[s] + d.first[s], node->d_fpos[s] + d.foff[s], n * sizeof(uint32_t)};
             }
             cols[nc++] = Col{(send_pre ? d.arena->d_pre[s] : d.arena->d_score[s]) + d.first[s], node->d_fscore[s] + d.foff[s], n * sizeof(double)};
+            if (with_ot) cols[nc++] = Col{d.arena->d_ot_cnt[s] + d.first[s], node->d_fot[s] + d.foff[s], n * sizeof(uint4)};
+            if (with_feat) cols[nc++] = Col{d.arena->d_feat[s] + d.first[s], node->d_ffeat[s] + d.foff[s], n * sizeof(uint32_t)};
             for (int c = 0; c < nc && st == ncclSuccess; ++c) {
                 moved += cols[c].bytes;
                 if (r) {
@@ -712,6 +764,12 @@ int crp_node_gather(crp_node *node, int root, int flags)
                 NODE_HIP(node, crp::launch_pos_rebase(rctx->stream, d.arena->d_pos[s] + d.first[s], n, map_of(k), out));
                 NODE_HIP(node, hipMemcpyAsync(node->d_fscore[s] + d.foff[s], (send_pre ? d.arena->d_pre[s] : d.arena->d_score[s]) + d.first[s],
                                               n * sizeof(double), hipMemcpyDeviceToDevice, rctx->stream));
+                if (with_ot)
+                    NODE_HIP(node, hipMemcpyAsync(node->d_fot[s] + d.foff[s], d.arena->d_ot_cnt[s] + d.first[s], n * sizeof(uint4),
+                                                  hipMemcpyDeviceToDevice, rctx->stream));
+                if (with_feat)
+                    NODE_HIP(node, hipMemcpyAsync(node->d_ffeat[s] + d.foff[s], d.arena->d_feat[s] + d.first[s], n * sizeof(uint32_t),
+                                                  hipMemcpyDeviceToDevice, rctx->stream));
             } else if (pos16) {
                 NODE_HIP(node, crp::launch_pos16_expand(rctx->stream, node->d_slo16[s] + soff[s][(size_t)k], n,
                                                         node->d_sbstart[s] + boff[s][(size_t)k], d.n_buckets, map_of(k), out));
@@ -733,7 +791,169 @@ int crp_node_gather(crp_node *node, int root, int flags)
     node->transport = r ? CRP_TRANSPORT_RCCL : (world == 1 ? 0 : CRP_TRANSPORT_PEER_COPY);
     node->total[0] = total[0];
     node->total[1] = total[1];
+    node->gflags = flags;
     node->have_gather = true;
+    return CRP_OK;
+}
+
+int crp_node_offtarget(crp_node *node, int guide_len, uint64_t *n_sites)
+{
+    crp::Range roctx_range("crp: node off-target seed scan");
+    if (!node) return CRP_ERR_INVALID;
+    if (!node->loaded) return CRP_ERR_STATE;
+    const int world = (int)node->dev.size();
+    for (int k = 0; k < world; ++k)
+        if (node->dev[(size_t)k].arena && !node->dev[(size_t)k].arena->have_hits) {
+            node->last_error = "crp_node_offtarget: scan first";
+            return CRP_ERR_STATE;
+        }
+    node->have_gather = false;
+    // 1. every device: its own sites into its own histogram -- a hit counts as a site on the device that OWNS it only
+    std::vector<uint64_t> sites((size_t)world, 0);
+    for (int k = 0; k < world; ++k) {  // (every device of the node takes part in the sum, with or without an arena)
+        const int rc = crp_offtarget_reset(node->dev[(size_t)k].ctx);
+        if (rc != CRP_OK) return dev_fail(node, k, rc, "crp_node_offtarget (reset)");
+    }
+    int rc = on_every_device(node, "crp_node_offtarget (sites)", [&](int k) {
+        NodeDev &d = node->dev[(size_t)k];
+        std::vector<uint64_t> own(2 * d.pieces.size());
+        for (size_t j = 0; j < d.pieces.size(); ++j) {
+            const NodePiece &p = node->pieces[d.pieces[j]];
+            own[2 * j] = p.arena_off + (p.start - p.text_lo);
+            own[2 * j + 1] = own[2 * j] + (p.end - p.start);
+        }
+        return crp_offtarget_add(d.arena, guide_len, own.data(), d.pieces.size(), &sites[(size_t)k]);
+    });
+    if (rc != CRP_OK) return rc;
+    // 2. the histograms summed over the devices: RCCL all-reduce in one group, or through the first device
+    if (world > 1) {
+        bool peer_copy = node->duplicates || node->transport_env == CRP_TRANSPORT_PEER_COPY;
+        if (!peer_copy && !ensure_comms(node)) {
+            if (node->transport_env == CRP_TRANSPORT_RCCL) {
+                node->last_error = "crp_node_offtarget: RCCL asked for (CRP_NODE_TRANSPORT=rccl) but unavailable: " + node->comms_error;
+                return CRP_ERR_COMM;
+            }
+            peer_copy = true;
+        }
+        if (!peer_copy) {
+            const crp::Rccl *r = crp::rccl();
+            ncclResult_t st = r->GroupStart();
+            for (int k = 0; k < world && st == ncclSuccess; ++k) {
+                crp_ctx *ctx = node->dev[(size_t)k].ctx;
+                st = r->AllReduce(ctx->d_ot_hist, ctx->d_ot_hist, crp::OT_HIST_ENTRIES, ncclUint32, ncclSum, node->comms[(size_t)k], ctx->stream);
+            }
+            const ncclResult_t st_end = r->GroupEnd();
+            if (st != ncclSuccess || st_end != ncclSuccess) {
+                node->last_error = std::string("crp_node_offtarget all-reduce: ") + r->GetErrorString(st != ncclSuccess ? st : st_end);
+                return CRP_ERR_COMM;
+            }
+            for (int k = 0; k < world; ++k) {
+                const int rk = crp_synchronize(node->dev[(size_t)k].ctx);
+                if (rk != CRP_OK) return dev_fail(node, k, rk, "crp_node_offtarget (all-reduce)");
+            }
+        } else {
+            // device 0 collects: every other histogram is copied beside its own and added, then the sum goes back
+            NodeDev &R = node->dev[0];
+            crp_ctx *rctx = R.ctx;
+            NODE_HIP(node, hipSetDevice(R.device));
+            uint32_t *tmp = nullptr;  // (64 MiB of scratch for the length of this call)
+            NODE_HIP(node, hipMalloc(reinterpret_cast<void **>(&tmp), crp::OT_HIST_ENTRIES * sizeof(uint32_t)));
+            const size_t bytes = crp::OT_HIST_ENTRIES * sizeof(uint32_t);
+            hipError_t e = hipSuccess;
+            for (int k = 1; k < world && e == hipSuccess; ++k) {
+                NodeDev &d = node->dev[(size_t)k];
+                e = d.device == R.device ? hipMemcpyAsync(tmp, d.ctx->d_ot_hist, bytes, hipMemcpyDeviceToDevice, rctx->stream)
+                                         : hipMemcpyPeerAsync(tmp, R.device, d.ctx->d_ot_hist, d.device, bytes, rctx->stream);
+                if (e == hipSuccess) e = crp::launch_add_u32(rctx->stream, rctx->d_ot_hist, tmp, crp::OT_HIST_ENTRIES);
+            }
+            for (int k = 1; k < world && e == hipSuccess; ++k) {
+                NodeDev &d = node->dev[(size_t)k];
+                e = d.device == R.device ? hipMemcpyAsync(d.ctx->d_ot_hist, rctx->d_ot_hist, bytes, hipMemcpyDeviceToDevice, rctx->stream)
+                                         : hipMemcpyPeerAsync(d.ctx->d_ot_hist, d.device, rctx->d_ot_hist, R.device, bytes, rctx->stream);
+            }
+            if (e == hipSuccess) e = hipStreamSynchronize(rctx->stream);
+            (void)hipFree(tmp);
+            if (e != hipSuccess) {
+                node->last_error = std::string("crp_node_offtarget (histogram sum): ") + hipGetErrorString(e);
+                return CRP_ERR_HIP;
+            }
+        }
+    }
+    // 3. every device: the Hamming-ball sums of the genome-wide histogram, then its own hits' counts (they stay in HBM)
+    rc = on_every_device(node, "crp_node_offtarget (solve + counts)", [&](int k) {
+        NodeDev &d = node->dev[(size_t)k];
+        int r2 = crp_offtarget_solve(d.ctx);
+        if (r2 == CRP_OK) r2 = crp_offtarget_counts(d.arena, nullptr, nullptr);
+        return r2;
+    });
+    if (rc != CRP_OK) return rc;
+    if (n_sites) {
+        *n_sites = 0;
+        for (uint64_t v : sites) *n_sites += v;
+    }
+    return CRP_OK;
+}
+
+int crp_node_annotate(crp_node *node, const crp_annotation *annotation, const uint64_t *seqid_of_contig, int dec)
+{
+    crp::Range roctx_range("crp: node annotation join");
+    if (!node || !annotation || (node->n_contigs && !seqid_of_contig) || dec < 0) return CRP_ERR_INVALID;
+    if (!node->loaded) return CRP_ERR_STATE;
+    for (const NodeDev &d : node->dev)
+        if (d.arena && !d.arena->have_hits) {
+            node->last_error = "crp_node_annotate: scan first";
+            return CRP_ERR_STATE;
+        }
+    node->have_gather = false;
+    return on_every_device(node, "crp_node_annotate", [&](int k) {
+        NodeDev &d = node->dev[(size_t)k];
+        // the track of THIS device's arena: every text is a piece of a contig (with its halo), named by the contig's seqid
+        std::vector<uint64_t> entries(4 * d.pieces.size());
+        for (size_t j = 0; j < d.pieces.size(); ++j) {
+            const NodePiece &p = node->pieces[d.pieces[j]];
+            const uint64_t e[4] = {seqid_of_contig[p.contig], p.text_lo, p.text_len, p.arena_off};
+            std::memcpy(&entries[4 * j], e, sizeof e);
+        }
+        uint64_t n = 0;
+        int rc = crp_annotation_track(annotation, entries.data(), d.pieces.size(), dec, nullptr, nullptr, 0, &n);
+        if (rc != CRP_OK && rc != CRP_ERR_CAPACITY) return rc;
+        std::vector<uint32_t> points(n), ids(n);
+        rc = crp_annotation_track(annotation, entries.data(), d.pieces.size(), dec, points.data(), ids.data(), n, &n);
+        if (rc == CRP_OK) rc = crp_annotate_set_track(d.arena, points.data(), ids.data(), n);
+        if (rc == CRP_OK) rc = crp_annotate_lookup(d.arena, nullptr, nullptr);
+        return rc;
+    });
+}
+
+int crp_node_fetch_offtarget(crp_node *node, uint32_t *ot_plus, uint32_t *ot_minus)
+{
+    if (!node) return CRP_ERR_INVALID;
+    if (!node->have_gather || !(node->gflags & CRP_GATHER_OFFTARGET)) return CRP_ERR_STATE;
+    crp_ctx *ctx = node->dev[(size_t)node->root].ctx;
+    NODE_HIP(node, hipSetDevice(ctx->device));
+    uint32_t *h[2] = {ot_plus, ot_minus};
+    for (int s = 0; s < 2; ++s)
+        if (h[s] && node->total[s]) {
+            const int rc = crp::staged_d2h(ctx, h[s], node->d_fot[s], node->total[s] * sizeof(uint4));
+            if (rc != CRP_OK) return dev_fail(node, node->root, rc, "crp_node_fetch_offtarget");
+        }
+    NODE_HIP(node, hipStreamSynchronize(ctx->stream));
+    return CRP_OK;
+}
+
+int crp_node_fetch_features(crp_node *node, uint32_t *feat_plus, uint32_t *feat_minus)
+{
+    if (!node) return CRP_ERR_INVALID;
+    if (!node->have_gather || !(node->gflags & CRP_GATHER_FEATURES)) return CRP_ERR_STATE;
+    crp_ctx *ctx = node->dev[(size_t)node->root].ctx;
+    NODE_HIP(node, hipSetDevice(ctx->device));
+    uint32_t *h[2] = {feat_plus, feat_minus};
+    for (int s = 0; s < 2; ++s)
+        if (h[s] && node->total[s]) {
+            const int rc = crp::staged_d2h(ctx, h[s], node->d_ffeat[s], node->total[s] * sizeof(uint32_t));
+            if (rc != CRP_OK) return dev_fail(node, node->root, rc, "crp_node_fetch_features");
+        }
+    NODE_HIP(node, hipStreamSynchronize(ctx->stream));
     return CRP_OK;
 }
 

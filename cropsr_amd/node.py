@@ -46,6 +46,8 @@ class NodeHits:
     def __init__(self, per_contig, cols, guide_len):
         self.guide_len = guide_len
         self.pos_plus, self.score_plus, self.pos_minus, self.score_minus = cols
+        self.ot_plus = self.ot_minus = None      # (n, 4) uint32 after a gather with offtarget=True
+        self.feat_plus = self.feat_minus = None  # uint32 label-set ids after a gather with features=True
         counts = np.asarray(per_contig, dtype=np.int64).reshape(-1, 2)
         self._cut_plus = np.concatenate(([0], np.cumsum(counts[:, 0])))
         self._cut_minus = np.concatenate(([0], np.cumsum(counts[:, 1])))
@@ -62,8 +64,13 @@ class NodeHits:
     def contig(self, k):
         a, b = int(self._cut_plus[k]), int(self._cut_plus[k + 1])
         c, d = int(self._cut_minus[k]), int(self._cut_minus[k + 1])
-        return dict(pos_plus=self.pos_plus[a:b], score_plus=self.score_plus[a:b],
-                    pos_minus=self.pos_minus[c:d], score_minus=self.score_minus[c:d])
+        out = dict(pos_plus=self.pos_plus[a:b], score_plus=self.score_plus[a:b],
+                   pos_minus=self.pos_minus[c:d], score_minus=self.score_minus[c:d])
+        if self.ot_plus is not None:
+            out["ot_plus"], out["ot_minus"] = self.ot_plus[a:b], self.ot_minus[c:d]
+        if self.feat_plus is not None:
+            out["feat_plus"], out["feat_minus"] = self.feat_plus[a:b], self.feat_minus[c:d]
+        return out
 
 
 class Node:
@@ -172,19 +179,41 @@ class Node:
         return dict(n_texts=int(nc.value), n_chars=int(nch.value), n_tiles=int(nt.value), geometry=name)
 
     # ---- seam 1 + 2 on every device at once
-    def scan_score_device(self, guide_len=20, want_pre=False):
+    def scan_score_device(self, guide_len=20, want_pre=False, want_seeds=False):
         """crp_node_scan_score: the scan queued on every device, then collected; tables stay in HBM.  Returns the rows
-        of all devices' tables together (including the few hits inside halos)."""
+        of all devices' tables together (including the few hits inside halos).  want_seeds: the scan also writes the
+        seed words the off-target step works on (CRP_SCAN_SEEDS)."""
         a, b = ctypes.c_uint64(), ctypes.c_uint64()
-        self._check(nat.lib().crp_node_scan_score(self._h, int(guide_len), nat.SCAN_PRE if want_pre else 0,
-                                                  ctypes.byref(a), ctypes.byref(b)), "crp_node_scan_score")
+        flags = (nat.SCAN_PRE if want_pre else 0) | (nat.SCAN_SEEDS if want_seeds else 0)
+        self._check(nat.lib().crp_node_scan_score(self._h, int(guide_len), flags, ctypes.byref(a), ctypes.byref(b)),
+                    "crp_node_scan_score")
         return a.value, b.value
 
-    def gather(self, root=0, pre=False, pos16=True, peer_copy=False):
+    def offtarget(self, guide_len=20):
+        """crp_node_offtarget: the genome-wide off-target seed scan over the node's resident tables (every device its own
+        sites, histograms summed over the devices, every device its own hits' counts).  Returns the number of sites."""
+        n = ctypes.c_uint64()
+        self._check(nat.lib().crp_node_offtarget(self._h, int(guide_len), ctypes.byref(n)), "crp_node_offtarget")
+        return n.value
+
+    def annotate(self, request):
+        """crp_node_annotate: the annotation join on every device (annotate.Request for the load()ed contigs)."""
+        ann = request.annotation
+        none = 0xFFFFFFFFFFFFFFFF
+        seqids = np.array([ann.seq_index.get(name, none) for name in request.names], dtype=np.uint64)
+        if seqids.size != self.n_contigs:
+            raise ValueError("the request names %d contigs, the node holds %d" % (seqids.size, self.n_contigs))
+        self._check(nat.lib().crp_node_annotate(self._h, ann._h, seqids.ctypes.data_as(nat.u64p), int(request.dec)),
+                    "crp_node_annotate")
+
+    def gather(self, root=0, pre=False, pos16=True, peer_copy=False, offtarget=False, features=False):
         """crp_node_gather: every device's owned rows to logical device `root` (one table per strand, contig order,
-        contig-local positions).  Returns dict(ms_total, ms_exchange, bytes_to_root, transport)."""
-        flags = (nat.GATHER_PRE if pre else 0) | (nat.GATHER_POS16 if pos16 else 0) | (nat.NODE_PEER_COPY if peer_copy else 0)
+        contig-local positions); offtarget / features: the columns of offtarget() / annotate() travel too.  Returns
+        dict(ms_total, ms_exchange, bytes_to_root, transport)."""
+        flags = ((nat.GATHER_PRE if pre else 0) | (nat.GATHER_POS16 if pos16 else 0) | (nat.NODE_PEER_COPY if peer_copy else 0) |
+                 (nat.GATHER_OFFTARGET if offtarget else 0) | (nat.GATHER_FEATURES if features else 0))
         self._check(nat.lib().crp_node_gather(self._h, int(root), flags), "crp_node_gather")
+        self._gathered = (bool(offtarget), bool(features))
         return self.gather_stats()
 
     def gather_stats(self):
@@ -233,10 +262,25 @@ class Node:
         cols = [np.empty(n_plus, np.uint32), np.empty(n_plus, np.float64), np.empty(n_minus, np.uint32), np.empty(n_minus, np.float64)]
         self._check(nat.lib().crp_node_fetch(self._h, cols[0].ctypes.data_as(nat.u32p), cols[1].ctypes.data_as(nat.f64p),
                                              cols[2].ctypes.data_as(nat.u32p), cols[3].ctypes.data_as(nat.f64p)), "crp_node_fetch")
-        return NodeHits(per, cols, guide_len)
+        hits = NodeHits(per, cols, guide_len)
+        with_ot, with_feat = getattr(self, "_gathered", (False, False))
+        if with_ot:
+            hits.ot_plus, hits.ot_minus = np.empty((n_plus, 4), np.uint32), np.empty((n_minus, 4), np.uint32)
+            self._check(nat.lib().crp_node_fetch_offtarget(self._h, hits.ot_plus.ctypes.data_as(nat.u32p),
+                                                           hits.ot_minus.ctypes.data_as(nat.u32p)), "crp_node_fetch_offtarget")
+        if with_feat:
+            hits.feat_plus, hits.feat_minus = np.empty(n_plus, np.uint32), np.empty(n_minus, np.uint32)
+            self._check(nat.lib().crp_node_fetch_features(self._h, hits.feat_plus.ctypes.data_as(nat.u32p),
+                                                          hits.feat_minus.ctypes.data_as(nat.u32p)), "crp_node_fetch_features")
+        return hits
 
-    def scan(self, guide_len=20, root=0, pre=False, pos16=True, peer_copy=False):
-        """load()ed genome -> NodeHits: scan on every device, gatherv to `root`, tables to the host."""
-        self.scan_score_device(guide_len, want_pre=pre)
-        self.gather(root, pre=pre, pos16=pos16, peer_copy=peer_copy)
+    def scan(self, guide_len=20, root=0, pre=False, pos16=True, peer_copy=False, offtarget=False, annotation=None):
+        """load()ed genome -> NodeHits: scan on every device (+ the opt-in off-target scan and annotation join over the
+        resident tables), gatherv to `root`, tables to the host."""
+        self.scan_score_device(guide_len, want_pre=pre, want_seeds=offtarget)
+        if offtarget:
+            self.offtarget(guide_len)
+        if annotation is not None:
+            self.annotate(annotation)
+        self.gather(root, pre=pre, pos16=pos16, peer_copy=peer_copy, offtarget=offtarget, features=annotation is not None)
         return self.fetch(guide_len)

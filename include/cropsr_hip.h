@@ -333,8 +333,22 @@ int crp_node_plan(const crp_node *node, uint64_t *pieces, uint64_t cap, uint64_t
  * devices' tables together, INCLUDING the few hits inside halos (at most 2 x CRP_HALO positions per device); the
  * exact totals come from crp_node_gather. */
 int crp_node_scan_score(crp_node *node, int guide_len, int flags, uint64_t *n_plus, uint64_t *n_minus);
+/* The two opt-in steps over the node's resident tables, between crp_node_scan_score and crp_node_gather:
+ *   crp_node_offtarget   the genome-wide off-target seed scan (see crp_offtarget_* below): every device adds the sites it
+ *                        OWNS to its histogram (scan with CRP_SCAN_SEEDS to hand the seed words over), the histograms
+ *                        are summed over the devices (RCCL all-reduce in one group; through device 0 when RCCL cannot
+ *                        run), every device solves and looks up its own hits.  *n_sites (may be NULL): sites in all.
+ *   crp_node_annotate    the annotation join (see crp_annotate_* below) on every device with the track of ITS pieces:
+ *                        seqid_of_contig[k] = index of contig k's FASTA name among the annotation's seqids
+ *                        (crp_annotation_seqid order; any value >= their number: no features), dec as in
+ *                        crp_annotation_track.
+ * The counts / ids stay in HBM and travel with crp_node_gather (CRP_GATHER_OFFTARGET / CRP_GATHER_FEATURES). */
+struct crp_annotation;
+int crp_node_offtarget(crp_node *node, int guide_len, uint64_t *n_sites);
+int crp_node_annotate(crp_node *node, const struct crp_annotation *annotation, const uint64_t *seqid_of_contig, int dec);
 /* The gatherv: every device's OWNED rows to logical device `root`.  flags: CRP_GATHER_PRE (the f64 column is the
- * pre-sigmoid sum), CRP_GATHER_POS16 (10 B per hit on the links instead of 12, see above),
+ * pre-sigmoid sum), CRP_GATHER_POS16 (10 B per hit on the links instead of 12, see above), CRP_GATHER_OFFTARGET /
+ * CRP_GATHER_FEATURES (the columns of the two steps above travel too),
  * CRP_NODE_PEER_COPY (device-to-device copies instead of RCCL for this call; always the case when a device is
  * listed twice, or when the environment says CRP_NODE_TRANSPORT=peer). */
 #define CRP_NODE_PEER_COPY 16
@@ -349,6 +363,10 @@ int crp_node_count_scored(crp_node *node, uint64_t *n_scored);
  * crp_node_gather / crp_node_load). */
 int crp_node_fetch(crp_node *node, uint32_t *pos_plus, double *score_plus, uint32_t *pos_minus, double *score_minus);
 int crp_node_tables_device(crp_node *node, void **pos_plus, void **score_plus, void **pos_minus, void **score_minus);
+/* After a gather with CRP_GATHER_OFFTARGET / CRP_GATHER_FEATURES: the off-target counts (4 x uint32 per row) and the
+ * label-set ids (uint32 per row) of the same rows, same order.  Either pointer may be NULL. */
+int crp_node_fetch_offtarget(crp_node *node, uint32_t *ot_plus, uint32_t *ot_minus);
+int crp_node_fetch_features(crp_node *node, uint32_t *feat_plus, uint32_t *feat_minus);
 /* The last crp_node_gather in numbers: wall time of the whole call and of its exchange step alone (ms), bytes that
  * crossed from peers to the root, transport used (1 RCCL, 2 device-to-device copies).  Any pointer may be NULL. */
 #define CRP_TRANSPORT_RCCL 1

@@ -351,3 +351,61 @@ def test_bench_real_fasta_and_bytes_per_survey_8d(tmp_path):
     assert n == 4641652 + 4 and r["characters"]["other"] == 4
     assert r["algorithmic_bytes_per_launch"] == (n + 3) // 4 + 12 * h and "12*H" in r["algorithmic_bytes"] and "2*ceil" not in r["algorithmic_bytes"]
     assert "three_launch" in r and r["all_kernels_ms"] == r["kernel_ms"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [1, 3, 4])
+def test_node_offtarget_and_annotation_vs_oracle(oracle, world, tmp_path):
+    """The two opt-in steps through the node handle (crp_node_offtarget, crp_node_annotate): every device adds the sites it
+    OWNS (a hit inside a halo is its neighbour's), the site histograms are summed over the devices, every device joins its
+    own pieces with the track of THOSE pieces; counts and label-set ids travel with the gatherv.  Per contig: the same
+    counts as the oracle's genome-wide enumeration and the same ids as the oracle's numpy join -- whatever the cut."""
+    from cropsr_amd import annotate, node as nd
+    from oracle import annotate_oracle
+    rng = np.random.default_rng(500 + world)
+    lengths = [300_000, 5, 70_000, 123_457, 40_000]
+    contigs = _genome(rng, lengths)
+    # repeats across the cuts: the same 40 kb block in three contigs, so seeds recur on several devices
+    block = rng.choice(ALPHA, 40_000).tobytes()
+    contigs[0] = contigs[0][:100_000] + block + contigs[0][140_000:]
+    contigs[3] = contigs[3][:60_000] + block + contigs[3][100_000:]
+    contigs[4] = b"'" + block + b"')]"
+    gff = tmp_path / "node.gff"
+    rows = ["##gff-version 3"]
+    for k, n in enumerate(lengths):
+        for g in range(max(1, n // 20_000)):
+            a = 1 + g * 20_000 + int(rng.integers(0, 5_000))
+            b = min(n, a + int(rng.integers(300, 12_000)))
+            if b > a:
+                rows.append("c%d\tsrc\tgene\t%d\t%d\t.\t+\t.\tID=g%d_%d" % (k, a, b, k, g))
+                rows.append("c%d\tsrc\tCDS\t%d\t%d\t.\t+\t0\tID=g%d_%d.cds" % (k, a + 10, max(a + 11, b - 10), k, g))
+    gff.write_text("\n".join(rows) + "\n")
+    ann = annotate.Annotation(str(gff))
+    req = annotate.Request(ann, ["c%d" % k for k in range(len(contigs))], 1)
+    want_ot = oracle.offtarget_genome(contigs, 20)
+    with nd.Node([0] * world) as node:
+        node.load(contigs)
+        for kw in ({}, {"pos16": False, "root": world - 1}):
+            hits = node.scan(20, offtarget=True, annotation=req, **kw)
+            n_feat = 0
+            for k, c in enumerate(contigs):
+                got = hits.contig(k)
+                want = oracle.scan_score(c, 20)
+                for key in ("pos_plus", "score_plus", "pos_minus", "score_minus"):
+                    assert (bits(got[key]) == bits(want[key])).all(), (world, k, key)
+                assert (got["ot_plus"] == want_ot[k]["ot_plus"]).all() and (got["ot_minus"] == want_ot[k]["ot_minus"]).all(), (world, k)
+                fp, fm = annotate_oracle.host_join(ann, "c%d" % k, 0, 1, got, 20, len(c))
+                assert (got["feat_plus"] == fp).all() and (got["feat_minus"] == fm).all(), (world, k)
+                n_feat += int((fp != annotate.NO_FEATURE).sum() + (fm != annotate.NO_FEATURE).sum())
+            assert n_feat > 5_000
+        # the seeds may also come from the planes (no CRP_SCAN_SEEDS): same counts
+        node.scan_score_device(20)
+        sites = node.offtarget(20)
+        node.gather(0, offtarget=True)
+        again = node.fetch()
+        assert sites > 20_000 and (again.ot_plus == hits.ot_plus).all() and (again.ot_minus == hits.ot_minus).all()
+        # a gather that asks for columns nobody computed is refused
+        node.scan_score_device(20)
+        with pytest.raises(Exception):
+            node.gather(0, features=True)
+    ann.close()
