@@ -64,6 +64,10 @@ def build_parser():
                      help="run on this many GPUs of the node, one process per GPU: contigs (cut where longer than a "
                           "GPU's share) are scanned in parallel and the hit tables gathered to the first one over RCCL; "
                           "the ranks are started here unless a launcher (torch.distributed.run) already did")
+    eng.add_argument("--devices", default=None, metavar="LIST",
+                     help="run on these HIP devices from THIS one process, e.g. 0,1,2,3: the genome is cut into equal "
+                          "contiguous shares, every device scans its own and the hit tables are gathered to the first one "
+                          "(RCCL) -- all inside the library (its node handle); no launcher, no ranks.  Same CSV bytes")
     eng.add_argument("--seed", type=int, default=None,
                      help="seed numpy's global RNG so crispr_id is reproducible (reference: unseeded)")
     eng.add_argument("--csv-writer", choices=["native", "python"], default="native",
@@ -271,6 +275,55 @@ class EngineBackend:
         self.engine.close()
 
 
+class NodeBackend:
+    """The same hit provider over SEVERAL MI355X in ONE process: the library's node handle (crp_node_*, node.Node).  The cut
+    of the genome into contiguous equal shares, the uploads, the scans on every device, the opt-in off-target scan and
+    annotation join and the gatherv to the first device all happen inside libcropsr_hip.so; this class only calls them.
+    What scan() returns is what EngineBackend.scan() returns on one GPU, bit for bit."""
+
+    def __init__(self, devices, finalize="gpu"):
+        from .node import Node
+        self.node = Node(devices)
+        self.finalize = finalize
+        self.last_annotate_s = None
+        self.last_gather = None  # node.gather_stats() of the last scan (--bench-json)
+        self._engine = None      # seam 2 on a few rows (rescore): a context of its own on the first device, opened when needed
+        self._devices = list(devices)
+
+    def scan(self, contig_strings, guide_len, offtarget=False, annotation=None):
+        want_pre = self.finalize == "host"
+        node = self.node
+        node.load(contig_strings)
+        node.scan_score_device(guide_len, want_pre=want_pre, want_seeds=offtarget)
+        if offtarget:
+            node.offtarget(guide_len)
+        if annotation is not None:
+            t0 = time.perf_counter()
+            node.annotate(annotation)
+            self.last_annotate_s = time.perf_counter() - t0
+        self.last_gather = node.gather(0, pre=want_pre, offtarget=offtarget, features=annotation is not None)
+        hits = node.fetch(guide_len)
+        out = []
+        for k in range(len(contig_strings)):
+            h = hits.contig(k)
+            if want_pre:  # the f64 column that travelled is the pre-sigmoid sum: CROPSR.py:313 on this host's numpy
+                h["score_plus"], h["score_minus"] = host_sigmoid(h["score_plus"]), host_sigmoid(h["score_minus"])
+            out.append(h)
+        return out
+
+    def rescore(self, rows_u8, order):
+        if self._engine is None:
+            from .engine import Engine
+            self._engine = Engine(self._devices[0])
+        pre, score = self._engine.score_30mers(rows_u8, order)
+        return host_sigmoid(pre) if self.finalize == "host" else score
+
+    def close(self):
+        if self._engine is not None:
+            self._engine.close()
+        self.node.close()
+
+
 def host_sigmoid(pre):
     """`1/(1+np.exp(score))` of CROPSR.py:313 -- the reference's own expression, evaluated by the numpy
     of the host this runs on (so its last bit is this host's, like the reference's)."""
@@ -376,6 +429,8 @@ def run(args, backend=None, out=sys.stdout, group=None):
     max_piece = int(os.environ.get("CROPSR_DIST_MAX_PIECE", "0")) or None
 
     def make_backend():
+        if getattr(args, "devices", None):
+            return NodeBackend([int(d) for d in str(args.devices).split(",")], finalize)
         device = getattr(args, "device", None)
         if device is None:
             device = group.local_rank if group is not None else 0
@@ -589,6 +644,9 @@ def run(args, backend=None, out=sys.stdout, group=None):
     timing.close()
     if ids is not None:
         ids.close()
+    if getattr(backend, "last_gather", None):  # one process over several devices (--devices): the node's gatherv, in numbers
+        stages["node_gatherv"] = backend.last_gather
+        stages["devices"] = list(backend.node.devices)
     if own_backend:
         backend.close()
     if verbose:
@@ -617,6 +675,9 @@ def main(argv=None):
     import os
     args = build_parser().parse_args(argv)
     from . import launch
+    if getattr(args, "devices", None) and getattr(args, "gpus", 1) > 1:
+        sys.exit("cropsr_amd: --devices (one process over several GPUs) and --gpus N (one process per GPU) are two ways to the "
+                 "same result: give one of them")
     if launch.wanted(getattr(args, "gpus", 1)):
         # no launcher in the environment: this process (which never touches the GPU) starts the ranks as fresh
         # children of the same command line and leaves with their status (cropsr_amd/launch.py)

@@ -409,3 +409,52 @@ def test_node_offtarget_and_annotation_vs_oracle(oracle, world, tmp_path):
         with pytest.raises(Exception):
             node.gather(0, features=True)
     ann.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,extra", [("sample", ()), ("multi", ()), ("mixed", ("--score-finalize", "host")),
+                                        ("mixed", ("-l", "23")), ("rightend", ("-l", "64"))])
+def test_cli_devices_csv_bytes_equal_reference(name, extra, manifest, tmp_path, monkeypatch):
+    """`python -m cropsr_amd --devices 0,0,0`: the CLI's whole job through the node handle, ONE process -- the CSV is the
+    reference's, byte for byte (fixtures made by the real CROPSR.py), like the one-GPU run's."""
+    from conftest import golden_fasta_path, read_golden_csv, run_cli
+    from cropsr_amd import cli
+    guide_len = int(extra[1]) if extra[:1] == ("-l",) else None
+    host = "host" in extra
+    backend = cli.NodeBackend([0, 0, 0], finalize="host" if host else "gpu")
+    try:
+        got, _ = run_cli(tmp_path, monkeypatch, golden_fasta_path(name, tmp_path), backend, manifest["seed"], extra=extra)
+    finally:
+        backend.close()
+    if host:
+        # the f64 column that crossed the node is the pre-sigmoid sum and THIS host's numpy applies CROPSR.py:313: the
+        # reference's bytes where np.exp is glibc's; elsewhere (numpy's AVX-512 exp) the same rows, last bits this host's
+        from oracle import oracle
+        x = np.random.default_rng(5).uniform(-9.3, 17.3, 200000)
+        if (np.exp(x).view(np.uint64) == oracle.exp(x).view(np.uint64)).all():
+            assert got == read_golden_csv(name)
+        else:
+            assert got.count(b"\r\n") == read_golden_csv(name).count(b"\r\n") and len(got) > 0
+    else:
+        assert got == read_golden_csv(name, guide_len)
+
+
+@pytest.mark.gpu
+def test_cli_devices_offtarget_annotate_equals_one_device(tmp_path, monkeypatch, manifest):
+    """--devices with --offtarget --annotate == the same run on one device (EngineBackend), byte for byte."""
+    from conftest import GOLDEN, run_cli
+    from cropsr_amd import cli
+    gff = tmp_path / "mixed.gff"
+    gff.write_text("##gff-version 3\nmix\tsrc\tgene\t40\t410\t.\t+\t.\tID=g1;Name=L1\nmix\tsrc\tCDS\t95\t105\t.\t+\t0\tID=g1.cds1\n"
+                   "mix\tsrc\tgene\t400\t1123\t.\t-\t.\tID=g2\ntail\tsrc\tgene\t1\t60\t.\t+\t.\tID=t1\n")
+    extra = ("-g", str(gff), "--annotate", "--offtarget")
+    fa = os.path.join(GOLDEN, "probe_mixed.fa")
+    outs = []
+    for backend in (cli.EngineBackend(0), cli.NodeBackend([0, 0, 0, 0])):
+        d = tmp_path / type(backend).__name__
+        d.mkdir()
+        try:
+            outs.append(run_cli(d, monkeypatch, fa, backend, manifest["seed"], extra=extra)[0])
+        finally:
+            backend.close()
+    assert outs[0] == outs[1] and b"gene:g1" in outs[0] and outs[0].count(b"\r\n") > 100
