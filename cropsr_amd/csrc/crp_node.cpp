@@ -4,9 +4,10 @@
 // for a handle that lets that one process reach the whole node: "multi-GPU fan-out happens inside the library (one
 // stream per device), not via Python threads".  This file is that handle:
 //
-//   crp_plan_shares      the cut: contigs, in order, dealt to the devices as contiguous equal shares (host code)
+//   crp_plan_shares      the cut: contigs, in order, dealt to the devices as contiguous equal shares (host code, crp_plan.cpp)
 //   crp_node_load        one host thread per device uploads its share (pieces with CRP_HALO characters of context)
-//   crp_node_scan_score  the scan is QUEUED on every device's stream, then collected: N kernels run side by side
+//   crp_node_scan_score  one host thread per device (alive as long as the node) launches and collects ITS device's scan:
+//                        the N kernels leave the host side by side and run side by side
 //   crp_node_gather      the path's one exchange.  Per device a tiny kernel finds the OWNED rows of its tables (a
 //                        hit belongs to the piece that contains its match index; with contiguous shares the owned
 //                        rows of a device are one run per strand), the peers pack their positions to 16 bits
@@ -21,7 +22,10 @@
 #include <algorithm>
 #include <array>
 #include <chrono>
+#include <condition_variable>
 #include <cstdlib>
+#include <memory>
+#include <mutex>
 #include <cstring>
 #include <new>
 #include <string>
@@ -29,6 +33,7 @@
 #include <vector>
 
 #include "crp_internal.h"
+#include "crp_plan.h"
 #include "crp_rccl.h"
 #include "crp_roctx.h"
 
@@ -61,45 +66,75 @@ struct NodeDev {
     uint64_t first[2] = {0, 0}, last[2] = {0, 0}, foff[2] = {0, 0};
 };
 
-inline uint64_t round_up8(uint64_t x) { return (x + 7) & ~(uint64_t)7; }
+// One host thread per device beyond the first, alive as long as the node: crp_node_scan_score hands every one of them the
+// scan of ITS device (launch + wait) and runs the first device's itself, so the N launches leave the host side by side --
+// queued one after the other from a single thread, the last device's kernel would start N - 1 launch latencies late, which
+// is a sixth of a 60 us scan at N = 8.  (Threads started per call would cost more than they save.)
+struct NodeWorker {
+    std::thread th;
+    std::mutex m;
+    std::condition_variable wake, finished;
+    int job = 0;  // 0 idle, 1 scan, 2 leave
+    bool done = true;
+    crp_arena *arena = nullptr;
+    int guide_len = 0, flags = 0, rc = CRP_OK;
+    uint64_t n[2] = {0, 0};
 
-// the cut (same as cropsr_amd/parallel.py split_evenly, which the multi-process path uses)
-void plan_shares(const uint64_t *lens, uint64_t n, int world, uint64_t min_piece, std::vector<std::array<uint64_t, 4>> &out)
-{
-    out.clear();
-    int64_t total = 0;
-    for (uint64_t k = 0; k < n; ++k) total += (int64_t)lens[k];
-    std::vector<int64_t> bounds((size_t)world);
-    for (int r = 0; r < world; ++r) bounds[(size_t)r] = (int64_t)(((unsigned __int128)(r + 1) * (unsigned __int128)total) / (unsigned)world);
-    const int64_t minp = (int64_t)min_piece;
-    int r = 0;
-    int64_t acc = 0;
-    for (uint64_t k = 0; k < n; ++k) {
-        const int64_t len = (int64_t)lens[k];
-        int64_t start = 0;
+    void loop()
+    {
         for (;;) {
-            const int64_t rest = len - start, room = bounds[(size_t)r] - acc;
-            if (r == world - 1 || rest <= room) {
-                out.push_back({k, (uint64_t)start, (uint64_t)len, (uint64_t)r});
-                acc += rest;
-                break;
-            }
-            if (room >= minp && rest - room >= minp) {  // cut at the boundary
-                out.push_back({k, (uint64_t)start, (uint64_t)(start + room), (uint64_t)r});
-                acc += room;
-                start += room;
-                r += 1;
-            } else if (2 * room >= rest) {  // a sliver would be left over: the rest of the contig stays here
-                out.push_back({k, (uint64_t)start, (uint64_t)len, (uint64_t)r});
-                acc += rest;
-                break;
-            } else {  // a sliver would be cut off: the next device takes the contig from here
-                r += 1;
-            }
+            std::unique_lock<std::mutex> lk(m);
+            wake.wait(lk, [&] { return job != 0; });
+            if (job == 2) return;
+            crp_arena *a = arena;
+            const int gl = guide_len, fl = flags;
+            lk.unlock();
+            uint64_t x = 0, y = 0;
+            int r = crp::scan_begin(a, gl, fl);
+            if (r == CRP_OK) r = crp::scan_finish(a, &x, &y);
+            lk.lock();
+            rc = r;
+            n[0] = x;
+            n[1] = y;
+            job = 0;
+            done = true;
+            lk.unlock();
+            finished.notify_one();
         }
-        while (r < world - 1 && acc >= bounds[(size_t)r]) r += 1;
     }
-}
+    void post(crp_arena *a, int gl, int fl)
+    {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            arena = a;
+            guide_len = gl;
+            flags = fl;
+            done = false;
+            job = 1;
+        }
+        wake.notify_one();
+    }
+    int wait(uint64_t out[2])
+    {
+        std::unique_lock<std::mutex> lk(m);
+        finished.wait(lk, [&] { return done; });
+        out[0] = n[0];
+        out[1] = n[1];
+        return rc;
+    }
+    void leave()
+    {
+        if (!th.joinable()) return;
+        {
+            std::lock_guard<std::mutex> lk(m);
+            job = 2;
+        }
+        wake.notify_one();
+        th.join();
+    }
+};
+
+inline uint64_t round_up8(uint64_t x) { return (x + 7) & ~(uint64_t)7; }
 
 double ms_since(std::chrono::steady_clock::time_point t0)
 {
@@ -110,6 +145,7 @@ double ms_since(std::chrono::steady_clock::time_point t0)
 
 struct crp_node {
     std::vector<NodeDev> dev;
+    std::vector<std::unique_ptr<NodeWorker>> workers;  // [k]: device k's scan thread (none for device 0), started by the first scan
     std::vector<NodePiece> pieces;
     uint64_t n_contigs = 0;
     bool loaded = false;
@@ -322,24 +358,6 @@ static int on_every_device(crp_node *node, const char *what, F step)
 
 extern "C" {
 
-int crp_plan_shares(const uint64_t *lens, uint64_t n, int world, uint64_t min_piece, uint64_t *pieces, uint64_t cap,
-                    uint64_t *n_pieces)
-{
-    if ((n && !lens) || world < 1 || !n_pieces || (cap && !pieces)) return CRP_ERR_INVALID;
-    for (uint64_t k = 0; k < n; ++k)
-        if (lens[k] >> 62) return CRP_ERR_INVALID;
-    std::vector<std::array<uint64_t, 4>> out;
-    try {
-        plan_shares(lens, n, world, min_piece ? min_piece : 4096, out);
-    } catch (...) {
-        return CRP_ERR_NOMEM;
-    }
-    *n_pieces = out.size();
-    if (out.size() > cap) return CRP_ERR_CAPACITY;
-    for (size_t q = 0; q < out.size(); ++q) std::memcpy(pieces + 4 * q, out[q].data(), 4 * sizeof(uint64_t));
-    return CRP_OK;
-}
-
 int crp_node_init(int n_devices, const int *device_ids, crp_node **out)
 {
     if (!out || n_devices < 1 || n_devices > 64 || !device_ids) return CRP_ERR_INVALID;
@@ -384,6 +402,9 @@ int crp_node_init(int n_devices, const int *device_ids, crp_node **out)
 int crp_node_destroy(crp_node *node)
 {
     if (!node) return CRP_OK;
+    for (auto &w : node->workers)
+        if (w) w->leave();
+    node->workers.clear();
     for (NodeDev &d : node->dev)
         if (d.ctx) (void)crp_synchronize(d.ctx);
     if (!node->comms.empty() && crp::rccl())
@@ -433,7 +454,7 @@ int crp_node_load(crp_node *node, const uint8_t *const *texts, const uint64_t *l
     const int world = (int)node->dev.size();
     try {
         std::vector<std::array<uint64_t, 4>> cut;
-        plan_shares(lens, n, world, 4096, cut);
+        crp::plan_shares(lens, n, world, 4096, cut);
         node->pieces.reserve(cut.size());
         for (const auto &c : cut) {
             NodePiece p;
@@ -515,23 +536,55 @@ int crp_node_scan_score(crp_node *node, int guide_len, int flags, uint64_t *n_pl
     if (!node->loaded) return CRP_ERR_STATE;
     node->have_gather = false;
     const int world = (int)node->dev.size();
-    int rc = CRP_OK, begun = 0;
-    // queue the launch on every device ...
-    for (; begun < world && rc == CRP_OK; ++begun) {
-        NodeDev &d = node->dev[(size_t)begun];
-        if (d.arena) rc = dev_fail(node, begun, crp::scan_begin(d.arena, guide_len, flags), "crp_node_scan_score (launch)");
+    // every device's scan on its own host thread (NodeWorker); the calling thread takes the first device that has an arena
+    if (node->workers.size() != (size_t)world) {
+        try {
+            node->workers.resize((size_t)world);
+        } catch (...) {
+            return CRP_ERR_NOMEM;
+        }
     }
-    if (rc != CRP_OK) begun -= 1;  // (the one that failed queued nothing)
-    // ... then collect them: the kernels run side by side
-    uint64_t tot[2] = {0, 0};
-    for (int k = 0; k < begun; ++k) {
+    int mine = -1;
+    std::vector<char> posted((size_t)world, 0);
+    for (int k = 0; k < world; ++k) {
         NodeDev &d = node->dev[(size_t)k];
         if (!d.arena) continue;
+        if (mine < 0) {
+            mine = k;
+            continue;
+        }
+        auto &w = node->workers[(size_t)k];
+        if (!w) {
+            try {
+                w.reset(new NodeWorker());
+                w->th = std::thread([p = w.get()] { p->loop(); });
+            } catch (...) {
+                w.reset();  // no thread to be had: this device is scanned from here, after the others were posted
+                continue;
+            }
+        }
+        w->post(d.arena, guide_len, flags);
+        posted[(size_t)k] = 1;
+    }
+    int rc = CRP_OK;
+    uint64_t tot[2] = {0, 0};
+    for (int k = 0; k < world; ++k) {  // the first device, and any device without a thread
+        NodeDev &d = node->dev[(size_t)k];
+        if (!d.arena || posted[(size_t)k]) continue;
         uint64_t a = 0, b = 0;
-        const int rk = crp::scan_finish(d.arena, &a, &b);
+        int rk = crp::scan_begin(d.arena, guide_len, flags);
+        if (rk == CRP_OK) rk = crp::scan_finish(d.arena, &a, &b);
         if (rk != CRP_OK && rc == CRP_OK) rc = dev_fail(node, k, rk, "crp_node_scan_score");
         tot[0] += a;
         tot[1] += b;
+    }
+    for (int k = 0; k < world; ++k) {
+        if (!posted[(size_t)k]) continue;
+        uint64_t n[2] = {0, 0};
+        const int rk = node->workers[(size_t)k]->wait(n);
+        if (rk != CRP_OK && rc == CRP_OK) rc = dev_fail(node, k, rk, "crp_node_scan_score");
+        tot[0] += n[0];
+        tot[1] += n[1];
     }
     if (rc != CRP_OK) return rc;
     if (n_plus) *n_plus = tot[0];

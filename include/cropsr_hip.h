@@ -296,8 +296,8 @@ int crp_gathered_fetch_features(crp_ctx *ctx, int rank, uint32_t *feat_plus, uin
 /* The reference is one process with one contig loop (CROPSR.py:333, :409).  A crp_node lets that one process drive N
  * GPUs through one handle: crp_node_load cuts the genome into N contiguous equal shares (a contig that straddles a
  * share boundary is cut there; every piece carries CRP_HALO characters of context either side, a hit belongs to the
- * piece that contains its match index) and uploads every share to its device; crp_node_scan_score queues the scan on
- * every device before it waits for any; crp_node_gather is the path's one exchange, the gatherv of the per-device tables
+ * piece that contains its match index) and uploads every share to its device; crp_node_scan_score launches the scan on
+ * every device from a host thread of that device's own, so the kernels start side by side; crp_node_gather is the path's one exchange, the gatherv of the per-device tables
  * to a root device -- RCCL in one process (ncclCommInitAll; per peer ncclSend, at the root ncclRecv, all inside one
  * ncclGroupStart / ncclGroupEnd) or, where RCCL cannot run (the same device listed twice: rehearsals on one GPU) or is
  * not wanted, device-to-device copies the root pulls over its own streams, one per peer.  The root ends up with ONE

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Collect the rocprofv3 evidence bench.py's roofline numbers are judged against.
-# Run on the GPU box from the repo root:   bash profiles/collect.sh r04
+# Run on the GPU box from the repo root:   bash profiles/collect.sh r05
 # Writes raw rocprof output under gpurun_out/prof_<tag>/ (scratch) and the
 # summaries under gpurun_out/profiles_<tag>/ -- copy those into profiles/.
 #   1. --kernel-trace --stats      : per-kernel average durations of the bench command
@@ -8,7 +8,7 @@
 #   3. --pmc WRITE_SIZE            : HBM write traffic  (separate pass)
 #   4. --pmc SQ_* (two passes)     : where the emit kernel's wave time goes
 set -e
-TAG=${1:-r04}
+TAG=${1:-r05}
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 RAW=gpurun_out/prof_$TAG

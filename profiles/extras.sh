@@ -1,9 +1,9 @@
 #!/bin/bash
 # The files of profiles/rNN/ that profiles/collect.sh does not write, for the SAME library build:
-#   bash profiles/extras.sh r04 [soak]     (GPU box, repo root; `soak` adds the 900-trial fuzz in all four scan-mode x geometry combinations, ~8 minutes)
+#   bash profiles/extras.sh r05 [soak]     (GPU box, repo root; `soak` adds the 900-trial fuzz in all four scan-mode x geometry combinations, ~8 minutes)
 # Everything lands under gpurun_out/profiles_<tag>/; copy it into profiles/<tag>/ beside collect.sh's files.
 set -e
-TAG=${1:-r04}
+TAG=${1:-r05}
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 RAW=gpurun_out/prof_$TAG
@@ -25,6 +25,12 @@ python3 bench.py --gpus 2 --share-gpu0 --scale 0.25 --steps 10 --warmup 3 --cpu-
 # six ranks on the one GPU (the most processes the pool lets one job keep on a card), weak headline + strong-scaling block
 python3 bench.py --gpus 6 --share-gpu0 --scale 0.25 --steps 10 --warmup 3 --cpu-sample-bases 0 --offtarget-steps 0 \
     > $OUT/bench_6ranks_self_launched_one_gpu.json 2> $RAW/6ranks.err
+# ONE process over four logical devices (the library's node handle; on this one-GPU box they are GPU 0 four times, the exchange
+# runs as device-to-device copies): weak headline of 4 x 0.25 genomes, gatherv packed / raw, strong block with digest check
+python3 bench.py --gpus 4 --single-process --share-gpu0 --scale 0.25 --steps 10 --warmup 3 --cpu-sample-bases 0 \
+    > $OUT/bench_single_process_4_logical_devices.json 2> $RAW/sp4.err
+python3 bench.py --gpus 4 --single-process --share-gpu0 --steps 10 --warmup 3 --cpu-sample-bases 0 \
+    > $OUT/bench_single_process_4_logical_devices_full_size.json 2> $RAW/sp4full.err
 # the whole CLI end to end (FASTA in, CSV out)
 python3 tools/e2e_cli.py switchgrass > $OUT/e2e_cli_switchgrass_first_process_on_the_box.json 2> $RAW/e2e0.err
 python3 tools/e2e_cli.py switchgrass > $OUT/e2e_cli_switchgrass.json 2> $RAW/e2e1.err
@@ -36,6 +42,7 @@ python3 tools/e2e_cli.py sorghum > $OUT/e2e_cli_sorghum.json 2> $RAW/e2e5.err
 python3 tools/e2e_cli.py sorghum --annotate 34000 > $OUT/e2e_cli_sorghum_annotate.json 2> $RAW/e2e6.err
 python3 tools/e2e_cli.py tair10 --annotate 27000 > $OUT/e2e_cli_tair10_annotate.json 2> $RAW/e2e7.err
 python3 tools/e2e_cli.py sorghum --annotate 34000 --procs 2 > $OUT/e2e_cli_sorghum_annotate_2ranks_one_gpu.json 2> $RAW/e2e8.err
+python3 tools/e2e_cli.py sorghum --annotate 34000 --devices 0,0,0,0 > $OUT/e2e_cli_sorghum_annotate_4_logical_devices_one_process.json 2> $RAW/e2e9.err
 python3 tools/annotate_bench.py sorghum 34000 > $OUT/annotate_lookup_sorghum.json 2> $RAW/ann1.err
 python3 tools/annotate_bench.py tair10 27000 > $OUT/annotate_lookup_tair10.json 2> $RAW/ann2.err
 { for p in 1 4; do python3 tools/e2e_cli.py tair10 --procs $p --md5 --cli-flag=--offtarget; done; } > $OUT/multi_process_cli_md5.txt 2> $RAW/md5.err

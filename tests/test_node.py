@@ -458,3 +458,76 @@ def test_cli_devices_offtarget_annotate_equals_one_device(tmp_path, monkeypatch,
         finally:
             backend.close()
     assert outs[0] == outs[1] and b"gene:g1" in outs[0] and outs[0].count(b"\r\n") > 100
+
+
+# ------------------------------------------------------------------ boxes with two or more GPUs
+def _second_gpu():
+    """True when HIP device 1 can be opened (the driver's multi-GPU node; the one-GPU boxes skip these tests)."""
+    from cropsr_amd import _native as nat
+    import ctypes
+    h = ctypes.c_void_p()
+    if nat.lib().crp_init(1, ctypes.byref(h)) != nat.CRP_OK:
+        return False
+    nat.lib().crp_destroy(h)
+    return True
+
+
+@pytest.mark.gpu
+def test_node_two_real_devices_on_rccl(oracle, tmp_path):
+    """Two DISTINCT devices (skipped on a one-GPU box): the node's exchange on the real transport -- ncclCommInitAll and
+    one grouped send/recv between two GPUs -- and as device-to-device copies over xGMI, with every column (positions packed
+    and raw, scores, off-target counts, label-set ids): the oracle's rows either way (nothing but a one-rank
+    communicator had ever carried these columns)."""
+    if not _second_gpu():
+        pytest.skip("needs two GPUs")
+    from cropsr_amd import annotate, node as nd
+    from oracle import annotate_oracle
+    rng = np.random.default_rng(42)
+    contigs = _genome(rng, [900_000, 40_000, 350_000, 7, 650_000])
+    gff = tmp_path / "two.gff"
+    gff.write_text("##gff-version 3\n" + "".join("c%d\tsrc\tgene\t%d\t%d\t.\t+\t.\tID=g%d_%d\n" % (k, a, a + 5000, k, a)
+                                               for k in (0, 2, 4) for a in range(1000, 300_000, 9000)))
+    ann = annotate.Annotation(str(gff))
+    req = annotate.Request(ann, ["c%d" % k for k in range(len(contigs))], 1)
+    want_ot = oracle.offtarget_genome(contigs, 20)
+    with nd.Node([0, 1]) as node:
+        node.load(contigs)
+        for kw, transport in (({}, "RCCL"), ({"pos16": False}, "RCCL"), ({"peer_copy": True}, "device-to-device"), ({"root": 1}, "RCCL")):
+            hits = node.scan(20, offtarget=True, annotation=req, **kw)
+            assert node.gather_stats()["transport"].startswith(transport), (kw, node.gather_stats())
+            for k, c in enumerate(contigs):
+                got, want = hits.contig(k), oracle.scan_score(c, 20)
+                for key in ("pos_plus", "score_plus", "pos_minus", "score_minus"):
+                    assert (bits(got[key]) == bits(want[key])).all(), (kw, k, key)
+                assert (got["ot_plus"] == want_ot[k]["ot_plus"]).all() and (got["ot_minus"] == want_ot[k]["ot_minus"]).all(), (kw, k)
+                fp, fm = annotate_oracle.host_join(ann, "c%d" % k, 0, 1, got, 20, len(c))
+                assert (got["feat_plus"] == fp).all() and (got["feat_minus"] == fm).all(), (kw, k)
+    ann.close()
+
+
+@pytest.mark.gpu
+def test_cli_two_real_gpus_rccl_equals_one_process(tmp_path, manifest):
+    """`python -m cropsr_amd --gpus 2 --offtarget --annotate` on two DISTINCT GPUs (skipped on a one-GPU box): one process per
+    GPU, the tables -- with the off-target counts and the label-set ids -- cross on RCCL between two ranks
+    (crp_gather_hits with CRP_GATHER_OFFTARGET | CRP_GATHER_FEATURES | CRP_GATHER_POS16), the site histogram is all-reduced:
+    the bytes of the one-process run."""
+    if not _second_gpu():
+        pytest.skip("needs two GPUs")
+    from conftest import GOLDEN
+    gff = tmp_path / "mixed.gff"
+    gff.write_text("##gff-version 3\nmix\tsrc\tgene\t40\t410\t.\t+\t.\tID=g1;Name=L1\nmix\tsrc\tCDS\t95\t105\t.\t+\t0\tID=g1.cds1\n"
+                   "mix\tsrc\tgene\t400\t1123\t.\t-\t.\tID=g2\ntail\tsrc\tgene\t1\t60\t.\t+\t.\tID=t1\n")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "CROPSR_LAUNCHED", "CROPSR_GATHER")}
+    env.update(PYTHONPATH=ROOT, CROPSR_DIST_MAX_PIECE="100")
+    common = ["-f", os.path.join(GOLDEN, "probe_mixed.fa"), "-g", str(gff), "--cas9", "--seed", str(manifest["seed"]),
+              "--offtarget", "--annotate"]
+    outs = []
+    for tag, extra in (("two", ["--gpus", "2"]), ("one", []), ("node", ["--devices", "0,1"])):
+        out = tmp_path / (tag + ".csv")
+        d = tmp_path / tag
+        d.mkdir()
+        p = subprocess.run([sys.executable, "-m", "cropsr_amd", "-o", str(out)] + common + extra, capture_output=True, text=True,
+                           timeout=900, cwd=str(d), env=env)
+        assert p.returncode == 0, p.stderr[-3000:]
+        outs.append(out.read_bytes())
+    assert outs[0] == outs[1] == outs[2] and b"gene:g1" in outs[0]

@@ -1,5 +1,6 @@
 """Host-side native code under sanitizers (CPU build only; the GPU pool has no ASan).
-The formatter, the FASTA loader and the annotation builder are compiled from source with g++, each with a small driver."""
+The formatter, the FASTA loader, the annotation builder and the node's cut are compiled from source with g++, each with a
+small driver."""
 import os
 import shutil
 import subprocess
@@ -42,3 +43,9 @@ def test_annotation_builder_fuzz_under_sanitizers(tmp_path):
     annotation_info) through crp_annotation_build / _track under ASan + UBSan: the label set of every coordinate and of every
     sampled arena position equals a direct loop over the rows."""
     _build_and_run("address,undefined", tmp_path, "annotation_driver", "crp_annotation.cpp")
+
+
+def test_node_cut_fuzz_under_sanitizers(tmp_path):
+    """20 000 random contig-length lists over 1..17 devices through crp_plan_shares under ASan + UBSan: coverage, order, at
+    most world - 1 cuts, and the one-run-per-table property crp_node_gather rests on."""
+    _build_and_run("address,undefined", tmp_path, "plan_driver", "crp_plan.cpp", defines=["-I", os.path.join(ROOT, "cropsr_amd", "csrc")])

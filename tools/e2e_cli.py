@@ -1,7 +1,9 @@
 """End-to-end timing of `python -m cropsr_amd` on a synthetic genome written as FASTA.
 
 usage: python tools/e2e_cli.py {ecoli|tair10|sorghum|switchgrass[:scale]} [--reference-behaviour] [--profile] [--annotate N_GENES]
-Writes the FASTA and the CSV under $TMPDIR (default /tmp), prints one JSON line.
+       python tools/e2e_cli.py real --fasta PATH [--gff PATH [--phytozome PATH]]      (a REAL genome: nothing is generated)
+Writes the FASTA and the CSV under $TMPDIR (default /tmp), prints one JSON line.  --devices 0,1,..: the CLI's one-process
+multi-GPU mode (the library's node handle).
 """
 import argparse
 import cProfile
@@ -58,20 +60,35 @@ def main():
     ap.add_argument("--annotate", type=int, default=0, metavar="N_GENES",
                     help="write a seeded synthetic Phytozome-style GFF3 with that many gene models and an annotation_info "
                          "file (bench_workload.synthetic_annotation) and run the CLI with -g / -p / --annotate")
+    ap.add_argument("--fasta", default=None, metavar="PATH", help="workload `real`: the genome to run on (SURVEY.md 8d)")
+    ap.add_argument("--gff", default=None, metavar="PATH", help="with --fasta: its GFF3; the run then uses --annotate")
+    ap.add_argument("--phytozome", default=None, metavar="PATH", help="with --gff: the annotation_info file")
+    ap.add_argument("--devices", default=None, metavar="LIST", help="pass --devices LIST to the CLI (one process, several GPUs)")
     a = ap.parse_args()
     import bench_workload as bw
     name, _, scale = a.workload.partition(":")
-    wl = {"ecoli": bw.ecoli_like, "tair10": bw.tair10_like, "sorghum": bw.sorghum_like}.get(name)
-    wl = wl() if wl else bw.switchgrass_like(scale=float(scale or 1.0))
     tmp = os.environ.get("TMPDIR", "/tmp")
-    fa = os.path.join(tmp, "e2e_%s.fa" % wl.name)
     gff = os.path.join(tmp, "e2e.gff")
     out_csv = a.out or os.path.join(tmp, "e2e_out.csv")
+    real = a.fasta is not None
+    if real:
+        class _Real:
+            name = os.path.basename(a.fasta)
+            n_bases = None
+        wl, fa = _Real(), a.fasta
+    else:
+        wl = {"ecoli": bw.ecoli_like, "tair10": bw.tair10_like, "sorghum": bw.sorghum_like}.get(name)
+        wl = wl() if wl else bw.switchgrass_like(scale=float(scale or 1.0))
+        fa = os.path.join(tmp, "e2e_%s.fa" % wl.name)
     t0 = time.time()
-    write_fasta(wl, fa)
+    if not real:
+        write_fasta(wl, fa)
     gff_rows = None
     extra = []
-    if a.annotate:
+    if real and a.gff:
+        gff = a.gff
+        extra = (["-p", a.phytozome] if a.phytozome else []) + ["--annotate"]
+    elif a.annotate and not real:
         info = os.path.join(tmp, "e2e_annotation_info.txt")
         gff_rows = bw.synthetic_annotation(wl, gff, info, n_genes=a.annotate)
         extra = ["-p", info, "--annotate"]
@@ -83,6 +100,8 @@ def main():
     if not a.reference_behaviour:
         argv.append("--each-contig-once")
     argv += a.cli_flag
+    if a.devices:
+        argv += ["--devices", a.devices]
     if a.procs > 1:
         import subprocess
         # the CLI starts its own ranks (cropsr_amd/launch.py); all of them on device 0 here, tables over the host transport
@@ -101,7 +120,8 @@ def main():
                           "wall_incl_process_start_s": round(wall, 3), "phases": json.load(open(stages_json)),
                           "gff_gene_cds_rows": gff_rows, "md5": file_md5(out_csv) if a.md5 else None}))
         os.remove(out_csv)
-        os.remove(fa)
+        if not real:
+            os.remove(fa)
         return
     from cropsr_amd import cli
     if a.ablate_ids:
@@ -123,7 +143,7 @@ def main():
     size = os.path.getsize(out_csv)
     with open(out_csv, "rb") as f:
         rows = sum(chunk.count(b"\n") for chunk in iter(lambda: f.read(1 << 24), b"")) - 1
-    print(json.dumps({"workload": wl.name, "bases": wl.n_bases, "rows": rows, "csv_bytes": size,
+    print(json.dumps({"workload": wl.name, "data": "real" if real else "synthetic", "bases": wl.n_bases, "rows": rows, "csv_bytes": size,
                       "fasta_write_s": round(t_gen, 2), "cli_wall_s": round(wall, 3),
                       "rows_per_s": round(rows / wall), "phases": json.load(open(stages_json)), "gff_gene_cds_rows": gff_rows,
                       "gff_bytes": os.path.getsize(gff),
@@ -133,7 +153,8 @@ def main():
         pstats.Stats(prof, stream=s).sort_stats("cumulative").print_stats(30)
         print(s.getvalue())
     os.remove(out_csv)
-    os.remove(fa)
+    if not real:
+        os.remove(fa)
 
 
 if __name__ == "__main__":

@@ -3,7 +3,7 @@
 # and the annotation join's kernels.  GPU box, repo root:  bash tools/pmc_calibrate.sh [tag]
 # Separate --pmc passes, --kernel-trace only beside them (MI355X_MICROARCH.md; the pool refuses other combinations).
 set -e
-TAG=${1:-r04}
+TAG=${1:-r05}
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 RAW=gpurun_out/pmc_cal_$TAG
