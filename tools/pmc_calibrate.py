@@ -101,7 +101,7 @@ def main():
                "lookup_gather_bytes_per_request": (ot["lookup_gather"] / bench["config"]["kept_hits_total"]
                                                    if ot.get("lookup_gather") and bench.get("config") else None),
                "correction": "reads = FETCH_SIZE x 1024 x 2 (every line reaching the fabric is tallied at 64 B: calibrated on "
-                             "streams, strided and random 16-byte gathers, profiles/r04/fetch_calibration.json); writes = "
+                             "streams, strided and random 16-byte gathers, profiles/r05/fetch_calibration.json); writes = "
                              "WRITE_SIZE x 1024 (exact for streaming stores; 32-byte sectors per scattered store)",
                "source": "tools/pmc_calibrate.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"}
     # the annotation look-up: bench.py's own annotate block runs it on the BENCH workload's tables (that is the figure the
