@@ -531,3 +531,44 @@ def test_cli_two_real_gpus_rccl_equals_one_process(tmp_path, manifest):
         assert p.returncode == 0, p.stderr[-3000:]
         outs.append(out.read_bytes())
     assert outs[0] == outs[1] == outs[2] and b"gene:g1" in outs[0]
+
+
+@pytest.mark.gpu
+def test_node_randomised_genomes_vs_oracle(oracle):
+    """Seeded fuzz of the node handle: random genomes (contig counts 0..12, lengths around the cut's thresholds -- the 4 096
+    characters below which nothing is cut, the halo, word and tile borders --, random alphabets and decoration), 1..7 logical
+    devices, random guide length / packing / root / pre-sigmoid column; one node per world size serves many genomes.  Every
+    contig's rows equal the oracle's.  CROPSR_FUZZ_TRIALS raises the trial count for a soak."""
+    from conftest import fuzz_settings
+    from cropsr_amd import node as nd
+    trials, seed, tick = fuzz_settings(60, 20261005)
+    rng = np.random.default_rng(seed)
+    alphabets = [b"ACGT", b"ACGTacgtN", b"GGCC", b"ACGTUZuzN')],", b"GGGGGGCCCCCCAT"]
+    anchors = [0, 1, 30, 64, 127, 128, 129, 255, 4095, 4096, 4097, 8191, 8192, 8193, 12288, 16384, 65535, 65536, 65537, 131072, 200000]
+    nodes = {}
+    total = cuts = 0
+    try:
+        for trial in range(trials):
+            tick("node", trial)
+            world = int(rng.integers(1, 8))
+            if world not in nodes:
+                nodes[world] = nd.Node([0] * world)
+            node = nodes[world]
+            contigs = []
+            for _ in range(int(rng.integers(0, 13))):
+                n = max(0, int(anchors[rng.integers(len(anchors))] + rng.integers(-70, 71)))
+                if rng.random() < 0.3:
+                    n = int(rng.integers(0, 3000))
+                body = rng.choice(np.frombuffer(alphabets[rng.integers(len(alphabets))], dtype=np.uint8), n).tobytes()
+                deco = rng.integers(3)
+                contigs.append(body if deco == 0 else b"'" + body + (b"')," if deco == 1 else b"')]"))
+            l = 20 if rng.random() < 0.7 else int(rng.integers(0, 51))
+            pre = bool(rng.random() < 0.25)
+            node.load(contigs)
+            cuts += len(node.plan()) - len(contigs)
+            hits = node.scan(l, root=int(rng.integers(0, world)), pre=pre, pos16=bool(rng.random() < 0.7))
+            total += _check_against_oracle(hits, contigs, oracle, l, (trial, world, l, pre), pre=pre)
+    finally:
+        for node in nodes.values():
+            node.close()
+    assert total > 30000 * trials // 60 and cuts > trials // 4
