@@ -754,14 +754,14 @@ def _rccl_world1(out_path, port):
     import bench
     from cropsr_amd import _native as nat
     args = argparse.Namespace(workload="switchgrass", scale=0.01, steps=2, warmup=1, preheat_ms=0.0, strong_steps=0,
-                              no_strong_check=False)
+                              no_strong_check=False, fasta=None, no_node_block=True)
 
     def fence():
         nat.check(nat.lib().crp_synchronize(eng._ctx), "crp_synchronize", eng._ctx)
         eng.comm_barrier()
     st = bench.strong_scaling_block(args, eng, group, True, fence, eng.comm_allreduce)
     ok = ok and st["digest_ok"] is True and st["gatherv_transport"].startswith("RCCL") and st["kept_hits"] == st["n1"]["kept_hits"]
-    ok = ok and st["ms_gatherv"] > 0 and len(st["per_rank"]) == 1
+    ok = ok and st["ms_gatherv"] > 0 and len(st["per_rank"]) == 1 and st["bytes_to_root"] == 0
     eng.close()
     with open(out_path, "w") as f:
         f.write("ok" if ok else "bad")
