@@ -1,6 +1,6 @@
 #!/bin/bash
 # The files of profiles/rNN/ that profiles/collect.sh does not write, for the SAME library build:
-#   bash profiles/extras.sh r05 [soak]     (GPU box, repo root; `soak` adds the 900-trial fuzz in all four scan-mode x geometry combinations, ~8 minutes)
+#   bash profiles/extras.sh r05 [soak]     (GPU box, repo root; `soak` adds the 900-trial fuzz in all four scan-mode x geometry combinations and of the node handle, ~9 minutes)
 # Everything lands under gpurun_out/profiles_<tag>/; copy it into profiles/<tag>/ beside collect.sh's files.
 set -e
 TAG=${1:-r05}
@@ -48,6 +48,7 @@ python3 tools/annotate_bench.py tair10 27000 > $OUT/annotate_lookup_tair10.json 
 { for p in 1 4; do python3 tools/e2e_cli.py tair10 --procs $p --md5 --cli-flag=--offtarget; done; } > $OUT/multi_process_cli_md5.txt 2> $RAW/md5.err
 if [ "$2" = soak ]; then
   CROPSR_FUZZ_TRIALS=900 CROPSR_FUZZ_PROGRESS=$RAW/fuzz_progress.txt python3 -m pytest -q tests/test_gpu_parity.py::test_randomised_arenas_vs_oracle \
-      tests/test_offtarget.py::test_gpu_randomised_genomes_vs_oracle > $OUT/fuzz_soak_900_trials_x4_modes.log 2>&1
+      tests/test_offtarget.py::test_gpu_randomised_genomes_vs_oracle tests/test_node.py::test_node_randomised_genomes_vs_oracle \
+      > $OUT/fuzz_soak_900_trials_x4_modes.log 2>&1
 fi
 ls -la $OUT
