@@ -454,6 +454,18 @@ def node_strong_block(args, node, devices, wl_name, one, n_warm, want=None, n1=N
     g = time_gather(pos16=True)
     g_raw = time_gather(pos16=False)
     g_peer = time_gather(pos16=True, peer_copy=True) if g["transport"].startswith("RCCL") else None
+    # To the HOST (where the reference's consumer, the CSV writer, lives): the gatherv into device 0 + one fetch over device 0's
+    # PCIe link, against CRP_NODE_HOST_GATHER -- no exchange at all, every device's rows over that device's own link, side by
+    # side, into the same host arrays.  Second pass each (the arrays' pages are touched, the staging buffers exist).
+    to_host = {}
+    for label, kw in (("gatherv_to_device_0_then_one_link", {}), ("every_device_over_its_own_link", {"to_host": True})):
+        for rep in range(2):
+            t0 = time.perf_counter()
+            node.gather(0, **kw)
+            t1 = time.perf_counter()
+            hits = node.fetch()
+            t2 = time.perf_counter()
+        to_host[label] = {"ms_gather": (t1 - t0) * 1e3, "ms_fetch": (t2 - t1) * 1e3, "ms": (t2 - t0) * 1e3}
     node.gather(0)
     dt_gather = g["ms"] * 1e-3
     n_scored = node.count_scored()
@@ -462,7 +474,7 @@ def node_strong_block(args, node, devices, wl_name, one, n_warm, want=None, n1=N
     strong = {"workload": wl_name, "scaling": "strong", "genomes": 1, "steps": steps, "pieces": len(plan),
               "contigs_cut": len(plan) - len(one), "halo": nat.HALO, "devices": list(devices),
               "ms_scan_max_rank": dt_scan * 1e3, "ms_gatherv": g["ms"], "gatherv_transport": g["transport"],
-              "bytes_to_root": g["bytes_to_root"], "gatherv": g, "gatherv_raw_u32_positions": g_raw,
+              "bytes_to_root": g["bytes_to_root"], "gatherv": g, "gatherv_raw_u32_positions": g_raw, "tables_to_the_host": to_host,
               "kept_hits": hits.n_plus + hits.n_minus, "gRNAs_scored": int(n_scored), "unit": "gRNAs/s",
               "value_scan_only": n_scored / dt_scan, "value": n_scored / (dt_scan + dt_gather),
               "per_rank": [{"rank": k, "kernel_ms": sprof[k]["ms"] / max(1, sprof[k]["launches"]),

@@ -118,8 +118,9 @@ KINDS = ("count", "tile_scan", "emit_score", "ot_seed", "ot_ball", "ot_lookup", 
 REDUCE_SUM, REDUCE_MAX = 0, 1
 COMM_ID_BYTES = 128
 GATHER_OFFTARGET, GATHER_PRE, GATHER_FEATURES, GATHER_POS16 = 1, 2, 4, 8
-NODE_PEER_COPY = 16
-TRANSPORTS = {0: "none (one device)", 1: "RCCL (in-library, one process)", 2: "device-to-device copies"}
+NODE_PEER_COPY, NODE_HOST_GATHER = 16, 32
+TRANSPORTS = {0: "none (one device)", 1: "RCCL (in-library, one process)", 2: "device-to-device copies",
+              3: "none: every device's rows over its own PCIe link to the host"}
 HALO = 128
 NO_FEATURE = 0xFFFFFFFF
 SCAN_PRE, SCAN_SEEDS = 1, 2

@@ -301,7 +301,11 @@ class NodeBackend:
             t0 = time.perf_counter()
             node.annotate(annotation)
             self.last_annotate_s = time.perf_counter() - t0
-        self.last_gather = node.gather(0, pre=want_pre, offtarget=offtarget, features=annotation is not None)
+        # CROPSR_GATHER=host (as for the process-per-GPU mode): the consumer is this host's CSV writer, so nothing needs to
+        # cross xGMI -- every device's rows come over its own PCIe link (CRP_NODE_HOST_GATHER); default: the gatherv to device 0
+        import os
+        to_host = os.environ.get("CROPSR_GATHER", "rccl") == "host"
+        self.last_gather = node.gather(0, pre=want_pre, offtarget=offtarget, features=annotation is not None, to_host=to_host)
         hits = node.fetch(guide_len)
         out = []
         for k in range(len(contig_strings)):

@@ -61,6 +61,11 @@ struct NodeDev {
     uint32_t *d_bstart[2] = {nullptr, nullptr};
     uint64_t lo16_cap[2] = {0, 0}, bstart_cap[2] = {0, 0};
     uint32_t n_buckets = 0;
+    // CRP_NODE_HOST_GATHER: this device's own piece map {begin[], sub[]} and the rebased positions of its owned rows
+    uint32_t *d_map_self = nullptr;
+    uint64_t map_self_cap = 0;
+    uint32_t *d_lpos[2] = {nullptr, nullptr};
+    uint64_t lpos_cap[2] = {0, 0};
     hipEvent_t ready = nullptr;  // everything this device contributes to the current gather is in place
     // the current gather: owned rows [first, last) of each table, and where they go in the root's tables
     uint64_t first[2] = {0, 0}, last[2] = {0, 0}, foff[2] = {0, 0};
@@ -164,6 +169,7 @@ struct crp_node {
     uint32_t *d_ffeat[2] = {nullptr, nullptr};   // CRP_GATHER_FEATURES: per-hit label-set ids
     uint64_t fot_cap[2] = {0, 0}, ffeat_cap[2] = {0, 0};
     int gflags = 0;                              // flags of the last gather
+    bool host_mode = false;                      // the last gather was CRP_NODE_HOST_GATHER: the rows wait on their own devices
     uint16_t *d_slo16[2] = {nullptr, nullptr};   // staging: the peers' packed positions, peer by peer (each at a multiple of 8)
     uint32_t *d_sbstart[2] = {nullptr, nullptr};  // and their bucket starts
     uint64_t slo16_cap[2] = {0, 0}, sbstart_cap[2] = {0, 0};
@@ -289,7 +295,17 @@ int load_device(crp_node *node, int k, const uint8_t *const *texts)
         d.h_bounds_cap = 4 * np;
     }
     CRP_HIP(ctx, hipMemcpyAsync(d.d_needles, needles.data(), 2 * np * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-    CRP_HIP(ctx, hipStreamSynchronize(ctx->stream));  // (`needles` leaves scope)
+    // its own piece map (begin[], then sub[]): what turns an arena position of an owned row into the position inside its contig
+    std::vector<uint32_t> map(2 * np);
+    for (size_t j = 0; j < np; ++j) {
+        const NodePiece &p = node->pieces[d.pieces[j]];
+        map[j] = needles[2 * j];
+        map[np + j] = (uint32_t)(p.arena_off + (p.start - p.text_lo) - p.start);  // (mod 2^32)
+    }
+    rc = crp::grow(ctx, reinterpret_cast<void **>(&d.d_map_self), &d.map_self_cap, 2 * np, sizeof(uint32_t));
+    if (rc != CRP_OK) return rc;
+    CRP_HIP(ctx, hipMemcpyAsync(d.d_map_self, map.data(), 2 * np * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    CRP_HIP(ctx, hipStreamSynchronize(ctx->stream));  // (`needles` and `map` leave scope)
     d.n_buckets = crp::pos16_buckets_for(d.arena->padded_words);
     return CRP_OK;
 }
@@ -418,6 +434,9 @@ int crp_node_destroy(crp_node *node)
         (void)hipSetDevice(d.device);
         (void)hipFree(d.d_needles);
         (void)hipFree(d.d_bounds);
+        (void)hipFree(d.d_map_self);
+        (void)hipFree(d.d_lpos[0]);
+        (void)hipFree(d.d_lpos[1]);
         if (d.h_bounds) (void)hipHostFree(d.h_bounds);
         for (int s = 0; s < 2; ++s) {
             (void)hipFree(d.d_lo16[s]);
@@ -599,7 +618,7 @@ int crp_node_gather(crp_node *node, int root, int flags)
 {
     crp::Range roctx_range("crp: node gatherv");
     if (!node || root < 0 || (size_t)root >= node->dev.size() ||
-        (flags & ~(CRP_GATHER_PRE | CRP_GATHER_POS16 | CRP_NODE_PEER_COPY | CRP_GATHER_OFFTARGET | CRP_GATHER_FEATURES)))
+        (flags & ~(CRP_GATHER_PRE | CRP_GATHER_POS16 | CRP_NODE_PEER_COPY | CRP_GATHER_OFFTARGET | CRP_GATHER_FEATURES | CRP_NODE_HOST_GATHER)))
         return CRP_ERR_INVALID;
     if (!node->loaded) return CRP_ERR_STATE;
     const bool send_pre = (flags & CRP_GATHER_PRE) != 0, pos16 = (flags & CRP_GATHER_POS16) != 0;
@@ -656,6 +675,44 @@ int crp_node_gather(crp_node *node, int root, int flags)
             total[s] += d.last[s] - d.first[s];
         }
     }
+
+    // ---- CRP_NODE_HOST_GATHER: nothing crosses xGMI.  Every device rebases the positions of its owned rows where they
+    // lie; crp_node_fetch then pulls every device's rows over that device's OWN PCIe link straight into their place in the
+    // caller's arrays -- N links instead of the root's one, for a consumer that lives on the host (the CSV writer).
+    if (flags & CRP_NODE_HOST_GATHER) {
+        const auto t_x = std::chrono::steady_clock::now();
+        for (int k = 0; k < world; ++k) {
+            NodeDev &d = node->dev[(size_t)k];
+            if (!d.arena) continue;
+            crp_ctx *ctx = d.ctx;
+            NODE_HIP(node, hipSetDevice(d.device));
+            const size_t np = d.pieces.size();
+            for (int s = 0; s < 2; ++s) {
+                const uint64_t n = d.last[s] - d.first[s];
+                const int rc = crp::grow(ctx, reinterpret_cast<void **>(&d.d_lpos[s]), &d.lpos_cap[s], n, sizeof(uint32_t));
+                if (rc != CRP_OK) return dev_fail(node, k, rc, "crp_node_gather (rebased positions)");
+                NODE_HIP(node, crp::launch_pos_rebase(ctx->stream, d.arena->d_pos[s] + d.first[s], n,
+                                                      crp::PieceMap{d.d_map_self, d.d_map_self + np, (uint32_t)np}, d.d_lpos[s]));
+            }
+        }
+        for (int k = 0; k < world; ++k) {
+            NodeDev &d = node->dev[(size_t)k];
+            if (!d.arena) continue;
+            NODE_HIP(node, hipSetDevice(d.device));
+            NODE_HIP(node, hipStreamSynchronize(d.ctx->stream));
+        }
+        node->ms_exchange = ms_since(t_x);
+        node->ms_total = ms_since(t_call);
+        node->bytes_to_root = 0;
+        node->transport = CRP_TRANSPORT_HOST_LINKS;
+        node->total[0] = total[0];
+        node->total[1] = total[1];
+        node->gflags = flags;
+        node->host_mode = true;
+        node->have_gather = true;
+        return CRP_OK;
+    }
+    node->host_mode = false;
 
     // ---- 2. transport, and the root's side: final tables, staging, piece maps
     bool peer_copy = node->duplicates || (flags & CRP_NODE_PEER_COPY) || node->transport_env == CRP_TRANSPORT_PEER_COPY;
@@ -985,6 +1042,19 @@ int crp_node_fetch_offtarget(crp_node *node, uint32_t *ot_plus, uint32_t *ot_min
 {
     if (!node) return CRP_ERR_INVALID;
     if (!node->have_gather || !(node->gflags & CRP_GATHER_OFFTARGET)) return CRP_ERR_STATE;
+    if (node->host_mode) {
+        uint32_t *h[2] = {ot_plus, ot_minus};
+        return on_every_device(node, "crp_node_fetch_offtarget (host gather)", [&](int k) {
+            NodeDev &d = node->dev[(size_t)k];
+            for (int s = 0; s < 2; ++s) {
+                const uint64_t n = d.last[s] - d.first[s];
+                if (!n || !h[s]) continue;
+                const int rc = crp::staged_d2h(d.ctx, h[s] + 4 * d.foff[s], d.arena->d_ot_cnt[s] + d.first[s], n * sizeof(uint4));
+                if (rc != CRP_OK) return rc;
+            }
+            return crp_synchronize(d.ctx);
+        });
+    }
     crp_ctx *ctx = node->dev[(size_t)node->root].ctx;
     NODE_HIP(node, hipSetDevice(ctx->device));
     uint32_t *h[2] = {ot_plus, ot_minus};
@@ -1001,6 +1071,19 @@ int crp_node_fetch_features(crp_node *node, uint32_t *feat_plus, uint32_t *feat_
 {
     if (!node) return CRP_ERR_INVALID;
     if (!node->have_gather || !(node->gflags & CRP_GATHER_FEATURES)) return CRP_ERR_STATE;
+    if (node->host_mode) {
+        uint32_t *h[2] = {feat_plus, feat_minus};
+        return on_every_device(node, "crp_node_fetch_features (host gather)", [&](int k) {
+            NodeDev &d = node->dev[(size_t)k];
+            for (int s = 0; s < 2; ++s) {
+                const uint64_t n = d.last[s] - d.first[s];
+                if (!n || !h[s]) continue;
+                const int rc = crp::staged_d2h(d.ctx, h[s] + d.foff[s], d.arena->d_feat[s] + d.first[s], n * sizeof(uint32_t));
+                if (rc != CRP_OK) return rc;
+            }
+            return crp_synchronize(d.ctx);
+        });
+    }
     crp_ctx *ctx = node->dev[(size_t)node->root].ctx;
     NODE_HIP(node, hipSetDevice(ctx->device));
     uint32_t *h[2] = {feat_plus, feat_minus};
@@ -1028,6 +1111,25 @@ int crp_node_count_scored(crp_node *node, uint64_t *n_scored)
 {
     if (!node || !n_scored) return CRP_ERR_INVALID;
     if (!node->have_gather) return CRP_ERR_STATE;
+    if (node->host_mode) {  // the rows are still on their devices: every device counts its owned run
+        const bool pre = (node->gflags & CRP_GATHER_PRE) != 0;
+        uint64_t sum = 0;
+        for (size_t k = 0; k < node->dev.size(); ++k) {
+            NodeDev &d = node->dev[k];
+            if (!d.arena) continue;
+            crp_ctx *c = d.ctx;
+            NODE_HIP(node, hipSetDevice(d.device));
+            NODE_HIP(node, hipMemsetAsync(c->d_scalar, 0, sizeof(uint64_t), c->stream));
+            for (int s = 0; s < 2; ++s)
+                NODE_HIP(node, crp::launch_count_scored(c->stream, (pre ? d.arena->d_pre[s] : d.arena->d_score[s]) + d.first[s],
+                                                        d.last[s] - d.first[s], c->d_scalar));
+            NODE_HIP(node, hipMemcpyAsync(c->h_scalar, c->d_scalar, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+            NODE_HIP(node, hipStreamSynchronize(c->stream));
+            sum += c->h_scalar[0];
+        }
+        *n_scored = sum;
+        return CRP_OK;
+    }
     crp_ctx *ctx = node->dev[(size_t)node->root].ctx;
     NODE_HIP(node, hipSetDevice(ctx->device));
     NODE_HIP(node, hipMemsetAsync(ctx->d_scalar, 0, sizeof(uint64_t), ctx->stream));
@@ -1043,6 +1145,25 @@ int crp_node_fetch(crp_node *node, uint32_t *pos_plus, double *score_plus, uint3
     crp::Range roctx_range("crp: node D2H tables");
     if (!node) return CRP_ERR_INVALID;
     if (!node->have_gather) return CRP_ERR_STATE;
+    if (node->host_mode) {
+        // every device's owned rows over ITS link into their place in the caller's arrays, one host thread per device
+        const bool pre = (node->gflags & CRP_GATHER_PRE) != 0;
+        uint32_t *hp[2] = {pos_plus, pos_minus};
+        double *hs[2] = {score_plus, score_minus};
+        return on_every_device(node, "crp_node_fetch (host gather)", [&](int k) {
+            NodeDev &d = node->dev[(size_t)k];
+            for (int s = 0; s < 2; ++s) {
+                const uint64_t n = d.last[s] - d.first[s];
+                if (!n) continue;
+                int rc = CRP_OK;
+                if (hp[s]) rc = crp::staged_d2h(d.ctx, hp[s] + d.foff[s], d.d_lpos[s], n * sizeof(uint32_t));
+                if (rc == CRP_OK && hs[s])
+                    rc = crp::staged_d2h(d.ctx, hs[s] + d.foff[s], (pre ? d.arena->d_pre[s] : d.arena->d_score[s]) + d.first[s], n * sizeof(double));
+                if (rc != CRP_OK) return rc;
+            }
+            return crp_synchronize(d.ctx);
+        });
+    }
     crp_ctx *ctx = node->dev[(size_t)node->root].ctx;
     NODE_HIP(node, hipSetDevice(ctx->device));
     uint32_t *hp[2] = {pos_plus, pos_minus};
@@ -1062,7 +1183,7 @@ int crp_node_fetch(crp_node *node, uint32_t *pos_plus, double *score_plus, uint3
 int crp_node_tables_device(crp_node *node, void **pos_plus, void **score_plus, void **pos_minus, void **score_minus)
 {
     if (!node) return CRP_ERR_INVALID;
-    if (!node->have_gather) return CRP_ERR_STATE;
+    if (!node->have_gather || node->host_mode) return CRP_ERR_STATE;  // (a host gather leaves no table on any one device)
     if (pos_plus) *pos_plus = node->d_fpos[0];
     if (score_plus) *score_plus = node->d_fscore[0];
     if (pos_minus) *pos_minus = node->d_fpos[1];

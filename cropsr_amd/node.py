@@ -206,12 +206,14 @@ class Node:
         self._check(nat.lib().crp_node_annotate(self._h, ann._h, seqids.ctypes.data_as(nat.u64p), int(request.dec)),
                     "crp_node_annotate")
 
-    def gather(self, root=0, pre=False, pos16=True, peer_copy=False, offtarget=False, features=False):
+    def gather(self, root=0, pre=False, pos16=True, peer_copy=False, offtarget=False, features=False, to_host=False):
         """crp_node_gather: every device's owned rows to logical device `root` (one table per strand, contig order,
-        contig-local positions); offtarget / features: the columns of offtarget() / annotate() travel too.  Returns
-        dict(ms_total, ms_exchange, bytes_to_root, transport)."""
+        contig-local positions); offtarget / features: the columns of offtarget() / annotate() travel too.  to_host:
+        CRP_NODE_HOST_GATHER -- nothing crosses xGMI, fetch() pulls every device's rows over that device's own PCIe link
+        into their place (for a consumer on the host).  Returns dict(ms_total, ms_exchange, bytes_to_root, transport)."""
         flags = ((nat.GATHER_PRE if pre else 0) | (nat.GATHER_POS16 if pos16 else 0) | (nat.NODE_PEER_COPY if peer_copy else 0) |
-                 (nat.GATHER_OFFTARGET if offtarget else 0) | (nat.GATHER_FEATURES if features else 0))
+                 (nat.GATHER_OFFTARGET if offtarget else 0) | (nat.GATHER_FEATURES if features else 0) |
+                 (nat.NODE_HOST_GATHER if to_host else 0))
         self._check(nat.lib().crp_node_gather(self._h, int(root), flags), "crp_node_gather")
         self._gathered = (bool(offtarget), bool(features))
         return self.gather_stats()
@@ -221,7 +223,7 @@ class Node:
         self._check(nat.lib().crp_node_gather_stats(self._h, ctypes.byref(ms_t), ctypes.byref(ms_x), ctypes.byref(nb), ctypes.byref(tr)),
                     "crp_node_gather_stats")
         return dict(ms_total=ms_t.value, ms_exchange=ms_x.value, bytes_to_root=int(nb.value), transport=nat.TRANSPORTS[tr.value],
-                    note=nat.lib().crp_node_last_error(self._h).decode() if tr.value == 2 else "")
+                    note=nat.lib().crp_node_last_error(self._h).decode() if tr.value == 2 else "")  # (why RCCL did not run, if it was asked for)
 
     def counts(self):
         """(per_contig (n, 2) uint64, n_plus, n_minus) of the last gather."""
@@ -274,7 +276,7 @@ class Node:
                                                           hits.feat_minus.ctypes.data_as(nat.u32p)), "crp_node_fetch_features")
         return hits
 
-    def scan(self, guide_len=20, root=0, pre=False, pos16=True, peer_copy=False, offtarget=False, annotation=None):
+    def scan(self, guide_len=20, root=0, pre=False, pos16=True, peer_copy=False, offtarget=False, annotation=None, to_host=False):
         """load()ed genome -> NodeHits: scan on every device (+ the opt-in off-target scan and annotation join over the
         resident tables), gatherv to `root`, tables to the host."""
         self.scan_score_device(guide_len, want_pre=pre, want_seeds=offtarget)
@@ -282,5 +284,6 @@ class Node:
             self.offtarget(guide_len)
         if annotation is not None:
             self.annotate(annotation)
-        self.gather(root, pre=pre, pos16=pos16, peer_copy=peer_copy, offtarget=offtarget, features=annotation is not None)
+        self.gather(root, pre=pre, pos16=pos16, peer_copy=peer_copy, offtarget=offtarget, features=annotation is not None,
+                    to_host=to_host)
         return self.fetch(guide_len)

@@ -352,6 +352,13 @@ int crp_node_annotate(crp_node *node, const struct crp_annotation *annotation, c
  * CRP_NODE_PEER_COPY (device-to-device copies instead of RCCL for this call; always the case when a device is
  * listed twice, or when the environment says CRP_NODE_TRANSPORT=peer). */
 #define CRP_NODE_PEER_COPY 16
+/* CRP_NODE_HOST_GATHER: for a consumer that lives on the HOST (the reference's consumer does: csv.writer, CROPSR.py:471-474).
+ * Nothing crosses xGMI and no table is built on `root`: the call makes the ownership cuts and the counts, every device
+ * rebases the positions of its owned rows where they lie, and crp_node_fetch (/_fetch_offtarget /_fetch_features) then
+ * copies every device's rows over THAT device's own PCIe link, side by side, straight into their place in the caller's
+ * arrays -- N host links instead of a gather into one GPU followed by one link.  Same rows, same order.
+ * crp_node_tables_device has nothing to hand out after such a gather (CRP_ERR_STATE). */
+#define CRP_NODE_HOST_GATHER 32
 int crp_node_gather(crp_node *node, int root, int flags);
 /* After crp_node_gather: kept hits per contig and strand (2 x n contigs: {plus, minus}) and in all; any pointer may
  * be NULL. */
@@ -368,9 +375,10 @@ int crp_node_tables_device(crp_node *node, void **pos_plus, void **score_plus, v
 int crp_node_fetch_offtarget(crp_node *node, uint32_t *ot_plus, uint32_t *ot_minus);
 int crp_node_fetch_features(crp_node *node, uint32_t *feat_plus, uint32_t *feat_minus);
 /* The last crp_node_gather in numbers: wall time of the whole call and of its exchange step alone (ms), bytes that
- * crossed from peers to the root, transport used (1 RCCL, 2 device-to-device copies).  Any pointer may be NULL. */
+ * crossed from peers to the root, transport used (1 RCCL, 2 device-to-device copies, 3 none: host gather).  Any pointer may be NULL. */
 #define CRP_TRANSPORT_RCCL 1
 #define CRP_TRANSPORT_PEER_COPY 2
+#define CRP_TRANSPORT_HOST_LINKS 3   /* CRP_NODE_HOST_GATHER: nothing moved between devices */
 int crp_node_gather_stats(const crp_node *node, double *ms_total, double *ms_exchange, uint64_t *bytes_to_root, int *transport);
 
 /* ---- annotation join (opt-in; a no-op in the reference) -------------------- */

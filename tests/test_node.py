@@ -164,11 +164,16 @@ def test_node_logical_devices_vs_oracle(oracle, world):
             node.load(contigs)
             plan = node.plan()
             assert [(p["contig"], p["start"], p["end"], p["device"]) for p in plan] == nd.plan_shares([len(c) for c in contigs], world)
-            for l, kw in ((20, {}), (20, {"pos16": False}), (20, {"pre": True}), (20, {"root": world - 1}), (23, {}), (7, {"pos16": False, "root": world // 2})):
+            for l, kw in ((20, {}), (20, {"pos16": False}), (20, {"pre": True}), (20, {"root": world - 1}), (23, {}), (7, {"pos16": False, "root": world // 2}),
+                          (20, {"to_host": True}), (20, {"to_host": True, "pre": True}), (9, {"to_host": True})):
                 hits = node.scan(l, **kw)
                 _check_against_oracle(hits, contigs, oracle, l, (world, g, l, kw), pre=kw.get("pre", False))
                 st = node.gather_stats()
-                assert st["transport"] == ("device-to-device copies" if world > 1 else "none (one device)")
+                if kw.get("to_host"):  # nothing crossed between devices: every device's rows came over its own link
+                    assert st["transport"].startswith("none: every device") and st["bytes_to_root"] == 0
+                    assert node.count_scored() == int((hits.score_plus != -1).sum() + (hits.score_minus != -1).sum())
+                else:
+                    assert st["transport"] == ("device-to-device copies" if world > 1 else "none (one device)")
             # what crossed to the root: 10 B per hit packed (+ the bucket starts), 12 B raw
             node.scan_score_device(20)
             raw = node.gather(0, pos16=False)["bytes_to_root"]
@@ -317,6 +322,8 @@ def test_bench_single_process_four_logical_devices():
     st = d["strong"]
     assert st["digest_ok"] is True and st["genomes"] == 1 and st["contigs_cut"] >= 1 and st["kept_hits"] == st["n1"]["kept_hits"]
     assert st["bytes_to_root"] > 0 and st["value"] < st["value_scan_only"] and len(st["per_rank"]) == 4
+    th = st["tables_to_the_host"]
+    assert th["every_device_over_its_own_link"]["ms"] > 0 and th["gatherv_to_device_0_then_one_link"]["ms_gather"] > 0
     r = d["roofline"]
     assert r["bound"] == "hbm" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
 
@@ -385,7 +392,7 @@ def test_node_offtarget_and_annotation_vs_oracle(oracle, world, tmp_path):
     want_ot = oracle.offtarget_genome(contigs, 20)
     with nd.Node([0] * world) as node:
         node.load(contigs)
-        for kw in ({}, {"pos16": False, "root": world - 1}):
+        for kw in ({}, {"pos16": False, "root": world - 1}, {"to_host": True}):
             hits = node.scan(20, offtarget=True, annotation=req, **kw)
             n_feat = 0
             for k, c in enumerate(contigs):
@@ -421,6 +428,8 @@ def test_cli_devices_csv_bytes_equal_reference(name, extra, manifest, tmp_path, 
     from cropsr_amd import cli
     guide_len = int(extra[1]) if extra[:1] == ("-l",) else None
     host = "host" in extra
+    if name == "multi":
+        monkeypatch.setenv("CROPSR_GATHER", "host")  # every device's rows over its own link (CRP_NODE_HOST_GATHER)
     backend = cli.NodeBackend([0, 0, 0], finalize="host" if host else "gpu")
     try:
         got, _ = run_cli(tmp_path, monkeypatch, golden_fasta_path(name, tmp_path), backend, manifest["seed"], extra=extra)
@@ -566,7 +575,7 @@ def test_node_randomised_genomes_vs_oracle(oracle):
             pre = bool(rng.random() < 0.25)
             node.load(contigs)
             cuts += len(node.plan()) - len(contigs)
-            hits = node.scan(l, root=int(rng.integers(0, world)), pre=pre, pos16=bool(rng.random() < 0.7))
+            hits = node.scan(l, root=int(rng.integers(0, world)), pre=pre, pos16=bool(rng.random() < 0.7), to_host=bool(rng.random() < 0.3))
             total += _check_against_oracle(hits, contigs, oracle, l, (trial, world, l, pre), pre=pre)
     finally:
         for node in nodes.values():
