@@ -258,10 +258,15 @@ class Node:
         nat.check(nat.lib().crp_arena_composition(ctypes.c_void_p(a), ctypes.byref(x), ctypes.byref(y)), "crp_arena_composition")
         return dict(n_plain=x.value, n_other=y.value)
 
-    def fetch(self, guide_len=20):
-        """Host copies of the gathered tables -> NodeHits."""
+    def fetch(self, guide_len=20, out=None):
+        """Host copies of the gathered tables -> NodeHits.  out: the NodeHits of an earlier fetch of the same size -- its
+        arrays are filled again (a caller that processes genome after genome keeps its pages: a fresh numpy array costs a
+        page fault per 4 KiB on first touch, several times what the link takes)."""
         per, n_plus, n_minus = self.counts()
-        cols = [np.empty(n_plus, np.uint32), np.empty(n_plus, np.float64), np.empty(n_minus, np.uint32), np.empty(n_minus, np.float64)]
+        if out is not None and out.pos_plus.size == n_plus and out.pos_minus.size == n_minus:
+            cols = [out.pos_plus, out.score_plus, out.pos_minus, out.score_minus]
+        else:
+            cols = [np.empty(n_plus, np.uint32), np.empty(n_plus, np.float64), np.empty(n_minus, np.uint32), np.empty(n_minus, np.float64)]
         self._check(nat.lib().crp_node_fetch(self._h, cols[0].ctypes.data_as(nat.u32p), cols[1].ctypes.data_as(nat.f64p),
                                              cols[2].ctypes.data_as(nat.u32p), cols[3].ctypes.data_as(nat.f64p)), "crp_node_fetch")
         hits = NodeHits(per, cols, guide_len)
