@@ -463,7 +463,7 @@ crp_arena *crp_node_arena(crp_node *node, int k)
     return (node && k >= 0 && (size_t)k < node->dev.size()) ? node->dev[(size_t)k].arena : nullptr;
 }
 
-int crp_node_load(crp_node *node, const uint8_t *const *texts, const uint64_t *lens, uint64_t n)
+static int node_load_impl(crp_node *node, const uint8_t *const *texts, const uint64_t *lens, uint64_t n)
 {
     crp::Range roctx_range("crp: node load (cut + H2D + pack on every device)");
     if (!node || (n && (!texts || !lens))) return CRP_ERR_INVALID;
@@ -534,7 +534,7 @@ int crp_node_load(crp_node *node, const uint8_t *const *texts, const uint64_t *l
     return CRP_OK;
 }
 
-int crp_node_plan(const crp_node *node, uint64_t *pieces, uint64_t cap, uint64_t *n_pieces)
+static int node_plan_impl(const crp_node *node, uint64_t *pieces, uint64_t cap, uint64_t *n_pieces)
 {
     if (!node || !n_pieces || (cap && !pieces)) return CRP_ERR_INVALID;
     if (!node->loaded) return CRP_ERR_STATE;
@@ -548,7 +548,7 @@ int crp_node_plan(const crp_node *node, uint64_t *pieces, uint64_t cap, uint64_t
     return CRP_OK;
 }
 
-int crp_node_scan_score(crp_node *node, int guide_len, int flags, uint64_t *n_plus, uint64_t *n_minus)
+static int node_scan_score_impl(crp_node *node, int guide_len, int flags, uint64_t *n_plus, uint64_t *n_minus)
 {
     crp::Range roctx_range("crp: node scan + score (all devices)");
     if (!node) return CRP_ERR_INVALID;
@@ -614,7 +614,7 @@ int crp_node_scan_score(crp_node *node, int guide_len, int flags, uint64_t *n_pl
     return CRP_OK;
 }
 
-int crp_node_gather(crp_node *node, int root, int flags)
+static int node_gather_impl(crp_node *node, int root, int flags)
 {
     crp::Range roctx_range("crp: node gatherv");
     if (!node || root < 0 || (size_t)root >= node->dev.size() ||
@@ -909,7 +909,7 @@ int crp_node_gather(crp_node *node, int root, int flags)
     return CRP_OK;
 }
 
-int crp_node_offtarget(crp_node *node, int guide_len, uint64_t *n_sites)
+static int node_offtarget_impl(crp_node *node, int guide_len, uint64_t *n_sites)
 {
     crp::Range roctx_range("crp: node off-target seed scan");
     if (!node) return CRP_ERR_INVALID;
@@ -1007,7 +1007,7 @@ int crp_node_offtarget(crp_node *node, int guide_len, uint64_t *n_sites)
     return CRP_OK;
 }
 
-int crp_node_annotate(crp_node *node, const crp_annotation *annotation, const uint64_t *seqid_of_contig, int dec)
+static int node_annotate_impl(crp_node *node, const crp_annotation *annotation, const uint64_t *seqid_of_contig, int dec)
 {
     crp::Range roctx_range("crp: node annotation join");
     if (!node || !annotation || (node->n_contigs && !seqid_of_contig) || dec < 0) return CRP_ERR_INVALID;
@@ -1038,7 +1038,7 @@ int crp_node_annotate(crp_node *node, const crp_annotation *annotation, const ui
     });
 }
 
-int crp_node_fetch_offtarget(crp_node *node, uint32_t *ot_plus, uint32_t *ot_minus)
+static int node_fetch_offtarget_impl(crp_node *node, uint32_t *ot_plus, uint32_t *ot_minus)
 {
     if (!node) return CRP_ERR_INVALID;
     if (!node->have_gather || !(node->gflags & CRP_GATHER_OFFTARGET)) return CRP_ERR_STATE;
@@ -1067,7 +1067,7 @@ int crp_node_fetch_offtarget(crp_node *node, uint32_t *ot_plus, uint32_t *ot_min
     return CRP_OK;
 }
 
-int crp_node_fetch_features(crp_node *node, uint32_t *feat_plus, uint32_t *feat_minus)
+static int node_fetch_features_impl(crp_node *node, uint32_t *feat_plus, uint32_t *feat_minus)
 {
     if (!node) return CRP_ERR_INVALID;
     if (!node->have_gather || !(node->gflags & CRP_GATHER_FEATURES)) return CRP_ERR_STATE;
@@ -1107,7 +1107,7 @@ int crp_node_counts(const crp_node *node, uint64_t *per_contig, uint64_t *n_plus
     return CRP_OK;
 }
 
-int crp_node_count_scored(crp_node *node, uint64_t *n_scored)
+static int node_count_scored_impl(crp_node *node, uint64_t *n_scored)
 {
     if (!node || !n_scored) return CRP_ERR_INVALID;
     if (!node->have_gather) return CRP_ERR_STATE;
@@ -1140,7 +1140,7 @@ int crp_node_count_scored(crp_node *node, uint64_t *n_scored)
     return CRP_OK;
 }
 
-int crp_node_fetch(crp_node *node, uint32_t *pos_plus, double *score_plus, uint32_t *pos_minus, double *score_minus)
+static int node_fetch_impl(crp_node *node, uint32_t *pos_plus, double *score_plus, uint32_t *pos_minus, double *score_minus)
 {
     crp::Range roctx_range("crp: node D2H tables");
     if (!node) return CRP_ERR_INVALID;
@@ -1201,5 +1201,24 @@ int crp_node_gather_stats(const crp_node *node, double *ms_total, double *ms_exc
     if (transport) *transport = node->transport;
     return CRP_OK;
 }
+
+
+// The entry points above may allocate (vectors, strings, threads): nothing is allowed to throw across the C ABI.
+#define CRP_NODE_GUARD(call)     \
+    try {                        \
+        return (call);           \
+    } catch (...) {              \
+        return CRP_ERR_NOMEM;    \
+    }
+int crp_node_load(crp_node *node, const uint8_t *const *texts, const uint64_t *lens, uint64_t n) { CRP_NODE_GUARD(node_load_impl(node, texts, lens, n)); }
+int crp_node_plan(const crp_node *node, uint64_t *pieces, uint64_t cap, uint64_t *n_pieces) { CRP_NODE_GUARD(node_plan_impl(node, pieces, cap, n_pieces)); }
+int crp_node_scan_score(crp_node *node, int guide_len, int flags, uint64_t *n_plus, uint64_t *n_minus) { CRP_NODE_GUARD(node_scan_score_impl(node, guide_len, flags, n_plus, n_minus)); }
+int crp_node_gather(crp_node *node, int root, int flags) { CRP_NODE_GUARD(node_gather_impl(node, root, flags)); }
+int crp_node_offtarget(crp_node *node, int guide_len, uint64_t *n_sites) { CRP_NODE_GUARD(node_offtarget_impl(node, guide_len, n_sites)); }
+int crp_node_annotate(crp_node *node, const crp_annotation *annotation, const uint64_t *seqid_of_contig, int dec) { CRP_NODE_GUARD(node_annotate_impl(node, annotation, seqid_of_contig, dec)); }
+int crp_node_fetch(crp_node *node, uint32_t *pos_plus, double *score_plus, uint32_t *pos_minus, double *score_minus) { CRP_NODE_GUARD(node_fetch_impl(node, pos_plus, score_plus, pos_minus, score_minus)); }
+int crp_node_fetch_offtarget(crp_node *node, uint32_t *ot_plus, uint32_t *ot_minus) { CRP_NODE_GUARD(node_fetch_offtarget_impl(node, ot_plus, ot_minus)); }
+int crp_node_fetch_features(crp_node *node, uint32_t *feat_plus, uint32_t *feat_minus) { CRP_NODE_GUARD(node_fetch_features_impl(node, feat_plus, feat_minus)); }
+int crp_node_count_scored(crp_node *node, uint64_t *n_scored) { CRP_NODE_GUARD(node_count_scored_impl(node, n_scored)); }
 
 }  // extern "C"
