@@ -581,3 +581,32 @@ def test_node_randomised_genomes_vs_oracle(oracle):
         for node in nodes.values():
             node.close()
     assert total > 30000 * trials // 60 and cuts > trials // 4
+
+
+@pytest.mark.gpu
+def test_integration_md_node_snippet_runs(oracle):
+    """The ctypes patch INTEGRATION.md shows for reaching the whole node from the one-process reference script is executed as
+    printed (the eight devices being GPU 0 eight times here) on a small genome: the tables it ends up with are the oracle's."""
+    import ctypes
+    import types
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    start = text.index("### The whole node from the one process")
+    code = text[text.index("```python", start) + len("```python"):]
+    code = code[:code.index("```")]
+    assert "crp_node_init(8, ids" in code and "crp_node_fetch" in code
+    code = code.replace("(*range(8))", "(*([0] * 8))")
+    rng = np.random.default_rng(31)
+    contigs = _genome(rng, [400_000, 9_000, 250_000])
+    env = {"ctypes": ctypes, "np": np, "_crp": ctypes.CDLL(os.path.join(ROOT, "cropsr_amd", "libcropsr_hip.so")),
+           "fasta_file": {"c%d" % k: c.decode("ascii") for k, c in enumerate(contigs)}, "args": types.SimpleNamespace(l=20)}
+    exec(code, env)
+    per = list(env["per_contig"])
+    a = b = 0
+    for k, c in enumerate(contigs):
+        want = oracle.scan_score(c, 20)
+        n_p, n_m = per[2 * k], per[2 * k + 1]
+        assert (env["pos_p"][a:a + n_p] == want["pos_plus"]).all() and (bits(env["sc_p"][a:a + n_p]) == bits(want["score_plus"])).all()
+        assert (env["pos_m"][b:b + n_m] == want["pos_minus"]).all() and (bits(env["sc_m"][b:b + n_m]) == bits(want["score_minus"])).all()
+        a, b = a + n_p, b + n_m
+    assert a == env["n_plus"].value and b == env["n_minus"].value and a + b > 30_000
+    env["_crp"].crp_node_destroy(env["node"])
