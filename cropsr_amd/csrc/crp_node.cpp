@@ -156,6 +156,7 @@ struct crp_node {
     bool loaded = false;
     bool duplicates = false;  // a device listed twice: RCCL cannot be used
     int transport_env = 0;    // CRP_NODE_TRANSPORT: 0 unset, CRP_TRANSPORT_*
+    int scan_threads_env = -1;  // CRP_NODE_SCAN_THREADS: -1 unset (threads unless a device is listed twice), 0 never, 1 always
     // RCCL, one communicator per logical device, created by the first gather that uses it
     std::vector<ncclComm_t> comms;
     bool comms_tried = false;
@@ -411,6 +412,7 @@ int crp_node_init(int n_devices, const int *device_ids, crp_node **out)
         if (!std::strcmp(e, "peer")) node->transport_env = CRP_TRANSPORT_PEER_COPY;
         else if (!std::strcmp(e, "rccl")) node->transport_env = CRP_TRANSPORT_RCCL;
     }
+    if (const char *e = std::getenv("CRP_NODE_SCAN_THREADS")) node->scan_threads_env = std::atoi(e) != 0;  // (tests: the threaded scan on one GPU)
     *out = node;
     return CRP_OK;
 }
@@ -568,7 +570,8 @@ static int node_scan_score_impl(crp_node *node, int guide_len, int flags, uint64
     // (a device listed more than once -- the rehearsal shape on a one-GPU box -- is scanned one logical device after the
     // other from this thread: N kernels launched at the same instant on ONE GPU only get in each other's way, their tiles'
     // look-backs waiting on workgroups that found no slot: 4 x 1.13 Gb took 2.32 ms that way against 1.64 ms one by one)
-    for (int k = 0; k < world && !node->duplicates; ++k) {
+    const bool threaded = node->scan_threads_env >= 0 ? node->scan_threads_env == 1 : !node->duplicates;
+    for (int k = 0; k < world && threaded; ++k) {
         NodeDev &d = node->dev[(size_t)k];
         if (!d.arena) continue;
         if (mine < 0) {

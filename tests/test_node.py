@@ -610,3 +610,35 @@ def test_integration_md_node_snippet_runs(oracle):
         a, b = a + n_p, b + n_m
     assert a == env["n_plus"].value and b == env["n_minus"].value and a + b > 30_000
     env["_crp"].crp_node_destroy(env["node"])
+
+
+def _threaded_scan_on_one_gpu(out_path):
+    """CRP_NODE_SCAN_THREADS=1: the per-device scan threads (what a node of DISTINCT GPUs uses) forced on for seven logical
+    devices on GPU 0 -- many scans back to back, a reload in between, every result against the oracle."""
+    os.environ["CRP_NODE_SCAN_THREADS"] = "1"
+    from cropsr_amd import node as nd
+    from oracle import oracle as orc
+    rng = np.random.default_rng(8)
+    total = 0
+    with nd.Node([0] * 7) as node:
+        for lengths in ([500_000, 30_000, 260_000], [90_000] * 9, [1_200_000]):
+            contigs = _genome(rng, lengths)
+            node.load(contigs)
+            for rep in range(40):
+                node.scan_score_device(20)
+            for l in (20, 23):
+                total += _check_against_oracle(node.scan(l, pos16=bool(l == 20)), contigs, orc, l, ("threads", lengths, l))
+    with open(out_path, "w") as f:
+        f.write(str(total))
+
+
+@pytest.mark.gpu
+def test_node_threaded_scan_forced_on_one_gpu(tmp_path):
+    """On a one-GPU box the node scans its logical devices one after the other (N kernels launched at once on one GPU only get
+    in each other's way); the worker threads a real multi-GPU node uses are forced on here so that they stay under test."""
+    out = tmp_path / "threads.txt"
+    code = "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_node; test_node._threaded_scan_on_one_gpu(%r)" % (
+        ROOT, os.path.join(ROOT, "tests"), str(out))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert int(out.read_text()) > 300_000
