@@ -96,7 +96,11 @@ class Node:
             nat.lib().crp_node_destroy(self._h)
             self._h = None
 
-    __del__ = close
+    def __del__(self):
+        try:  # (at interpreter exit the module globals may already be gone)
+            self.close()
+        except Exception:
+            pass
 
     def __enter__(self):
         return self

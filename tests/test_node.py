@@ -98,6 +98,19 @@ def test_plan_shares_capacity_protocol_and_bad_arguments():
     assert L.crp_node_gather(None, 0, 0) == -1 and L.crp_node_last_error(None) == b""
 
 
+def test_node_has_no_cpu_fallback_without_gpu():
+    """Without a HIP device the node handle fails loudly too (CRP_ERR_NO_DEVICE), and the single-process bench and CLI with it."""
+    if os.path.exists("/dev/kfd"):
+        pytest.skip("a GPU is present")
+    from cropsr_amd import _native as nat, node as nd
+    with pytest.raises(nat.CropsrHipError) as e:
+        nd.Node([0, 1])
+    assert e.value.status == nat.CRP_ERR_NO_DEVICE
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--single-process", "--scale", "0.01"],
+                       capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert p.returncode != 0 and "no usable HIP device" in p.stderr and not [l for l in p.stdout.splitlines() if l.startswith("{")]
+
+
 def test_pos16_host_transport_round_trip():
     """The 16-bit position packing of the exchange as the host transport (sockets) does it in numpy: exact for any
     ascending table, including empty buckets, runs longer than 65 536 positions without a hit, and the table's ends."""
