@@ -70,6 +70,9 @@ def parse_args():
     ap.add_argument("--single-process", action="store_true",
                     help="--gpus N through the library's node handle (crp_node_*): ONE process, no launcher, no sockets -- the cut, "
                          "the fan-out over the N devices and the gatherv happen inside libcropsr_hip.so")
+    ap.add_argument("--strong-only", action="store_true",
+                    help="--single-process: only the strong-scaling block (ONE genome over the N devices, digest-checked); the line "
+                         "is {\"strong\": ...}.  What rank 0 of a process-per-GPU run starts as its closing node block")
     ap.add_argument("--devices", default=None, metavar="LIST",
                     help="--single-process: the HIP devices to use, e.g. 0,1,2,3 (default 0..N-1; with --share-gpu0: device 0, N times)")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the switchgrass-like genome (debug)")
@@ -276,15 +279,12 @@ def strong_scaling_block(args, eng, group, use_rccl, fence, reduce):
     for q in mine:
         wanted.setdefault(pieces[q][0], []).append(q)
     ref_builder = eng.arena_builder(lengths) if (rank == 0 and check) else None
-    kept_strings = [] if (ref_builder is not None and not args.no_node_block) else None  # (rank 0: for the node block that follows)
     t_gen = time.perf_counter()
     views = {}
     for k in (range(len(lengths)) if ref_builder is not None else sorted(wanted)):
         s = wl.contig_string(k)
         if ref_builder is not None:
             ref_builder.add(s)
-            if kept_strings is not None:
-                kept_strings.append(s)
         for q in wanted.get(k, ()):
             v, shift = parallel.piece_view(s, pieces[q][1], pieces[q][2])
             views[q] = (np.array(v, dtype=np.uint8, copy=True), shift)  # (a copy: the contig itself is released)
@@ -398,7 +398,6 @@ def strong_scaling_block(args, eng, group, use_rccl, fence, reduce):
             out["speedup_vs_n1"] = t1 / (dt_scan + dt_gather)
             out["efficiency_vs_n1"] = t1 / (dt_scan + dt_gather) / world
             out["efficiency_vs_n1_scan_only"] = t1 / dt_scan / world
-            out["_for_node_block"] = (kept_strings, want, dict(out["n1"]))  # (popped by main before the line is built)
             ref.close()
         fence()
     arena.close()
@@ -546,6 +545,15 @@ def main_single_process(args):
 
     def strings_of(wl):
         return [wl.contig_string(k) for k in range(len(wl.specs))]
+
+    if args.strong_only:
+        wl = make_workload(args, 0)
+        strong = node_strong_block(args, node, devices, wl.name, strings_of(wl), max(1, args.warmup))
+        print(json.dumps({"strong": strong, "n_gpus": world, "config": {"library_build": build_id, "device": info["name"].strip()}}), flush=True)
+        node.close()
+        if strong.get("digest_ok") is False:
+            sys.exit(1)
+        return
 
     # ---- weak workload: `world` genomes, generated side by side (numpy releases the GIL), ONE contig list
     t_gen = time.perf_counter()
@@ -1096,40 +1104,43 @@ def main():
         unguard()
 
     # ---- the same N devices through the library's single-process node handle (crp_node_*), on the strong
-    # block's genome: rank 0 opens a node over all of them -- its peers hold their own contexts on them and wait at the
-    # barrier below -- and runs scan + gatherv on RCCL in ONE process (ncclCommInitAll, one grouped send/recv) and as
-    # device-to-device copies, with the same digest check.  It runs on a helper thread: if it does not come back within
-    # --collective-timeout the line says so and the run still ends in order.
+    # block's genome.  Rank 0 starts a CHILD PROCESS -- `bench.py --gpus N --single-process --strong-only`: one fresh process
+    # that opens a node over all N devices (its peers here hold their own contexts on them and wait at the barrier below),
+    # cuts, scans, and runs the gatherv on RCCL-in-one-process (ncclCommInitAll, one grouped send/recv) and as device-to-
+    # device copies, digest-checked against its own N = 1 scan -- and puts the child's `strong` block into the line.  A child,
+    # not a thread: whatever goes wrong in there (a crash inside RCCL, a bootstrap that never returns: the child is killed
+    # after --collective-timeout) cannot take this rank or its line down.
     node_block = None
-    for_node = strong.pop("_for_node_block", None) if isinstance(strong, dict) else None
     if world > 1 and not args.no_node_block and not args.no_strong:
-        if rank == 0 and for_node and for_node[0]:
-            result = {}
-
-            def run_node_block():
-                try:
-                    from cropsr_amd import node as nd
-                    devices = [0] * world if args.share_gpu0 else list(range(world))
-                    with nd.Node(devices) as node:
-                        node.configure(two_pass=True if args.two_pass else None,
-                                       geometry=None if args.geometry == "auto" else args.geometry)
-                        result["block"] = node_strong_block(args, node, devices, genomes[0].name, for_node[0], max(1, args.warmup),
-                                                            want=for_node[1], n1=for_node[2])
-                except BaseException as e:
-                    import traceback
-                    traceback.print_exc()
-                    result["block"] = {"error": repr(e)[:300]}
-
-            worker = threading.Thread(target=run_node_block, name="node_block", daemon=True)
-            worker.start()
-            worker.join(args.collective_timeout if args.collective_timeout > 0 else None)
-            if worker.is_alive():
-                node_block = {"error": "did not return within %.0f s" % args.collective_timeout}
-                from cropsr_amd import engine as _engine
-                _engine._COMM_STUCK = True  # (a thread of this process sits inside RCCL: leave through os._exit at the end)
-            else:
-                node_block = result.get("block")
-            del for_node
+        if rank == 0:
+            import subprocess
+            cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(world), "--single-process", "--strong-only",
+                   "--steps", str(args.strong_steps or args.steps), "--warmup", str(args.warmup), "--workload", args.workload,
+                   "--scale", str(args.scale), "--geometry", args.geometry, "--cpu-sample-bases", "0",
+                   "--collective-timeout", str(args.collective_timeout)]
+            cmd += ["--share-gpu0"] if args.share_gpu0 else []
+            cmd += ["--two-pass"] if args.two_pass else []
+            cmd += ["--no-strong-check"] if args.no_strong_check else []
+            cmd += ["--fasta", args.fasta] if args.fasta else []
+            env = {k: v for k, v in os.environ.items()
+                   if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_ADDR",
+                                "MASTER_PORT", "CROPSR_LAUNCHED", "CROPSR_RDZV_ENDPOINT", "TORCHELASTIC_RUN_ID")}
+            t_child = time.perf_counter()
+            try:
+                limit = (args.collective_timeout + 120.0) if args.collective_timeout > 0 else None
+                p = subprocess.run(cmd, capture_output=True, text=True, timeout=limit, env=env, cwd=ROOT)
+                lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+                if lines:
+                    node_block = json.loads(lines[-1]).get("strong") or {"error": "the child printed no strong block"}
+                else:
+                    node_block = {"error": "the child printed no line (status %d): %s" % (p.returncode, p.stderr[-300:])}
+                if p.returncode != 0 and "error" not in node_block and node_block.get("digest_ok") is not False:
+                    node_block["child_status"] = p.returncode
+            except subprocess.TimeoutExpired:
+                node_block = {"error": "the child did not finish within %.0f s and was killed" % limit}
+            except Exception as e:
+                node_block = {"error": repr(e)[:300]}
+            node_block["wall_s_incl_process_start"] = round(time.perf_counter() - t_child, 3)
         group.barrier()
 
     # ---- the opt-in off-target seed scan of cfg 5 on the same resident genome and hit tables

@@ -22,8 +22,9 @@ python3 bench.py --workload ecoli --cpu-sample-bases 0 > $OUT/bench_ecoli_like.j
 # N = 2 started by the program itself, both ranks on this one GPU (host transport for fences and the final gatherv)
 python3 bench.py --gpus 2 --share-gpu0 --scale 0.25 --steps 10 --warmup 3 --cpu-sample-bases 0 \
     > $OUT/bench_2ranks_self_launched_one_gpu.json 2> $RAW/2ranks.err
-# six ranks on the one GPU (the most processes the pool lets one job keep on a card), weak headline + strong-scaling block
-python3 bench.py --gpus 6 --share-gpu0 --scale 0.25 --steps 10 --warmup 3 --cpu-sample-bases 0 --offtarget-steps 0 \
+# six ranks on the one GPU (the most processes the pool lets one job keep on a card: no room for rank 0's node-block child),
+# weak headline + strong-scaling block
+python3 bench.py --gpus 6 --share-gpu0 --scale 0.25 --steps 10 --warmup 3 --cpu-sample-bases 0 --offtarget-steps 0 --no-node-block \
     > $OUT/bench_6ranks_self_launched_one_gpu.json 2> $RAW/6ranks.err
 # ONE process over four logical devices (the library's node handle; on this one-GPU box they are GPU 0 four times, the exchange
 # runs as device-to-device copies): weak headline of 4 x 0.25 genomes, gatherv packed / raw, strong block with digest check

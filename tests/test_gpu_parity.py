@@ -887,7 +887,8 @@ def test_bench_starts_its_own_ranks(launcher):
     assert st["kept_hits"] == st["n1"]["kept_hits"] and 0 < st["efficiency_vs_n1"] <= st["efficiency_vs_n1_scan_only"]
     assert abs(st["per_rank"][0]["bases"] - st["per_rank"][1]["bases"]) < 0.02 * st["per_rank"][0]["bases"]
     assert all(r["tiles"] > 0 and r["kernel_ms"] > 0 for r in st["per_rank"])
-    # rank 0's closing block: the same devices through the single-process node handle, same genome, same digests
+    # rank 0's closing block: a child process drives the same devices through the single-process node handle -- same genome,
+    # digest-checked against its own N = 1 scan
     nb = d["single_process_node"]
     assert nb["digest_ok"] is True and nb["kept_hits"] == st["kept_hits"] and nb["gatherv_transport"] == "device-to-device copies", nb
     assert 0 < nb["bytes_to_root"] < nb["gatherv_raw_u32_positions"]["bytes_to_root"] and nb["devices"] == [0, 0]
@@ -905,8 +906,10 @@ def test_bench_four_ranks_on_the_one_gpu():
     import sys
     from conftest import ROOT
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "CROPSR_LAUNCHED")}
+    # (--no-node-block: rank 0's closing block is one more process on the card -- four ranks, the child and this test runner
+    # would be the six the pool allows; the two-rank test above runs it)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--share-gpu0", "--scale", "0.05",
-                        "--steps", "3", "--warmup", "1", "--offtarget-steps", "0"],
+                        "--steps", "3", "--warmup", "1", "--offtarget-steps", "0", "--no-node-block"],
                        capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
@@ -919,8 +922,7 @@ def test_bench_four_ranks_on_the_one_gpu():
     assert st["digest_ok"] is True and len(st["per_rank"]) == 4 and st["kept_hits"] == st["n1"]["kept_hits"], st
     shares = [r["bases"] for r in st["per_rank"]]
     assert max(shares) - min(shares) <= 6 * 4096 * 2
-    nb = d["single_process_node"]
-    assert nb["digest_ok"] is True and nb["kept_hits"] == st["kept_hits"] and len(nb["per_rank"]) == 4, nb
+    assert "single_process_node" not in d
     print("four ranks on one GPU: rendezvous %.2f-%.2f s, device HBM in use %.2f GiB; strong: scan %.3f ms + gatherv %.1f ms"
           % (min(r["rendezvous_s"] for r in d["per_rank"]), max(r["rendezvous_s"] for r in d["per_rank"]),
              max(r["device_hbm_in_use_GiB"] for r in d["per_rank"]), st["ms_scan_max_rank"], st["ms_gatherv"]))
