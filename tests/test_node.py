@@ -655,3 +655,16 @@ def test_node_threaded_scan_forced_on_one_gpu(tmp_path):
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout + r.stderr
     assert int(out.read_text()) > 300_000
+
+
+@pytest.mark.gpu
+def test_bench_single_process_one_device_and_strong_only():
+    """`--single-process` with ONE device is the N = 1 line through the node handle (CPU baseline included); `--strong-only`
+    is what rank 0 of a process-per-GPU run starts as its closing node block: just the strong block, digest-checked."""
+    d = _bench("--gpus", "1", "--single-process", "--scale", "0.01", "--steps", "3", "--warmup", "1", "--cpu-sample-bases", "20000")
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["cpu_baseline"]["kind"] == "port" and d["gpu_over_cpu"] > 10
+    assert "gatherv" not in d and "strong" not in d and d["roofline"]["frac"] > 0 and d["roofline"]["traffic_source"]
+    d = _bench("--gpus", "3", "--single-process", "--strong-only", "--share-gpu0", "--scale", "0.02", "--steps", "2", "--warmup", "1")
+    st = d["strong"]
+    assert set(d) == {"strong", "n_gpus", "config"} and st["digest_ok"] is True and len(st["per_rank"]) == 3 and st["devices"] == [0, 0, 0]
+    assert st["tables_to_the_host"]["every_device_over_its_own_link"]["ms"] > 0
