@@ -668,3 +668,39 @@ def test_bench_single_process_one_device_and_strong_only():
     st = d["strong"]
     assert set(d) == {"strong", "n_gpus", "config"} and st["digest_ok"] is True and len(st["per_rank"]) == 3 and st["devices"] == [0, 0, 0]
     assert st["tables_to_the_host"]["every_device_over_its_own_link"]["ms"] > 0
+
+
+@pytest.mark.gpu
+def test_integration_md_seam_snippets_run(oracle):
+    """The two ctypes patches INTEGRATION.md section B shows for `CROPSR.py` -- seam 2 (`rs1_score`) and seam 1 (the scan loops) --
+    executed as printed: `rs1_score` returns the oracle's bits for a batch (incl. the rows OpenBLAS sums in its tail order), and
+    the tables seam 1 ends up with are the oracle's, contig by contig."""
+    import ctypes
+    import types
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+
+    def block(after):
+        at = text.index(after)
+        code = text[text.index("```python", at) + len("```python"):]
+        return code[:code.index("```")]
+    seam2 = block("### Seam 2").replace('"/path/to/cropsr_amd/libcropsr_hip.so"', repr(os.path.join(ROOT, "cropsr_amd", "libcropsr_hip.so")))
+    seam1 = block("### Seam 1")
+    rng = np.random.default_rng(77)
+    contigs = _genome(rng, [120_000, 3_000, 64])
+    env = {"fasta_file": {"k%d" % k: c.decode("ascii") for k, c in enumerate(contigs)}, "args": types.SimpleNamespace(l=20)}
+    exec(seam2, env)
+    rows = rng.choice(np.frombuffer(b"ATCGN", dtype=np.uint8), size=(1003, 30))
+    got = env["rs1_score"](rows)
+    _, want = oracle.rs1_batch(rows)
+    assert (bits(got) == bits(want)).all()
+    assert (bits(env["rs1_score"](rows[:1])) == bits(oracle.rs1_batch(rows[:1])[1])).all()
+    exec(seam1, env)
+    offs, pos_p, sc_p, pos_m, sc_m = env["offs"], env["pos_p"], env["sc_p"], env["pos_m"], env["sc_m"]
+    for k, c in enumerate(contigs):
+        want = oracle.scan_score(c, 20)
+        sel = (pos_p >= offs[k]) & (pos_p < offs[k] + len(c))
+        assert (pos_p[sel] - offs[k] == want["pos_plus"]).all() and (bits(sc_p[sel]) == bits(want["score_plus"])).all()
+        sel = (pos_m >= offs[k]) & (pos_m < offs[k] + len(c))
+        assert (pos_m[sel] - offs[k] == want["pos_minus"]).all() and (bits(sc_m[sel]) == bits(want["score_minus"])).all()
+    env["_crp"].crp_arena_destroy(env["arena"])
+    env["_crp"].crp_destroy(env["_ctx"])
