@@ -232,16 +232,23 @@ def cpu_baseline(sample_string, n_bases):
 def load_profile_facts(build_id, workload):
     """HBM traffic and VALU instruction counts per launch of the emit kernel, from the committed
     rocprofv3 summary -- used only if it was measured on THIS build of the library and this workload."""
-    path = os.path.join(ROOT, "profiles", "traffic.json")
-    if not os.path.exists(path):
-        return None, "no profiles/traffic.json"
-    with open(path) as f:
-        tj = json.load(f)
-    if tj.get("workload") != workload or tj.get("kernel") != "emit_kernel":
-        return None, "profiles/traffic.json is for another workload"
-    if tj.get("build_id") != build_id:
-        return None, "profiles/traffic.json was measured on build %s, this is %s: stale, not used" % (tj.get("build_id"), build_id)
-    return tj, tj.get("source", "profiles/traffic.json")
+    import glob
+    # profiles/traffic.json is the headline workload's; profiles/traffic_<config>.json the smaller configs' (collect.sh rNN <config>)
+    paths = [os.path.join(ROOT, "profiles", "traffic.json")] + sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_*.json")))
+    why = "no profiles/traffic.json"
+    for path in paths:
+        if not os.path.exists(path):
+            continue
+        with open(path) as f:
+            tj = json.load(f)
+        name = "profiles/" + os.path.basename(path)
+        if tj.get("workload") != workload or tj.get("kernel") != "emit_kernel":
+            why = "no profiles/traffic*.json for this workload"
+            continue
+        if tj.get("build_id") != build_id:
+            return None, "%s was measured on build %s, this is %s: stale, not used" % (name, tj.get("build_id"), build_id)
+        return tj, tj.get("source", name)
+    return None, why
 
 
 def table_digests(per_contig):
