@@ -704,3 +704,25 @@ def test_integration_md_seam_snippets_run(oracle):
         assert (pos_m[sel] - offs[k] == want["pos_minus"]).all() and (bits(sc_m[sel]) == bits(want["score_minus"])).all()
     env["_crp"].crp_arena_destroy(env["arena"])
     env["_crp"].crp_destroy(env["_ctx"])
+
+
+@pytest.mark.gpu
+def test_cli_devices_command_line(tmp_path, manifest):
+    """The program itself: `python -m cropsr_amd --devices 0,0 ...` (no launcher, one process) writes the reference's CSV for
+    the sample genome, with and without CROPSR_GATHER=host; `--devices` together with `--gpus N` is refused."""
+    from conftest import GOLDEN, golden_fasta_path, read_golden_csv
+    fa = golden_fasta_path("sample", tmp_path)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "CROPSR_LAUNCHED", "CROPSR_GATHER")}
+    env["PYTHONPATH"] = ROOT
+    common = ["-f", fa, "-g", os.path.join(GOLDEN, "sample_head.gff"), "--cas9", "--seed", str(manifest["seed"])]
+    for tag, extra_env in (("rccl", {}), ("host", {"CROPSR_GATHER": "host"})):
+        d = tmp_path / tag
+        d.mkdir()
+        out = d / "out.csv"
+        p = subprocess.run([sys.executable, "-m", "cropsr_amd", "--devices", "0,0", "-o", str(out)] + common, capture_output=True,
+                           text=True, timeout=600, cwd=str(d), env=dict(env, **extra_env))
+        assert p.returncode == 0, p.stderr[-2000:]
+        assert out.read_bytes() == read_golden_csv("sample") and manifest["cases"]["sample"]["stdout"] in p.stdout
+    p = subprocess.run([sys.executable, "-m", "cropsr_amd", "--devices", "0,0", "--gpus", "2", "-o", str(tmp_path / "x.csv")] + common,
+                       capture_output=True, text=True, timeout=600, cwd=str(tmp_path), env=env)
+    assert p.returncode != 0 and "give one of them" in p.stderr
