@@ -68,6 +68,11 @@ SIGNATURES = {
     "crp_node_size": (ctypes.c_int, [ctypes.c_void_p]),
     "crp_node_ctx": (ctypes.c_void_p, [ctypes.c_void_p, ctypes.c_int]),
     "crp_node_arena": (ctypes.c_void_p, [ctypes.c_void_p, ctypes.c_int]),
+    "crp_node_arenas": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    "crp_node_arena_at": (ctypes.c_void_p, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]),
+    "crp_node_set_option": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int64]),
+    "crp_node_transport_note": (ctypes.c_char_p, [ctypes.c_void_p]),
+    "crp_node_comm_stuck": (ctypes.c_int, []),
     "crp_node_load": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), u64p, ctypes.c_uint64]),
     "crp_node_plan": (ctypes.c_int, [ctypes.c_void_p, u64p, ctypes.c_uint64, u64p]),
     "crp_node_scan_score": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, u64p, u64p]),
@@ -119,6 +124,7 @@ REDUCE_SUM, REDUCE_MAX = 0, 1
 COMM_ID_BYTES = 128
 GATHER_OFFTARGET, GATHER_PRE, GATHER_FEATURES, GATHER_POS16 = 1, 2, 4, 8
 NODE_PEER_COPY, NODE_HOST_GATHER = 16, 32
+NODE_OPT_ARENA_WORDS, NODE_OPT_COMM_INIT_TIMEOUT_MS, NODE_OPT_COLLECTIVE_TIMEOUT_MS = 1, 2, 3
 TRANSPORTS = {0: "none (one device)", 1: "RCCL (in-library, one process)", 2: "device-to-device copies",
               3: "none: every device's rows over its own PCIe link to the host"}
 HALO = 128
@@ -126,7 +132,7 @@ NO_FEATURE = 0xFFFFFFFF
 SCAN_PRE, SCAN_SEEDS = 1, 2
 OT_SEEDS = 1 << 24
 OT_NOT_A_SITE, OT_NOT_OWNED = 0xFFFFFFFF, 0xFFFFFFFE
-ABI_VERSION = 5
+ABI_VERSION = 6
 CRP_ERR_NO_DEVICE = -2
 CRP_ERR_CAPACITY = -6
 CRP_ERR_IO = -8

@@ -431,6 +431,11 @@ def run(args, backend=None, out=sys.stdout, group=None):
     if own_group:
         group = _distributed()
     max_piece = int(os.environ.get("CROPSR_DIST_MAX_PIECE", "0")) or None
+    if getattr(args, "devices", None) and group is not None and group.world > 1:
+        # an external launcher started several ranks AND the command line asks for one process over several devices: every
+        # rank would open every listed GPU, and only rank 0 would have a use for them
+        sys.exit("cropsr_amd: --devices (one process over several GPUs) cannot run under a launcher that started %d ranks "
+                 "(one process per GPU): give one of them" % group.world)
 
     def make_backend():
         if getattr(args, "devices", None):
@@ -673,6 +678,12 @@ def _leave(status):
     eng_mod = sys.modules.get(__package__ + ".engine")  # (only a run that opened the GPU has imported it)
     if eng_mod is not None:
         eng_mod.leave_if_comm_stuck(status)
+    node_mod = sys.modules.get(__package__ + ".node")  # (--devices: ncclCommInitAll runs on a helper thread of the library)
+    if node_mod is not None and node_mod.comm_stuck():
+        import os
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(status)
 
 
 def main(argv=None):

@@ -81,7 +81,8 @@ struct crp_comm {
     std::vector<uint64_t> counts;  // last gather: {n_plus, n_minus} per rank
     std::vector<uint64_t> raw;     // host copy of d_counts
     int test_fail = 0;             // test hook, environment CRP_TEST_GATHER_FAIL: 1 = the root's receive buffers
-                                   // "do not fit", 2 = the last rank's arena "has no tables"
+                                   // "do not fit", 2 = the last rank's arena "has no tables", 3 = the last rank sends
+                                   // one row too few of its score column (a protocol error only a checking transport sees)
     // root's receive side of the last crp_gather_hits: column-wise, peers back to back in rank order
     uint32_t *d_gpos[2] = {nullptr, nullptr};
     double *d_gscore[2] = {nullptr, nullptr};
@@ -390,7 +391,8 @@ int crp_gather_hits(crp_ctx *ctx, crp_arena *a, int root, int flags, uint64_t *c
                 st = r->Send(a->d_pos[s], mine[s], ncclUint32, root, c->comm, ctx->stream);
             }
             if (st == ncclSuccess)
-                st = r->Send(send_pre ? a->d_pre[s] : a->d_score[s], mine[s], ncclDouble, root, c->comm, ctx->stream);
+                st = r->Send(send_pre ? a->d_pre[s] : a->d_score[s], mine[s] - (c->test_fail == 3 && c->rank == c->world - 1 ? 1 : 0), ncclDouble,
+                             root, c->comm, ctx->stream);
             if (st == ncclSuccess && with_ot) st = r->Send(a->d_ot_cnt[s], 4 * mine[s], ncclUint32, root, c->comm, ctx->stream);
             if (st == ncclSuccess && with_feat) st = r->Send(a->d_feat[s], mine[s], ncclUint32, root, c->comm, ctx->stream);
         }

@@ -146,8 +146,9 @@ __global__ __launch_bounds__(BLOCK) void pos16_expand_kernel(const uint16_t *__r
     }
 }
 
-__global__ __launch_bounds__(BLOCK) void pos_rebase_kernel(const uint32_t *__restrict__ pos, uint64_t n, PieceMap map,
-                                                           uint32_t *__restrict__ out)
+// (pos and out may be the same array -- crp_node_gather rebases raw positions where they landed; every thread reads its rows
+// before it writes them -- so neither is __restrict__)
+__global__ __launch_bounds__(BLOCK) void pos_rebase_kernel(const uint32_t *pos, uint64_t n, PieceMap map, uint32_t *out)
 {
     const uint64_t i0 = ((uint64_t)blockIdx.x * BLOCK + threadIdx.x) * G_ROWS;
     if (i0 >= n) return;

@@ -39,6 +39,11 @@ class NodeError(nat.CropsrHipError):
     pass
 
 
+def comm_stuck():
+    """crp_node_comm_stuck: communicator bootstraps of this process whose helper thread never came back from RCCL."""
+    return int(nat.lib().crp_node_comm_stuck())
+
+
 class NodeHits:
     """The gathered tables of one Node.scan(): pos_* are positions LOCAL to their contig string (the regex match indices
     of CROPSR.py:418 / :429), contig after contig; `contig(k)` slices contig k's rows like engine.Hits.contig(k)."""
@@ -161,26 +166,59 @@ class Node:
         self.lengths = lens
 
     def plan(self):
-        """[dict(contig, start, end, device, arena_offset, halo_before)] -- the cut crp_node_load made."""
+        """[dict(contig, start, end, device, arena_offset, halo_before, arena)] -- the cut crp_node_load made (arena: which
+        of the device's arenas the piece lies in; a device has more than one only beyond 2^31 characters, or with
+        set_option(arena_words=...))."""
         n = ctypes.c_uint64()
         cap = self.n_contigs + self.size
-        out = np.zeros((cap, 6), dtype=np.uint64)
-        self._check(nat.lib().crp_node_plan(self._h, out.ctypes.data_as(nat.u64p), cap, ctypes.byref(n)), "crp_node_plan")
-        keys = ("contig", "start", "end", "device", "arena_offset", "halo_before")
+        out = np.zeros((cap, 7), dtype=np.uint64)
+        st = nat.lib().crp_node_plan(self._h, out.ctypes.data_as(nat.u64p), cap, ctypes.byref(n))
+        if st == nat.CRP_ERR_CAPACITY:  # (more arenas than devices: every further arena may add a piece)
+            cap = int(n.value)
+            out = np.zeros((cap, 7), dtype=np.uint64)
+            st = nat.lib().crp_node_plan(self._h, out.ctypes.data_as(nat.u64p), cap, ctypes.byref(n))
+        self._check(st, "crp_node_plan")
+        keys = ("contig", "start", "end", "device", "arena_offset", "halo_before", "arena")
         return [dict(zip(keys, (int(v) for v in row))) for row in out[:n.value]]
 
+    def set_option(self, arena_words=None, comm_init_timeout_s=None, collective_timeout_s=None):
+        """crp_node_set_option: most words per arena (0: the library's limit), and the two bounds on RCCL waits (seconds;
+        <= 0: none)."""
+        L = nat.lib()
+        if arena_words is not None:
+            self._check(L.crp_node_set_option(self._h, nat.NODE_OPT_ARENA_WORDS, int(arena_words)), "crp_node_set_option(arena_words)")
+        if comm_init_timeout_s is not None:
+            self._check(L.crp_node_set_option(self._h, nat.NODE_OPT_COMM_INIT_TIMEOUT_MS, int(round(comm_init_timeout_s * 1000))),
+                        "crp_node_set_option(comm_init_timeout)")
+        if collective_timeout_s is not None:
+            self._check(L.crp_node_set_option(self._h, nat.NODE_OPT_COLLECTIVE_TIMEOUT_MS, int(round(collective_timeout_s * 1000))),
+                        "crp_node_set_option(collective_timeout)")
+
+    def n_arenas(self, k):
+        return int(nat.lib().crp_node_arenas(self._h, int(k)))
+
+    def _arenas(self, k):
+        L = nat.lib()
+        return [ctypes.c_void_p(L.crp_node_arena_at(self._h, int(k), j)) for j in range(self.n_arenas(k))]
+
     def arena_stats(self, k):
-        """dict(n_chars, n_tiles, geometry) of logical device k's arena, or None if it got no piece."""
-        a = nat.lib().crp_node_arena(self._h, int(k))
-        if not a:
+        """dict(n_texts, n_chars, n_tiles, geometry, n_arenas) of logical device k's arenas together, or None if it got no
+        piece."""
+        arenas = self._arenas(k)
+        if not arenas:
             return None
-        a = ctypes.c_void_p(a)
-        nc, nch, nw = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
-        nat.check(nat.lib().crp_arena_stats(a, ctypes.byref(nc), ctypes.byref(nch), ctypes.byref(nw)), "crp_arena_stats")
-        g, nt, tw = ctypes.c_int(), ctypes.c_uint64(), ctypes.c_uint64()
-        nat.check(nat.lib().crp_arena_tiles(a, ctypes.byref(g), ctypes.byref(nt), ctypes.byref(tw)), "crp_arena_tiles")
-        name = [key for key, v in nat.GEOMETRIES.items() if v == g.value][0]
-        return dict(n_texts=int(nc.value), n_chars=int(nch.value), n_tiles=int(nt.value), geometry=name)
+        out = dict(n_texts=0, n_chars=0, n_tiles=0, geometry=None, n_arenas=len(arenas))
+        for a in arenas:
+            nc, nch, nw = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
+            nat.check(nat.lib().crp_arena_stats(a, ctypes.byref(nc), ctypes.byref(nch), ctypes.byref(nw)), "crp_arena_stats")
+            g, nt, tw = ctypes.c_int(), ctypes.c_uint64(), ctypes.c_uint64()
+            nat.check(nat.lib().crp_arena_tiles(a, ctypes.byref(g), ctypes.byref(nt), ctypes.byref(tw)), "crp_arena_tiles")
+            name = [key for key, v in nat.GEOMETRIES.items() if v == g.value][0]
+            out["n_texts"] += int(nc.value)
+            out["n_chars"] += int(nch.value)
+            out["n_tiles"] += int(nt.value)
+            out["geometry"] = name if out["geometry"] in (None, name) else "mixed"
+        return out
 
     # ---- seam 1 + 2 on every device at once
     def scan_score_device(self, guide_len=20, want_pre=False, want_seeds=False):
@@ -227,7 +265,7 @@ class Node:
         self._check(nat.lib().crp_node_gather_stats(self._h, ctypes.byref(ms_t), ctypes.byref(ms_x), ctypes.byref(nb), ctypes.byref(tr)),
                     "crp_node_gather_stats")
         return dict(ms_total=ms_t.value, ms_exchange=ms_x.value, bytes_to_root=int(nb.value), transport=nat.TRANSPORTS[tr.value],
-                    note=nat.lib().crp_node_last_error(self._h).decode() if tr.value == 2 else "")  # (why RCCL did not run, if it was asked for)
+                    note=nat.lib().crp_node_transport_note(self._h).decode())  # (why RCCL is not / no longer in use: "" while it is)
 
     def counts(self):
         """(per_contig (n, 2) uint64, n_plus, n_minus) of the last gather."""
@@ -245,22 +283,30 @@ class Node:
 
     def device_counts(self, k):
         """dict(n_plus, n_minus, n_scored) of logical device k's OWN tables (rows inside its halos included), or None."""
-        a = nat.lib().crp_node_arena(self._h, int(k))
-        if not a:
+        arenas = self._arenas(k)
+        if not arenas:
             return None
-        a = ctypes.c_void_p(a)
-        x, y, z = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
-        nat.check(nat.lib().crp_hits_counts(a, ctypes.byref(x), ctypes.byref(y)), "crp_hits_counts")
-        nat.check(nat.lib().crp_count_scored(a, ctypes.byref(z)), "crp_count_scored")
-        return dict(n_plus=x.value, n_minus=y.value, n_scored=z.value)
+        out = dict(n_plus=0, n_minus=0, n_scored=0)
+        for a in arenas:
+            x, y, z = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
+            nat.check(nat.lib().crp_hits_counts(a, ctypes.byref(x), ctypes.byref(y)), "crp_hits_counts")
+            nat.check(nat.lib().crp_count_scored(a, ctypes.byref(z)), "crp_count_scored")
+            out["n_plus"] += x.value
+            out["n_minus"] += y.value
+            out["n_scored"] += z.value
+        return out
 
     def arena_composition(self, k):
-        a = nat.lib().crp_node_arena(self._h, int(k))
-        if not a:
+        arenas = self._arenas(k)
+        if not arenas:
             return None
-        x, y = ctypes.c_uint64(), ctypes.c_uint64()
-        nat.check(nat.lib().crp_arena_composition(ctypes.c_void_p(a), ctypes.byref(x), ctypes.byref(y)), "crp_arena_composition")
-        return dict(n_plain=x.value, n_other=y.value)
+        out = dict(n_plain=0, n_other=0)
+        for a in arenas:
+            x, y = ctypes.c_uint64(), ctypes.c_uint64()
+            nat.check(nat.lib().crp_arena_composition(a, ctypes.byref(x), ctypes.byref(y)), "crp_arena_composition")
+            out["n_plain"] += x.value
+            out["n_other"] += y.value
+        return out
 
     def fetch(self, guide_len=20, out=None):
         """Host copies of the gathered tables -> NodeHits.  out: the NodeHits of an earlier fetch of the same size -- its

@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define CRP_ABI_VERSION 5
+#define CRP_ABI_VERSION 6
 
 typedef enum crp_status {
     CRP_OK = 0,
@@ -321,13 +321,48 @@ int crp_node_destroy(crp_node *node);
 const char *crp_node_last_error(const crp_node *node);
 int crp_node_size(const crp_node *node);           /* number of logical devices (negative status on a NULL handle) */
 crp_ctx *crp_node_ctx(crp_node *node, int k);      /* logical device k's context (NULL: out of range) */
-crp_arena *crp_node_arena(crp_node *node, int k);  /* its arena after crp_node_load (NULL: none -- the device got no piece) */
+crp_arena *crp_node_arena(crp_node *node, int k);  /* its (first) arena after crp_node_load (NULL: none -- the device got no piece) */
+/* A device's share is packed into as many arenas as it needs (one arena addresses fewer than 2^31 characters; the
+ * reference reads a genome of any size whole, CROPSR.py:59): a share beyond one arena goes on in the next, and a piece that
+ * no arena can hold is cut again, with halos like every other cut.  Scan, the two opt-in steps, the ownership cuts and the
+ * gatherv run arena by arena inside the library; the caller sees one table per strand as before.  crp_node_arenas: how
+ * many arenas logical device k holds (negative status: bad argument); crp_node_arena_at: its j-th one. */
+int crp_node_arenas(const crp_node *node, int k);
+crp_arena *crp_node_arena_at(crp_node *node, int k, int j);
+/* Knobs of a node (the environment sets the defaults at crp_node_init):
+ *   CRP_NODE_OPT_ARENA_WORDS            most 64-character words one arena of the node may hold; 0 = crp_arena_max_words().
+ *                                       Smaller values only make more arenas (tests; a way to bound one allocation).
+ *   CRP_NODE_OPT_COMM_INIT_TIMEOUT_MS   how long ncclCommInitAll may take (it runs on a helper thread; default 180 000,
+ *                                       environment CRP_NODE_COMM_INIT_TIMEOUT_S): a bootstrap that has not returned by then
+ *                                       is left behind (crp_node_comm_stuck) and the node goes on as device-to-device
+ *                                       copies, or fails with CRP_ERR_COMM if RCCL was asked for by name
+ *                                       (CRP_NODE_TRANSPORT=rccl).  <= 0: no bound.
+ *   CRP_NODE_OPT_COLLECTIVE_TIMEOUT_MS  how long the grouped send/recv of crp_node_gather and the histogram all-reduce
+ *                                       of crp_node_offtarget may take (default 300 000, environment
+ *                                       CRP_NODE_COLLECTIVE_TIMEOUT_S): RCCL has no time-out of its own, so the streams are
+ *                                       awaited by polling an event.  When the bound runs out the communicators are
+ *                                       aborted (ncclCommAbort) and never used again by this node; the call then starts over
+ *                                       on the device-to-device transport from fresh state and returns CRP_OK (crp_node_last_error
+ *                                       and crp_node_transport_note say what happened) -- or, with CRP_NODE_TRANSPORT=rccl,
+ *                                       returns CRP_ERR_COMM naming the stage.  <= 0: no bound. */
+#define CRP_NODE_OPT_ARENA_WORDS 1
+#define CRP_NODE_OPT_COMM_INIT_TIMEOUT_MS 2
+#define CRP_NODE_OPT_COLLECTIVE_TIMEOUT_MS 3
+int crp_node_set_option(crp_node *node, int option, int64_t value);
+/* Why RCCL is not (or no longer) this node's transport -- "" while it is, or was never wanted. */
+const char *crp_node_transport_note(const crp_node *node);
+/* Communicator bootstraps of this PROCESS that never returned: their helper threads still sit inside RCCL, and the
+ * runtime's tear-down at a normal exit may wait for them -- a program that sees a non-zero value should flush its output
+ * and leave through _exit (cropsr_amd/cli.py does). */
+int crp_node_comm_stuck(void);
 /* The genome: n contig strings, in order (the strings CROPSR.py:409 iterates over).  Cuts (crp_plan_shares), uploads
  * share r to device r (one host thread per device), seals.  The caller's strings are read, not kept.  A second call
- * replaces the genome. */
+ * replaces the genome.  Any total size; a single contig string may have at most 2^32 - 1 characters (the tables carry
+ * contig-local positions as 32 bits): CRP_ERR_CAPACITY names a longer one. */
 int crp_node_load(crp_node *node, const uint8_t *const *texts, const uint64_t *lens, uint64_t n);
-/* The cut that was made: 6 x uint64 per piece {contig, start, end, device, arena offset of the piece's text on that
- * device, index of `start` inside that text (the left halo's length)}.  Same capacity protocol as crp_plan_shares. */
+/* The cut that was made: 7 x uint64 per piece {contig, start, end, device, arena offset of the piece's text in its
+ * arena, index of `start` inside that text (the left halo's length), which of the device's arenas}.  Same capacity
+ * protocol as crp_plan_shares; at most n + world - 1 pieces plus one per arena beyond a device's first. */
 int crp_node_plan(const crp_node *node, uint64_t *pieces, uint64_t cap, uint64_t *n_pieces);
 /* crp_scan_score on every device at once (same guide_len / flags).  *n_plus / *n_minus (may be NULL): rows of all
  * devices' tables together, INCLUDING the few hits inside halos (at most 2 x CRP_HALO positions per device); the
@@ -350,7 +385,9 @@ int crp_node_annotate(crp_node *node, const struct crp_annotation *annotation, c
  * pre-sigmoid sum), CRP_GATHER_POS16 (10 B per hit on the links instead of 12, see above), CRP_GATHER_OFFTARGET /
  * CRP_GATHER_FEATURES (the columns of the two steps above travel too),
  * CRP_NODE_PEER_COPY (device-to-device copies instead of RCCL for this call; always the case when a device is
- * listed twice, or when the environment says CRP_NODE_TRANSPORT=peer). */
+ * listed twice, or when the environment says CRP_NODE_TRANSPORT=peer).  CRP_NODE_TRANSPORT=rccl: RCCL or CRP_ERR_COMM (no
+ * falling back; also with a device listed twice, where the real RCCL refuses the clique); CRP_NODE_TRANSPORT=try: RCCL
+ * is attempted even with a device listed twice and given up for device-to-device copies like in the default mode. */
 #define CRP_NODE_PEER_COPY 16
 /* CRP_NODE_HOST_GATHER: for a consumer that lives on the HOST (the reference's consumer does: csv.writer, CROPSR.py:471-474).
  * Nothing crosses xGMI and no table is built on `root`: the call makes the ownership cuts and the counts, every device

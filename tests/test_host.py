@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), name
     assert sorted(nat.SIGNATURES) == declared
-    assert L.crp_abi_version() == nat.ABI_VERSION == 5
+    assert L.crp_abi_version() == nat.ABI_VERSION == 6
     assert b"no CPU fallback" in L.crp_strerror(nat.CRP_ERR_NO_DEVICE)
 
 
