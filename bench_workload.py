@@ -141,6 +141,19 @@ def sorghum_like():
     return Workload("sorghum-like-730Mb", specs, gc=0.44, soft_mask=0.60, n_frac=0.01)
 
 
+def maize_like():
+    """A genome beyond one arena (2^31 characters): 10 chromosomes (150-310 Mb) + 300 scaffolds (1-300 kb), ~2.4 Gb like
+    Zea mays B73 v4, GC 0.47, 85 % soft-masked, 0.5 % N.  Not a BASELINE.json config: the size the node handle's
+    several-arenas-per-device path is held to (the reference reads a genome of any size whole, CROPSR.py:59)."""
+    rng = np.random.default_rng(np.random.SeedSequence([6, 0]))
+    chrom, scaf = _lengths(rng, 10, 150_000_000, 310_000_000, 300, 1_000, 300_000)
+    f = (2.4e9 - sum(scaf)) / sum(chrom)
+    chrom = [int(c * f) for c in chrom]
+    specs = [ContigSpec("chr%d" % (i + 1), n, (6, 0, i)) for i, n in enumerate(chrom)]
+    specs += [ContigSpec("B73V4_ctg%d" % (i + 1), n, (6, 0, 1000 + i)) for i, n in enumerate(scaf)]
+    return Workload("maize-like-2.4Gb", specs, gc=0.47, soft_mask=0.85, n_frac=0.005)
+
+
 def ecoli_like():
     """cfg 2 stand-in: one 4 641 652-base contig, GC 0.508, upper case, no N."""
     return Workload("ecoli-like-4.6Mb", [ContigSpec("NC_000913", 4_641_652, (2, 0, 0))],

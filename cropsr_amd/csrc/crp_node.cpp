@@ -733,6 +733,7 @@ static int node_load_impl(crp_node *node, const uint8_t *const *texts, const uin
                 }
                 p.slot = (uint32_t)(d.n_slots - 1);
                 sl->words += need;
+                if (p.end != end) sl->words = limit;  // a piece that ends inside its contig closes its arena: one run per table
                 sl->pieces.push_back((uint32_t)node->pieces.size());
                 node->pieces.push_back(p);
                 if (p.end == end) break;

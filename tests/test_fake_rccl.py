@@ -181,6 +181,33 @@ def _child_fuzz(out, trials, seed):
     _write(out, {"hits": total, "cuts": cuts, "stats": fake_rccl.in_process_stats()})
 
 
+def _child_arenas(out, world, words):
+    """Several arenas per device (a tiny per-arena limit) with the exchange on RCCL: a device posts one run of sends per
+    arena, the root the matching receives, in the same order."""
+    import fake_rccl
+    import test_node as tn
+    from cropsr_amd import node as nd
+    from oracle import oracle
+    rng = np.random.default_rng(77 + world)
+    contigs = tn._genome(rng, [260_000, 5, 0, 70_000, 123_457, 64, 40_000])
+    want_ot = oracle.offtarget_genome(contigs, 20)
+    total = 0
+    with nd.Node([0] * world) as node:
+        node.set_option(arena_words=words)
+        node.load(contigs)
+        n_arenas = [node.n_arenas(k) for k in range(world)]
+        assert max(n_arenas) > 1
+        for l, kw in ((20, {}), (20, {"pos16": False, "root": world - 1}), (23, {"pre": True})):
+            hits = node.scan(l, **kw)
+            assert node.gather_stats()["transport"] == RCCL_NAME
+            total += tn._check_against_oracle(hits, contigs, oracle, l, (world, words, l, kw), pre=kw.get("pre", False))
+        hits = node.scan(20, offtarget=True)
+        for k in range(len(contigs)):
+            got = hits.contig(k)
+            assert (got["ot_plus"] == want_ot[k]["ot_plus"]).all() and (got["ot_minus"] == want_ot[k]["ot_minus"]).all(), k
+    _write(out, {"hits": total, "n_arenas": n_arenas, "stats": fake_rccl.in_process_stats()})
+
+
 def _child_failure(out, world, mode):
     """One failure injected (miscount: the root posts one receive 8 bytes short; hang_init / hang_group: the double never
     returns / never completes): what the calls return, how long they took, what the node says, and -- where the node is
@@ -251,6 +278,17 @@ def test_node_offtarget_and_annotation_on_rccl_double(world, tmp_path):
         assert r["n_feat"] > 5_000
         st = r["stats"]
         assert st["collectives"] == 2 and st["pairs"] > 20 and st["mismatches"] == 0, st
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,words", [(2, 600), (3, 137)])
+def test_node_several_arenas_per_device_on_rccl_double(world, words):
+    import fake_rccl
+    with fake_rccl.Session(CRP_NODE_TRANSPORT="rccl") as s:
+        p, r = s.run_child("_child_arenas", world, words)
+        assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+        n_peer_arenas = sum(r["n_arenas"]) - r["n_arenas"][0]
+        assert r["hits"] > 100_000 and r["stats"]["mismatches"] == 0 and r["stats"]["pairs"] > 4 * n_peer_arenas, r
 
 
 @pytest.mark.gpu

@@ -432,6 +432,112 @@ def test_node_offtarget_and_annotation_vs_oracle(oracle, world, tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("world", [1, 2, 4])
+def test_node_several_arenas_per_device_vs_oracle(oracle, world, tmp_path):
+    """A share larger than one arena (forced here with a tiny per-arena limit; for real beyond 2^31 characters per device --
+    the reference reads any genome whole, CROPSR.py:59): the share goes on in further arenas, a piece no arena can hold is cut
+    again with halos, and scan, ownership cuts, gatherv (packed, raw, to the host, another root, pre-sigmoid), off-target
+    counts and label-set ids all run arena by arena -- per contig the oracle's rows, whatever the limit."""
+    from cropsr_amd import annotate, node as nd
+    from oracle import annotate_oracle
+    rng = np.random.default_rng(900 + world)
+    lengths = [300_000, 5, 0, 70_000, 9_000, 123_457, 64, 1, 40_000]
+    contigs = _genome(rng, lengths)
+    block = rng.choice(ALPHA, 30_000).tobytes()  # a repeat across arenas and devices: seeds recur
+    contigs[0] = contigs[0][:100_000] + block + contigs[0][130_000:]
+    contigs[5] = contigs[5][:60_000] + block + contigs[5][90_000:]
+    gff = tmp_path / "arenas.gff"
+    rows = ["##gff-version 3"]
+    for k, n in enumerate(lengths):
+        for g in range(n // 15_000):
+            a = 1 + g * 15_000 + int(rng.integers(0, 4_000))
+            b = min(n, a + int(rng.integers(300, 12_000)))
+            if b > a:
+                rows.append("c%d\tsrc\tgene\t%d\t%d\t.\t+\t.\tID=g%d_%d" % (k, a, b, k, g))
+    gff.write_text("\n".join(rows) + "\n")
+    ann = annotate.Annotation(str(gff))
+    req = annotate.Request(ann, ["c%d" % k for k in range(len(contigs))], 1)
+    want_ot = oracle.offtarget_genome(contigs, 20)
+    with nd.Node([0] * world) as node:
+        with pytest.raises(Exception):
+            node.set_option(arena_words=3)  # (not even one piece between two halos)
+        for words in (600, 137, 2000):  # 38 400, 8 768 and 128 000 characters per arena
+            node.set_option(arena_words=words)
+            node.load(contigs)
+            plan = node.plan()
+            n_arenas = [node.n_arenas(k) for k in range(world)]
+            assert sum(n_arenas) == len({(p["device"], p["arena"]) for p in plan}) and max(n_arenas) > 1, (words, n_arenas)
+            assert len(plan) > len(contigs) + world - 1  # pieces were cut again at arena ends
+            for k, c in enumerate(contigs):  # the pieces still cover every contig once, in order
+                mine = [p for p in plan if p["contig"] == k]
+                assert mine[0]["start"] == 0 and mine[-1]["end"] == len(c) and all(a["end"] == b["start"] for a, b in zip(mine, mine[1:]))
+            st = node.arena_stats(0)
+            assert st["n_arenas"] == n_arenas[0] and st["n_chars"] <= n_arenas[0] * words * 64
+            for l, kw in ((20, {}), (20, {"pos16": False}), (20, {"to_host": True}), (20, {"pre": True, "root": world - 1}),
+                          (23, {"to_host": True, "pre": True}), (7, {"pos16": False})):
+                hits = node.scan(l, **kw)
+                _check_against_oracle(hits, contigs, oracle, l, (world, words, l, kw), pre=kw.get("pre", False))
+                if kw.get("to_host"):
+                    assert node.count_scored() == int((hits.score_plus != -1).sum() + (hits.score_minus != -1).sum())
+            for kw in ({}, {"to_host": True}, {"pos16": False, "root": world - 1}):
+                hits = node.scan(20, offtarget=True, annotation=req, **kw)
+                n_feat = 0
+                for k, c in enumerate(contigs):
+                    got, want = hits.contig(k), oracle.scan_score(c, 20)
+                    for key in ("pos_plus", "score_plus", "pos_minus", "score_minus"):
+                        assert (bits(got[key]) == bits(want[key])).all(), (world, words, kw, k, key)
+                    assert (got["ot_plus"] == want_ot[k]["ot_plus"]).all() and (got["ot_minus"] == want_ot[k]["ot_minus"]).all(), (world, words, kw, k)
+                    fp, fm = annotate_oracle.host_join(ann, "c%d" % k, 0, 1, got, 20, len(c))
+                    assert (got["feat_plus"] == fp).all() and (got["feat_minus"] == fm).all(), (world, words, kw, k)
+                    n_feat += int((fp != annotate.NO_FEATURE).sum() + (fm != annotate.NO_FEATURE).sum())
+                assert n_feat > 5_000
+        node.set_option(arena_words=0)  # back to the library's limit: one arena per device again
+        node.load(contigs)
+        assert [node.n_arenas(k) for k in range(world)] == [1 if any(p["device"] == k for p in node.plan()) else 0 for k in range(world)]
+        _check_against_oracle(node.scan(20), contigs, oracle, 20, (world, "default"))
+    ann.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.slow
+def test_node_maize_size_genome_on_one_device_equals_engine_genome():
+    """VERDICT r05 #3's full-size run: a 2.4 Gb maize-size stand-in (more than the 2^31 characters one arena addresses)
+    through Node([0]) -- one device, two arenas inside the handle -- == Engine.genome's tables (the path that already spread
+    a genome over arenas) by SHA-256 per contig, gathered on the device and over the host links."""
+    import bench_workload as bw
+    from cropsr_amd import Engine, node as nd
+
+    def digest(h):
+        d = hashlib.sha256()
+        for key in ("pos_plus", "score_plus", "pos_minus", "score_minus"):
+            d.update(np.ascontiguousarray(h[key]).tobytes())
+        return d.hexdigest()
+
+    wl = bw.maize_like()
+    strings = [wl.contig_string(k) for k in range(len(wl.specs))]
+    total = sum(s.size for s in strings)
+    assert total > (1 << 31)
+    with Engine(0) as eng:
+        genome = eng.genome(strings)
+        assert len(genome.arenas) >= 2
+        one = genome.scan_score(20)
+        want = [digest(one.contig(k)) for k in range(len(strings))]
+        n_hits = one.n_plus + one.n_minus
+        del one
+        genome.close()
+    with nd.Node([0]) as node:
+        node.load(strings)
+        assert node.n_arenas(0) >= 2 and node.arena_stats(0)["n_chars"] == total
+        for kw in ({}, {"to_host": True}):
+            hits = node.scan(20, **kw)
+            got = [digest(hits.contig(k)) for k in range(len(strings))]
+            assert got == want, (kw, [k for k in range(len(strings)) if got[k] != want[k]][:10])
+            assert hits.n_plus + hits.n_minus == n_hits
+            del hits
+    print("node maize-like on one device: %d characters, %d arenas, %d hits" % (total, 2, n_hits))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name,extra", [("sample", ()), ("multi", ()), ("mixed", ("--score-finalize", "host")),
                                         ("mixed", ("-l", "23")), ("rightend", ("-l", "64"))])
 def test_cli_devices_csv_bytes_equal_reference(name, extra, manifest, tmp_path, monkeypatch):
