@@ -61,6 +61,11 @@ SIGNATURES = {
     "crp_gather_hits": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, u64p]),
     "crp_gathered_fetch": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, u32p, f64p, u32p, u32p, f64p, u32p]),
     "crp_gathered_fetch_features": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, u32p, u32p]),
+    "crp_scan_stream": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), u64p, ctypes.c_uint64, ctypes.c_int, ctypes.c_int,
+                                       ctypes.c_uint64, u32p, f64p, ctypes.c_uint64, u32p, f64p, ctypes.c_uint64, u64p, u64p, u64p, f64p]),
+    "crp_scan_stream_prepare": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64]),
+    "crp_host_alloc": (ctypes.c_int, [ctypes.c_uint64, voidpp]),
+    "crp_host_free": (ctypes.c_int, [ctypes.c_void_p]),
     "crp_plan_shares": (ctypes.c_int, [u64p, ctypes.c_uint64, ctypes.c_int, ctypes.c_uint64, u64p, ctypes.c_uint64, u64p]),
     "crp_node_init": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_int), voidpp]),
     "crp_node_destroy": (ctypes.c_int, [ctypes.c_void_p]),

@@ -76,6 +76,45 @@ void parallel_copy(void *dst, const void *src, size_t n, int threads)
         if (pool[k].joinable()) pool[k].join();
 }
 
+// several copies at once, the bytes of all of them dealt evenly to the threads (a slice's four table columns are 5-20 MB
+// each: one after the other they would never occupy more than a few threads)
+void parallel_copy_multi(const CopySeg *segs, int n_segs, int threads)
+{
+    size_t total = 0;
+    for (int i = 0; i < n_segs; ++i) total += segs[i].bytes;
+    if (!total) return;
+    constexpr size_t MIN_PER_THREAD = 1ull << 20;
+    constexpr int MAX_THREADS = 64;
+    const int tt = (int)std::max<size_t>(1, std::min<size_t>(std::min(threads, MAX_THREADS), total / MIN_PER_THREAD));
+    const size_t per_t = ((total + tt - 1) / tt + 4095) & ~(size_t)4095;
+    auto work = [=](int k) {  // thread k takes the bytes [k * per_t, (k + 1) * per_t) of the concatenation
+        size_t lo = per_t * (size_t)k, hi = std::min(total, lo + per_t), base = 0;
+        for (int i = 0; i < n_segs && lo < hi; ++i) {
+            const size_t end = base + segs[i].bytes;
+            if (lo < end) {
+                const size_t a = lo - base, b = std::min(hi, end) - base;
+                std::memcpy(static_cast<uint8_t *>(segs[i].dst) + a, static_cast<const uint8_t *>(segs[i].src) + a, b - a);
+                lo = base + b;
+            }
+            base = end;
+        }
+    };
+    std::thread pool[MAX_THREADS];
+    bool started[MAX_THREADS] = {};
+    for (int k = 1; k < tt; ++k) {
+        try {
+            pool[k] = std::thread(work, k);
+            started[k] = true;
+        } catch (...) {
+        }
+    }
+    work(0);
+    for (int k = 1; k < tt; ++k) {
+        if (started[k]) pool[k].join();
+        else work(k);
+    }
+}
+
 int staging_ready(crp_ctx *ctx)
 {
     if (ctx->pin[0]) return CRP_OK;
@@ -96,8 +135,25 @@ static int pin_wait(crp_ctx *ctx, int b)
     return CRP_OK;
 }
 
+// host memory the GPU can reach by DMA (crp_host_alloc, hipHostMalloc, hipHostRegister): no staging copy needed
+bool is_pinned_host(const void *p)
+{
+    hipPointerAttribute_t attr;
+    const hipError_t e = hipPointerGetAttributes(&attr, p);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();  // (pageable memory: "invalid value", not an error of the caller's)
+        return false;
+    }
+    return attr.type == hipMemoryTypeHost;
+}
+
 int staged_h2d(crp_ctx *ctx, void *d_dst, const void *src, size_t n)
 {
+    if (n >= STAGE_CHUNK / 4 && is_pinned_host(src)) {  // straight off the caller's pinned pages; the caller keeps them until the stream has passed
+        CRP_HIP(ctx, hipMemcpyAsync(d_dst, src, n, hipMemcpyHostToDevice, ctx->stream));
+        CRP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return CRP_OK;
+    }
     if (n < STAGE_CHUNK / 4) {  // small: the runtime's own path (which returns once `src` has been read)
         if (n) CRP_HIP(ctx, hipMemcpyAsync(d_dst, src, n, hipMemcpyHostToDevice, ctx->stream));
         return CRP_OK;
@@ -119,7 +175,7 @@ int staged_h2d(crp_ctx *ctx, void *d_dst, const void *src, size_t n)
 
 int staged_d2h(crp_ctx *ctx, void *dst, const void *d_src, size_t n)
 {
-    if (n < STAGE_CHUNK / 4) {
+    if (n < STAGE_CHUNK / 4 || is_pinned_host(dst)) {  // small, or DMA straight into the caller's pinned pages
         if (n) {
             CRP_HIP(ctx, hipMemcpyAsync(dst, d_src, n, hipMemcpyDeviceToHost, ctx->stream));
             CRP_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -256,6 +312,7 @@ int crp_destroy(crp_ctx *ctx)
     (void)hipFree(ctx->d_ot_part1);
     (void)hipFree(ctx->d_ot_bucket);
     crp::comm_release(ctx);
+    crp::stream_release(ctx);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return CRP_OK;
@@ -433,12 +490,17 @@ int crp_arena_add_contig_ascii(crp_arena *a, const uint8_t *text, uint64_t len, 
     // all contigs, and nothing here waits for the GPU except for a pinned buffer that is still on the link: the call
     // returns when `text` has been read (crp_arena_seal waits for the uploads).  A small contig costs a memcpy and
     // two asynchronous calls, not a stream synchronisation.
+    // (a string in pinned memory -- crp_host_alloc -- is read by DMA straight off its pages: no staging copy; the caller keeps
+    // it until crp_arena_seal)
+    const bool direct = len >= kUploadChunk / 4 && crp::is_pinned_host(text);
     uint64_t c0 = 0;
     do {
         const uint64_t c1 = std::min<uint64_t>(len, c0 + kUploadChunk);
         const bool last = c1 == len;
         const uint64_t w0 = c0 / 64, w1 = last ? n_words : c1 / 64;
-        if (c1 > c0) {
+        if (c1 > c0 && direct) {
+            CRP_HIP(ctx, hipMemcpyAsync(ctx->d_text, text + c0, c1 - c0, hipMemcpyHostToDevice, ctx->stream));
+        } else if (c1 > c0) {
             const int b = ctx->pin_next;
             ctx->pin_next ^= 1;
             if (ctx->pin_busy[b]) {
@@ -581,7 +643,9 @@ static int chain_headers_point_at_host(crp_arena *a)
     return CRP_OK;
 }
 
-int crp_arena_seal(crp_arena *a)
+// sync = false (crp_stream.cpp): nothing here needs the host to wait -- the scratch is zeroed and the headers written in
+// stream order, before whatever scan is queued next
+static int arena_seal_impl(crp_arena *a, bool sync)
 {
     if (!a) return CRP_ERR_INVALID;
     if (a->sealed) return CRP_OK;
@@ -596,20 +660,33 @@ int crp_arena_seal(crp_arena *a)
     const uint64_t tw = (uint64_t)crp::tile_words(a->geo);
     const uint64_t eff = round_up(a->used_words, tw);  // <= padded_words
     a->n_tiles = (uint32_t)(eff / tw);
-    CRP_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&a->d_tile_cnt), a->n_tiles * sizeof(uint2)));
-    CRP_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&a->d_tile_off), a->n_tiles * sizeof(uint2)));
-    for (int b = 0; b < 2; ++b) {
-        CRP_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&a->d_chain[b]), crp::chain_bytes(a->n_tiles)));
-        CRP_HIP(ctx, hipMemsetAsync(a->d_chain[b], 0, crp::chain_bytes(a->n_tiles), ctx->stream));
+    if (a->n_tiles > a->tile_cap) {  // (an arena that is reset and filled again keeps its scratch: crp::arena_reset)
+        (void)hipFree(a->d_tile_cnt);
+        (void)hipFree(a->d_tile_off);
+        (void)hipFree(a->d_chain[0]);
+        (void)hipFree(a->d_chain[1]);
+        a->d_tile_cnt = a->d_tile_off = nullptr;
+        a->d_chain[0] = a->d_chain[1] = nullptr;
+        a->tile_cap = 0;
+        // room for the finest geometry over the whole capacity, so that a refill never allocates
+        const uint32_t cap = (uint32_t)std::max<uint64_t>(a->n_tiles, a->padded_words / (uint64_t)crp::tile_words(crp::GEO_SMALL) + 1);
+        CRP_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&a->d_tile_cnt), cap * sizeof(uint2)));
+        CRP_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&a->d_tile_off), cap * sizeof(uint2)));
+        for (int b = 0; b < 2; ++b) CRP_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&a->d_chain[b]), crp::chain_bytes(cap)));
+        a->tile_cap = cap;
     }
-    CRP_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&a->d_totals), 2 * sizeof(uint64_t)));
-    CRP_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&a->h_totals), 4 * sizeof(uint64_t), hipHostMallocDefault));
+    for (int b = 0; b < 2; ++b) CRP_HIP(ctx, hipMemsetAsync(a->d_chain[b], 0, crp::chain_bytes(a->n_tiles), ctx->stream));
+    a->chain_cur = 0;
+    if (!a->d_totals) CRP_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&a->d_totals), 2 * sizeof(uint64_t)));
+    if (!a->h_totals) CRP_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&a->h_totals), 4 * sizeof(uint64_t), hipHostMallocDefault));
     int rc = chain_headers_point_at_host(a);
     if (rc != CRP_OK) return rc;
-    CRP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (sync) CRP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     a->sealed = true;
     return CRP_OK;
 }
+
+int crp_arena_seal(crp_arena *a) { return arena_seal_impl(a, true); }
 
 int crp_arena_tiles(const crp_arena *a, int *geometry, uint64_t *n_tiles, uint64_t *tile_words)
 {
@@ -751,12 +828,14 @@ static int single_launch(crp_arena *a, const crp::Planes &pl, uint64_t eff_words
 // Waits for single_launch's kernel.  CRP_OK with *too_small = true: the tables held fewer rows than n[] (nothing was
 // written out of bounds).  CRP_ERR_STATE with *chain_failed = true: a look-back timed out (the caller then runs the
 // three-launch sequence).
-static int single_collect(crp_arena *a, const crp::HitTables &out, uint64_t n[2], bool *chain_failed, bool *too_small)
+static int single_collect(crp_arena *a, const crp::HitTables &out, uint64_t n[2], bool *chain_failed, bool *too_small, bool kernel_done = false)
 {
     crp_ctx *ctx = a->ctx;
     *chain_failed = *too_small = false;
     // header: fail << 32, total '+', total '-' -- the kernel also writes it to h_totals (pinned)
-    CRP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // (kernel_done: the caller has waited for an event behind the launch -- crp_stream.cpp, whose stream already holds the
+    // uploads of later slices and must not be waited for as a whole)
+    if (!kernel_done) CRP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     a->chain_cur ^= 1;  // the kernel left the other buffer zeroed
     if (a->h_totals[0] >> 32) {  // fail flag: a look-back spin ran out; neither buffer can be trusted now
         for (int b = 0; b < 2; ++b)
@@ -782,6 +861,37 @@ static ScanWant scan_want(int guide_len, int flags)
 }  // extern "C"
 
 namespace crp {
+
+// An arena emptied for another genome slice (crp_stream.cpp): same planes (all void again, in stream order), same scratch,
+// same tables -- nothing is allocated or freed, so refilling costs a 4-plane memset and no synchronisation.  Whatever was
+// queued for the arena must have completed or be ordered before on the context's stream.
+int arena_reset(crp_arena *a)
+{
+    if (!a) return CRP_ERR_INVALID;
+    crp_ctx *ctx = a->ctx;
+    CRP_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t bytes = std::min<uint64_t>(a->padded_words, round_up(a->used_words + 1, crp::ARENA_ALIGN_WORDS)) * sizeof(uint64_t);
+    for (int p = 0; p < 4; ++p) CRP_HIP(ctx, hipMemsetAsync(a->d_plane[p], p < 2 ? 0xFF : 0x00, bytes, ctx->stream));  // all void
+    a->used_words = 1;
+    a->n_contigs = a->n_chars = 0;
+    a->sealed = false;
+    a->have_hits = a->have_pre = a->have_raw = a->have_feat = a->have_track = false;
+    a->n_hits[0] = a->n_hits[1] = 0;
+    a->scan_pending = 0;
+    a->ot_epoch = 0;
+    return CRP_OK;
+}
+
+int arena_seal_async(crp_arena *a) { return arena_seal_impl(a, false); }
+
+// the tables a first scan of `chars` characters would ask for (scan_begin's density guess), allocated ahead of it
+int arena_reserve_tables(crp_arena *a, uint64_t chars, bool want_pre)
+{
+    if (!a) return CRP_ERR_INVALID;
+    CRP_HIP(a->ctx, hipSetDevice(a->ctx->device));
+    const uint64_t rows[2] = {chars / 8 + 1024, chars / 8 + 1024};
+    return reserve_tables(a, rows, ScanWant{want_pre, false});
+}
 
 // First half of crp_scan_score: validates, and in the single-launch mode queues the kernel on the context's stream
 // without waiting for it.  (Three-launch mode: nothing is queued; scan_finish runs the whole sequence.)
@@ -813,7 +923,7 @@ int scan_begin(crp_arena *a, int guide_len, int flags)
     return CRP_OK;
 }
 
-int scan_finish(crp_arena *a, uint64_t *n_plus, uint64_t *n_minus)
+int scan_finish(crp_arena *a, uint64_t *n_plus, uint64_t *n_minus, bool kernel_done)
 {
     if (!a) return CRP_ERR_INVALID;
     if (!a->scan_pending) return CRP_ERR_STATE;
@@ -829,7 +939,7 @@ int scan_finish(crp_arena *a, uint64_t *n_plus, uint64_t *n_minus)
         rc = scan_two_pass(a, pl, eff_words, guide_len, want, n);
     } else {
         bool chain_failed = false, too_small = false;
-        rc = single_collect(a, a->pend_out, n, &chain_failed, &too_small);
+        rc = single_collect(a, a->pend_out, n, &chain_failed, &too_small, kernel_done);
         if (rc == CRP_OK && too_small) {  // once more, with the exact sizes
             const uint64_t rows[2] = {n[0], n[1]};
             rc = single_launch(a, pl, eff_words, guide_len, want, rows, &a->pend_out);

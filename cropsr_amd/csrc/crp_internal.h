@@ -59,6 +59,8 @@ struct crp_ctx {
     uint64_t ot_epoch = 0;          // bumped by crp_offtarget_reset: arenas added before it are stale
     // multi-GPU (crp_comm.cpp)
     crp_comm *comm = nullptr;
+    // pipelined seam 1 (crp_stream.cpp): the lanes -- further contexts on this device, each with a reusable arena
+    struct crp_stream_state *stream_state = nullptr;
 };
 
 struct crp_arena {
@@ -76,6 +78,7 @@ struct crp_arena {
     uint64_t *d_totals = nullptr;
     uint64_t *h_totals = nullptr;  // pinned
     uint32_t n_tiles = 0;
+    uint32_t tile_cap = 0;  // tiles the per-tile scratch has room for (an arena that is reset and refilled keeps it)
     int geo = 0;  // GEO_*: tile geometry, chosen at seal
     // hit tables: [0] = '+', [1] = '-'
     uint32_t *d_pos[2] = {nullptr, nullptr};
@@ -153,6 +156,18 @@ int staged_h2d(crp_ctx *ctx, void *d_dst, const void *src, size_t n);
 int staged_d2h(crp_ctx *ctx, void *dst, const void *d_src, size_t n);
 int staging_ready(crp_ctx *ctx);
 void parallel_copy(void *dst, const void *src, size_t n, int threads);
+struct CopySeg {
+    void *dst;
+    const void *src;
+    size_t bytes;
+};
+void parallel_copy_multi(const CopySeg *segs, int n_segs, int threads);  // all of them at once, bytes dealt evenly to the threads
+bool is_pinned_host(const void *p);  // memory the GPU reaches by DMA (crp_host_alloc): the staged copies go direct
+
+// crp_stream.cpp's arena reuse: empty an arena for the next slice / seal without waiting (crp_api.cpp)
+int arena_reset(crp_arena *a);
+int arena_seal_async(crp_arena *a);
+int arena_reserve_tables(crp_arena *a, uint64_t chars, bool want_pre);
 
 // grow-only device buffer: *p holds at least `need` elements of `elem` bytes afterwards
 int grow(crp_ctx *ctx, void **p, uint64_t *cap, uint64_t need, size_t elem);
@@ -161,7 +176,7 @@ int grow(crp_ctx *ctx, void **p, uint64_t *cap, uint64_t need, size_t elem);
 // scan_finish waits for it, repeats it where it must (tables too small, look-back time-out) and publishes the tables --
 // a caller with several devices queues all of them before it waits for any (crp_node.cpp)
 int scan_begin(crp_arena *a, int guide_len, int flags);
-int scan_finish(crp_arena *a, uint64_t *n_plus, uint64_t *n_minus);
+int scan_finish(crp_arena *a, uint64_t *n_plus, uint64_t *n_minus, bool kernel_done = false);  // kernel_done: an event behind the launch has been waited for
 
 // crp_gather.hip: the kernels either side of the gatherv (ownership cuts, 16-bit position packing, rebasing at the root)
 struct PieceMap {
@@ -183,6 +198,7 @@ hipError_t launch_add_u32(hipStream_t s, uint32_t *dst, const uint32_t *src, uin
 constexpr uint64_t OT_HIST_ENTRIES = 1ull << 24;  // 4^12 seeds (crp_offtarget.hip: OT_SEEDS)
 
 void comm_release(crp_ctx *ctx);  // crp_comm.cpp; called by crp_destroy
+void stream_release(crp_ctx *ctx);  // crp_stream.cpp; called by crp_destroy
 void comm_forget_arena(crp_ctx *ctx, const crp_arena *a);
 int comm_allreduce_u32(crp_ctx *ctx, uint32_t *d_buf, uint64_t n);  // in-place sum over the ranks; no-op without a communicator
 int comm_world(const crp_ctx *ctx);  // 0 without a communicator

@@ -9,6 +9,7 @@
 // the rows a device owns are ONE run of each of its tables, which is what crp_node_gather sends.
 #include "crp_plan.h"
 
+#include <algorithm>
 #include <cstring>
 
 #include "cropsr_hip.h"
@@ -50,6 +51,51 @@ void plan_shares(const uint64_t *lens, uint64_t n, int world, uint64_t min_piece
             }
         }
         while (r < world - 1 && acc >= bounds[(size_t)r]) r += 1;
+    }
+}
+
+static inline uint64_t words_for(uint64_t len) { return (len + 63) / 64 + 1; }  // = crp_arena_words_for (crp_api.cpp; no HIP here)
+
+uint64_t slice_words_min(uint64_t halo) { return words_for(2 * halo + 64) + 2; }
+
+void plan_slices(const uint64_t *lens, uint64_t n, uint64_t limit_words, uint64_t halo, std::vector<std::array<uint64_t, 4>> &out)
+{
+    out.clear();
+    uint64_t slice = 0, used = 1;  // (word 0 of an arena is its leading separator)
+    bool any = false;              // the current slice holds a piece
+    for (uint64_t k = 0; k < n; ++k) {
+        const uint64_t len = lens[k];
+        uint64_t start = 0;
+        for (;;) {
+            uint64_t end = len;
+            const uint64_t text_lo = start > halo ? start - halo : 0;
+            uint64_t need = words_for(len - text_lo);  // (a piece that ends its contig has no right halo)
+            bool cut = false;
+            if (used + need > limit_words) {
+                if (any) {  // the run goes on in a new slice
+                    slice += 1;
+                    used = 1;
+                    any = false;
+                }
+                if (used + need > limit_words) {  // not even an empty slice holds it: cut to what one takes
+                    const uint64_t chars = (limit_words - used - 1) * 64;
+                    const uint64_t own = (chars - (start - text_lo) - halo) & ~(uint64_t)63;
+                    end = start + own;
+                    need = words_for(std::min(len, end + halo) - text_lo);
+                    cut = true;
+                }
+            }
+            out.push_back({k, start, end, slice});
+            used += need;
+            any = true;
+            if (cut) {  // a piece that ends inside its contig closes its slice: one run per table
+                slice += 1;
+                used = 1;
+                any = false;
+            }
+            if (end == len) break;
+            start = end;
+        }
     }
 }
 

@@ -231,6 +231,26 @@ class Arena:
         return sp, sm
 
 
+class PinnedTables:
+    """Hit tables in pinned host memory (crp_host_alloc), as numpy arrays that keep the allocation alive."""
+
+    def __init__(self, rows_plus, rows_minus):
+        self._ptrs = []
+        self.arrays = tuple(self._alloc(n, dt) for n, dt in ((rows_plus, np.uint32), (rows_plus, np.float64),
+                                                             (rows_minus, np.uint32), (rows_minus, np.float64)))
+
+    def _alloc(self, n, dtype):
+        import weakref as _wr
+        n = int(n)
+        nbytes = max(1, n) * np.dtype(dtype).itemsize
+        p = ctypes.c_void_p()
+        nat.check(nat.lib().crp_host_alloc(nbytes, ctypes.byref(p)), "crp_host_alloc")
+        buf = (ctypes.c_uint8 * nbytes).from_address(p.value)
+        arr = np.frombuffer(buf, dtype=dtype, count=n)
+        _wr.finalize(buf, nat.lib().crp_host_free, ctypes.c_void_p(p.value))  # (the array holds `buf`; freed with the last view)
+        return arr
+
+
 # Engines still open when the interpreter exits are closed here, in an atexit handler: that runs
 # before module globals are torn down and before the HIP runtime's own static destructors, so no
 # __del__ ever calls into a runtime that is already gone.
@@ -341,6 +361,54 @@ class Engine:
         a = Arena(self, h, offsets, lengths)
         self._arenas.add(a)
         return a
+
+    # ---- seam 1 as a pipeline (crp_scan_stream)
+    def stream_prepare(self, slice_chars=0):
+        """Open the pipeline's lanes (two further contexts, three slice arenas) ahead of the first scan_stream()."""
+        nat.check(nat.lib().crp_scan_stream_prepare(self._ctx, int(slice_chars)), "crp_scan_stream_prepare", self._ctx)
+
+    def empty_tables(self, rows_plus, rows_minus):
+        """Four numpy arrays (pos_plus u32, score_plus f64, pos_minus u32, score_minus f64) over PINNED host memory
+        (crp_host_alloc): fetches and scan_stream() fill them by DMA, with no staging copy and no first-touch page faults.
+        For callers that keep their tables from genome to genome (pinning 0.6 GB costs more than one copy saves).  The
+        memory is released when the arrays are garbage-collected."""
+        return PinnedTables(rows_plus, rows_minus).arrays
+
+    def scan_stream(self, contigs, guide_len=20, want_pre=False, out=None, slice_chars=0, density=1.0 / 6):
+        """All contigs through crp_scan_stream: upload, scan and table fetch as a pipeline over slices of the genome,
+        H2D and D2H side by side.  Returns node.NodeHits (one table per strand, contig after contig, positions LOCAL to the
+        contig string; hits.contig(k) like Hits.contig(k)) with .stream_stats.  out: (pos_plus, score_plus, pos_minus,
+        score_minus) arrays to fill -- e.g. empty_tables(); default: fresh pageable arrays sized for `density` hits per
+        character and strand (a multiple of what genomes have; untouched pages cost nothing).  Tables that turn out too small
+        (poly-G) are replaced by exactly sized ones and the scan repeated."""
+        from .node import NodeHits
+        L = nat.lib()
+        bufs = [_as_u8(c) for c in contigs]
+        n = len(bufs)
+        ptrs = (ctypes.c_void_p * max(1, n))(*[b.ctypes.data if b.size else None for b in bufs])
+        lens = np.array([b.size for b in bufs], dtype=np.uint64)
+        total = int(lens.sum())
+        per = np.zeros((max(1, n), 2), dtype=np.uint64)
+        stats = np.zeros(12, dtype=np.float64)
+        a, b = ctypes.c_uint64(), ctypes.c_uint64()
+        if out is None:
+            cap = int(total * density) + 1024
+            out = (np.empty(cap, np.uint32), np.empty(cap, np.float64), np.empty(cap, np.uint32), np.empty(cap, np.float64))
+        for attempt in range(2):
+            pp, sp, pm, sm = out
+            st = L.crp_scan_stream(self._ctx, ptrs, lens.ctypes.data_as(nat.u64p), n, int(guide_len), nat.SCAN_PRE if want_pre else 0,
+                                   int(slice_chars), pp.ctypes.data_as(nat.u32p), sp.ctypes.data_as(nat.f64p), min(pp.size, sp.size),
+                                   pm.ctypes.data_as(nat.u32p), sm.ctypes.data_as(nat.f64p), min(pm.size, sm.size),
+                                   per.ctypes.data_as(nat.u64p), ctypes.byref(a), ctypes.byref(b), stats.ctypes.data_as(nat.f64p))
+            if st != nat.CRP_ERR_CAPACITY or attempt:
+                break
+            out = (np.empty(a.value, np.uint32), np.empty(a.value, np.float64), np.empty(b.value, np.uint32), np.empty(b.value, np.float64))
+        nat.check(st, "crp_scan_stream", self._ctx)
+        hits = NodeHits(per[:n], [out[0][:a.value], out[1][:a.value], out[2][:b.value], out[3][:b.value]], guide_len)
+        keys = ("wall_s", "uploader_busy_s", "drainer_busy_s", "slices", "lanes", "first_slice_on_host_s", "uploader_waiting_s",
+                "drainer_waiting_s", "copier_busy_s", "copier_waiting_s", "copier_bytes", "tables_pinned")
+        hits.stream_stats = dict(zip(keys, (float(v) for v in stats)))
+        return hits
 
     def genome(self, contigs, max_words=None, pack="device"):
         """Like arena(), for inputs that may exceed one arena (2^31 characters)."""

@@ -292,6 +292,40 @@ int crp_gathered_fetch(crp_ctx *ctx, int rank, uint32_t *pos_plus, double *score
 /* Root only, after a crp_gather_hits with CRP_GATHER_FEATURES: the ids rank `rank` contributed (uint32 per hit). */
 int crp_gathered_fetch_features(crp_ctx *ctx, int rank, uint32_t *feat_plus, uint32_t *feat_minus);
 
+/* ---- seam 1 as a pipeline: upload | scan | fetch side by side ---------------- */
+/* The reference's loop produces and consumes contig by contig (CROPSR.py:409-474).  crp_arena_* + crp_scan_score +
+ * crp_fetch_hits do the three steps of seam 1 one after the other; crp_scan_stream does them as a pipeline over slices
+ * of the genome (slice_chars characters each, 0 = 64 Mi; whole contigs while they fit, a longer contig cut with
+ * CRP_HALO characters of context either side and every hit owned by the piece its match index falls in): while slice k is
+ * scanned, slice k + 1 crosses the host link upwards and the tables of slice k - 1 cross it downwards.  One blocking
+ * call; the caller's strings are read, not kept.
+ *   texts / lens / n   the contig strings CROPSR.py:409 iterates over, in order (each at most 2^32 - 1 characters)
+ *   flags              CRP_SCAN_PRE: the f64 column is the pre-sigmoid sum (CROPSR.py:312) instead of the score
+ *   pos_* / score_*    the caller's tables, cap_* rows each (a pointer may be NULL: that column is not copied): ONE table
+ *                      per strand, contig after contig, ascending inside a contig, positions LOCAL to the contig string
+ *                      (the regex match indices of CROPSR.py:418 / :429) -- what crp_node_fetch returns.  Pinned memory
+ *                      (crp_host_alloc) is written by DMA directly; pageable memory through the staging buffers.
+ *   per_contig         2 x n values {plus, minus} (may be NULL); *n_plus / *n_minus: the totals
+ *   stats              12 doubles (may be NULL): wall seconds, uploader busy, drainer busy (incl. waiting for the scans),
+ *                      slices, lanes, seconds until the first slice's tables were on the host, uploader waiting for a
+ *                      lane, drainer waiting for a staging buffer, copier busy (staging -> the caller's pageable tables),
+ *                      copier waiting for the D2H copies, bytes the copier moved, 1 if the tables were pinned
+ * CRP_ERR_CAPACITY: a table was too small -- nothing was written beyond cap_*, *n_plus / *n_minus hold the sizes to
+ * come back with.  crp_scan_stream_prepare opens the pipeline's lanes (further contexts on the device -- four lanes in all,
+ * environment CRP_STREAM_LANES 2..8 -- each with an arena of slice_chars and its tables) ahead of time, e.g. while the
+ * FASTA is still being read. */
+int crp_scan_stream(crp_ctx *ctx, const uint8_t *const *texts, const uint64_t *lens, uint64_t n, int guide_len, int flags,
+                    uint64_t slice_chars, uint32_t *pos_plus, double *score_plus, uint64_t cap_plus, uint32_t *pos_minus,
+                    double *score_minus, uint64_t cap_minus, uint64_t *per_contig, uint64_t *n_plus, uint64_t *n_minus,
+                    double *stats);
+int crp_scan_stream_prepare(crp_ctx *ctx, uint64_t slice_chars);
+/* Host memory the GPU reaches by DMA (hipHostMalloc): tables allocated here are filled by crp_fetch_hits,
+ * crp_node_fetch and crp_scan_stream without a staging copy and without first-touch page faults, and contig strings kept
+ * here are uploaded straight off their pages (they must then stay valid until crp_arena_seal / the end of
+ * crp_scan_stream).  For callers that keep their buffers from genome to genome: pinning costs more than one copy saves. */
+int crp_host_alloc(uint64_t bytes, void **out);
+int crp_host_free(void *p);
+
 /* ---- multi-GPU: ONE process over N GPUs, the node handle -------------------- */
 /* The reference is one process with one contig loop (CROPSR.py:333, :409).  A crp_node lets that one process drive N
  * GPUs through one handle: crp_node_load cuts the genome into N contiguous equal shares (a contig that straddles a

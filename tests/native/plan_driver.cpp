@@ -2,12 +2,15 @@
 // crp_plan_shares under ASan + UBSan; every plan must cover each contig once and in order, give the devices non-decreasing
 // contiguous runs, cut at most world - 1 times, and let only a device's first piece begin -- and only its last piece end --
 // inside a contig (what crp_node_gather's "one run of owned rows per table" rests on).  Also the capacity protocol.
+#include <algorithm>
+#include <array>
 #include <cstdint>
 #include <cstdio>
 #include <random>
 #include <vector>
 
 #include "cropsr_hip.h"
+#include "crp_plan.h"
 
 #define REQUIRE(c)                                                       \
     do {                                                                 \
@@ -54,6 +57,42 @@ int main()
             REQUIRE(!first && at == lens[k]);
         }
         REQUIRE(q == got);
+    }
+    // plan_slices (crp_scan_stream's cut; the node handle packs a device's share into arenas by the same rule): every contig
+    // covered once and in order, slices in order, no slice over its word limit, and only a slice's FIRST piece begins -- only
+    // its LAST ends -- inside a contig
+    for (int trial = 0; trial < 20000; ++trial) {
+        const uint64_t halo = 128;
+        const uint64_t n = rng() % 30;
+        std::vector<uint64_t> lens(n);
+        const int kind = (int)(rng() % 3);
+        for (auto &l : lens) l = kind == 0 ? rng() % 3000 : kind == 1 ? rng() % 200000 : (rng() % 6 == 0 ? 500000 + rng() % 3000000 : rng() % 20000);
+        const uint64_t lo = crp::slice_words_min(halo);
+        const uint64_t limit = rng() % 4 == 0 ? lo + rng() % 8 : lo + rng() % 20000;
+        std::vector<std::array<uint64_t, 4>> out;
+        crp::plan_slices(lens.data(), n, limit, halo, out);
+        size_t q = 0;
+        uint64_t prev_slice = 0, used = 1;
+        for (uint64_t k = 0; k < n; ++k) {
+            uint64_t at = 0;
+            bool first = true;
+            while (q < out.size() && out[q][0] == k) {
+                const uint64_t s = out[q][1], e = out[q][2], sl = out[q][3];
+                REQUIRE(s == at && e >= s && e <= lens[k] && (e > s || lens[k] == 0) && sl >= prev_slice && sl <= prev_slice + 1);
+                if (sl != prev_slice) used = 1;
+                const uint64_t text_lo = s > halo ? s - halo : 0, text_end = std::min(lens[k], e + halo);
+                used += (text_end - text_lo + 63) / 64 + 1;
+                REQUIRE(used <= limit);
+                if (s > 0) REQUIRE(q == 0 || out[q - 1][3] != sl);                  // begins inside a contig: first piece of its slice
+                if (e < lens[k]) REQUIRE(q + 1 == out.size() || out[q + 1][3] != sl);  // ends inside one: last piece of its slice
+                at = e;
+                prev_slice = sl;
+                first = false;
+                ++q;
+            }
+            REQUIRE(!first && at == lens[k]);
+        }
+        REQUIRE(q == out.size());
     }
     int trial = -1;
     uint64_t x = 0, one = (uint64_t)1 << 63;
