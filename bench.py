@@ -92,6 +92,9 @@ def parse_args():
     ap.add_argument("--launch-timeout", type=float, default=900.0,
                     help="--gpus N without a launcher: stop the self-started ranks after this many seconds (kept well below "
                          "a 1500 s step time-out of whoever runs the bench, so that the launcher's own 124 path comes first)")
+    ap.add_argument("--no-pipelined", action="store_true",
+                    help="N = 1: skip the host-to-host block that sends the same genome through crp_scan_stream (upload | scan | "
+                         "fetch as a pipeline over slices) beside the serial upload / scan / fetch numbers of `pcie_inclusive`")
     ap.add_argument("--no-strong", action="store_true",
                     help="N > 1: skip the strong-scaling block (ONE genome cut over the N ranks, BASELINE.json configs[3], [4])")
     ap.add_argument("--no-node-block", action="store_true",
@@ -808,6 +811,8 @@ def main():
     sample = None
     my_bases = 0
     t_upload = 0.0
+    keep_strings = world == 1 and not args.no_pipelined  # (the pipelined host-to-host block below sends them through again)
+    kept_strings = []
     for i in mine:
         g, k = all_specs[i]
         s = genomes[g].contig_string(k)
@@ -817,6 +822,8 @@ def main():
         builder.add(s)  # characters over PCIe + the ballot pack kernel, synchronous
         t_upload += time.perf_counter() - t_up
         my_bases += genomes[g].specs[k].length
+        if keep_strings:
+            kept_strings.append(s)
         del s
     t_up = time.perf_counter()
     arena = builder.seal()  # (flushes the small contigs the builder still holds, waits for the uploads)
@@ -861,9 +868,58 @@ def main():
         t_fetch_again = time.perf_counter()
         arena.fetch(n_plus, n_minus, out=host_cols)  # and again into the same arrays: what a caller that keeps its buffers pays
         t_fetch_again = time.perf_counter() - t_fetch_again
-        del host_cols
     else:
         t_fetch = time.perf_counter() - t_fetch
+        host_cols = None
+    # ---- the same boundary as a PIPELINE (crp_scan_stream, never `value`): the genome goes up in slices while the slice
+    # before is scanned and the tables of the one before that come down -- host strings in, host tables out, one call
+    pipelined = None
+    if keep_strings and rank == 0:
+        import numpy as np
+        try:
+            eng.stream_prepare()
+
+            def run(out=None):
+                h = eng.scan_stream(kept_strings, 20, out=out)
+                return h, h.stream_stats
+            fresh, pinned = [], []
+            for rep in range(4):
+                h, st = run()
+                if rep == 0:  # the same rows as the one-arena scan: counts, and the f64 column bit for bit (same order)
+                    same = (h.n_plus == n_plus and h.n_minus == n_minus and
+                            np.array_equal(h.score_plus.view(np.uint64), host_cols[2].view(np.uint64)) and
+                            np.array_equal(h.score_minus.view(np.uint64), host_cols[5].view(np.uint64)))
+                else:
+                    fresh.append(st["wall_s"])
+                stats_fresh = st
+                del h
+            t_pin = time.perf_counter()
+            out = eng.empty_tables(n_plus, n_minus)
+            t_pin = time.perf_counter() - t_pin
+            for rep in range(4):
+                h, st = run(out)
+                if rep:
+                    pinned.append(st["wall_s"])
+                del h
+            del out
+            up_bytes, down_bytes = int(sum(int(x.size) for x in kept_strings)), 12 * int(n_plus + n_minus)
+            med = lambda v: sorted(v)[len(v) // 2]
+            pipelined = {"pipelined_s": med(fresh), "pipelined_into_pinned_tables_s": med(pinned), "tables_equal_the_serial_scan": bool(same),
+                         "runs_s": {"fresh_pageable_tables": fresh, "pinned_tables": pinned}, "pinning_the_tables_once_s": t_pin,
+                         "slices": int(stats_fresh["slices"]), "lanes": int(stats_fresh["lanes"]),
+                         "first_slice_on_host_s": stats_fresh["first_slice_on_host_s"],
+                         "uploader_busy_s": stats_fresh["uploader_busy_s"], "copier_busy_s": stats_fresh["copier_busy_s"],
+                         "bytes_up": up_bytes, "bytes_down": down_bytes,
+                         # the link: 56 GB/s one way alone, 48 + 48 GB/s with both directions busy (profiles/microbench/duplex_copy.hip)
+                         "link_floor_s": max(up_bytes, down_bytes) / 48e9, "link_floor_if_one_direction_at_a_time_s": (up_bytes + down_bytes) / 56e9}
+            if not same:
+                raise SystemExit("bench.py: crp_scan_stream's tables differ from the one-arena scan's")
+        except SystemExit:
+            raise
+        except Exception as e:  # (reported, not fatal: the headline does not depend on it)
+            pipelined = {"error": "%s: %s" % (type(e).__name__, e)}
+    del host_cols
+    kept_strings = []
 
     # count / scan kernel times from a few extra steps outside the timed region; inside it only the
     # emit+score kernel (the one the roofline is quoted on) is bracketed by HIP events
@@ -1000,6 +1056,10 @@ def main():
                                "fetch_tables_into_reused_arrays_s": t_fetch_again,
                                "gRNAs_per_s": scored / (t_upload + dt / args.steps + t_fetch)},
         }
+        if pipelined is not None:
+            line["pcie_inclusive"].update(pipelined)
+            if "pipelined_s" in pipelined:
+                line["pcie_inclusive"]["gRNAs_per_s_pipelined"] = scored / pipelined["pipelined_s"]
         if rccl_error:
             line["rccl_error"] = rccl_error
         if strong is not None:

@@ -216,6 +216,7 @@ class EngineBackend:
         # own PCIe link and the control sockets carry them (ranks sharing one GPU, where RCCL cannot run)
         self.transport = os.environ.get("CROPSR_GATHER", "rccl")
         self.last_annotate_s = None  # --bench-json: seconds the last annotation join took on this rank
+        self.last_stream = None      # --bench-json: crp_scan_stream's own numbers for the last plain scan
 
     def connect(self):
         """Collective over the group: create the RCCL communicator (transport "rccl")."""
@@ -239,10 +240,33 @@ class EngineBackend:
                 hits["score_" + strand] = host_sigmoid(pre)
         return hits
 
+    def warm_up(self):
+        """On the start-up helper thread, while the FASTA is still being read: the lanes of the pipelined scan (two further
+        streams, four slice arenas with their tables, the landing buffers)."""
+        import os
+        if self.group is None and os.environ.get("CROPSR_STREAM", "1") != "0":
+            self.engine.stream_prepare()
+
     def scan(self, contig_strings, guide_len, offtarget=False, annotation=None):
-        """One arena pass on the GPU for all contig strings (seam 1 + 2).  annotation (annotate.Request): the hit
-        dicts also carry feat_plus / feat_minus, the label-set id of every row, joined on the GPU while the tables
-        are resident."""
+        """One pass on the GPU for all contig strings (seam 1 + 2).  The plain scan goes through crp_scan_stream -- upload,
+        scan and table fetch as a pipeline over slices of the genome, the host link busy in both directions (the reference's
+        loop is produce-and-consume per contig too, CROPSR.py:409-474); CROPSR_STREAM=0, or the opt-in steps that work on
+        resident tables (offtarget, annotation), take the arena calls: upload, one scan, fetch.  annotation
+        (annotate.Request): the hit dicts also carry feat_plus / feat_minus, the label-set id of every row, joined on the GPU
+        while the tables are resident."""
+        import os
+        if not offtarget and annotation is None and os.environ.get("CROPSR_STREAM", "1") != "0":
+            want_pre = self.finalize == "host"
+            hits = self.engine.scan_stream(contig_strings, guide_len, want_pre=want_pre)
+            self.last_stream = hits.stream_stats  # (--bench-json)
+            out = []
+            for k in range(len(contig_strings)):
+                h = hits.contig(k)
+                if want_pre:  # the f64 column is the pre-sigmoid sum: CROPSR.py:313 on this host's numpy
+                    h["score_plus"], h["score_minus"] = host_sigmoid(h["score_plus"]), host_sigmoid(h["score_minus"])
+                out.append(h)
+            self.last_annotate_s = None
+            return out
         genome = self.engine.genome(contig_strings)  # as many arenas as the genome needs
         hits = genome.scan_score(guide_len, want_pre=self.finalize == "host", offtarget=offtarget, annotation=annotation)
         out = [self._finalize(hits.contig(k)) for k in range(len(contig_strings))]
@@ -443,7 +467,10 @@ def run(args, backend=None, out=sys.stdout, group=None):
         device = getattr(args, "device", None)
         if device is None:
             device = group.local_rank if group is not None else 0
-        return EngineBackend(device, group, finalize)
+        b = EngineBackend(device, group, finalize)
+        if not offtarget and not getattr(args, "annotate", False):
+            b.warm_up()
+        return b
 
     # Opening the GPU (HIP start-up, code object, two pinned staging buffers: ~0.3 s) starts NOW on a helper thread and
     # is collected where the backend is first needed: it overlaps reading and parsing the FASTA.
@@ -653,6 +680,8 @@ def run(args, backend=None, out=sys.stdout, group=None):
     timing.close()
     if ids is not None:
         ids.close()
+    if getattr(backend, "last_stream", None):  # the pipelined scan's own account of the upload + scan + fetch stage
+        stages["scan_stream"] = backend.last_stream
     if getattr(backend, "last_gather", None):  # one process over several devices (--devices): the node's gatherv, in numbers
         stages["node_gatherv"] = backend.last_gather
         stages["devices"] = list(backend.node.devices)
