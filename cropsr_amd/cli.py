@@ -468,7 +468,11 @@ def run(args, backend=None, out=sys.stdout, group=None):
         if device is None:
             device = group.local_rank if group is not None else 0
         b = EngineBackend(device, group, finalize)
-        if not offtarget and not getattr(args, "annotate", False):
+        try:  # (a genome of a few slices at least: below that there is nothing to prepare, one small lane is made on the spot)
+            big = isinstance(args.f, str) and os.path.getsize(args.f) >= (256 << 20)
+        except OSError:
+            big = False
+        if big and not offtarget and not getattr(args, "annotate", False):
             b.warm_up()
         return b
 

@@ -168,7 +168,7 @@ int ensure_lanes(crp_ctx *ctx, size_t want, uint64_t slice_words, bool landing)
     if (st->lanes.size() < want) st->lanes.resize(want);
     for (size_t k = 0; k < want; ++k) {
         Lane &l = st->lanes[k];
-        if (l.arena && l.arena_words != slice_words) {
+        if (l.arena && l.arena_words < slice_words) {  // (a roomier arena than asked for serves as well)
             (void)crp_arena_destroy(l.arena);
             l.arena = nullptr;
         }
@@ -190,10 +190,10 @@ int ensure_lanes(crp_ctx *ctx, size_t want, uint64_t slice_words, bool landing)
         if (!l.cut) CRP_HIP(ctx, hipEventCreateWithFlags(&l.cut, hipEventDisableTiming));
         if (!l.down) CRP_HIP(ctx, hipEventCreateWithFlags(&l.down, hipEventDisableTiming));
     }
-    for (int b = 0; b < N_LAND && landing; ++b) {
-        if (!st->land[b]) CRP_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&st->land[b]), crp::STAGE_CHUNK, hipHostMallocDefault));
+    for (int b = 0; b < N_LAND; ++b)
         if (!st->landed[b]) CRP_HIP(ctx, hipEventCreateWithFlags(&st->landed[b], hipEventDisableTiming));
-    }
+    for (int b = 0; b < N_LAND && landing; ++b)  // (crp_scan_stream_prepare; a scan allocates them as it first needs them)
+        if (!st->land[b]) CRP_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&st->land[b]), crp::STAGE_CHUNK, hipHostMallocDefault));
     return CRP_OK;
 }
 
@@ -305,7 +305,14 @@ static int scan_stream_impl(crp_ctx *ctx, const uint8_t *const *texts, const uin
     tables_pinned = tables_pinned && any_table;
 
     const size_t n_lanes = std::min<size_t>(lanes_wanted(), n_slices);
-    int rc = ensure_lanes(ctx, n_lanes, slice_words, any_table && !tables_pinned);
+    // (a genome smaller than a slice: the one lane it needs is sized for it, not for 64 Mi characters)
+    uint64_t lane_words = slice_words;
+    if (n_slices == 1) {
+        uint64_t need = 1;
+        for (const Piece &p : pieces) need += crp_arena_words_for(p.text_len);
+        lane_words = std::max<uint64_t>(crp::slice_words_min(CRP_HALO), std::min(slice_words, need + 1));
+    }
+    int rc = ensure_lanes(ctx, n_lanes, lane_words, false);
     if (rc != CRP_OK) return rc;
     crp_stream_state *st = ctx->stream_state;
     std::vector<Lane> &lanes = st->lanes;
@@ -437,6 +444,10 @@ static int scan_stream_impl(crp_ctx *ctx, const uint8_t *const *texts, const uin
                         job.buf = next_land;
                         next_land = (next_land + 1) % N_LAND;
                         land_used = 0;
+                        if (!st->land[job.buf]) {  // (a small genome never needs more than the first)
+                            e = hipHostMalloc(reinterpret_cast<void **>(&st->land[job.buf]), crp::STAGE_CHUNK, hipHostMallocDefault);
+                            if (e != hipSuccess) return hip_fail(e, "landing buffer");
+                        }
                     }
                     const size_t take = std::min(cols[ci].bytes - done, crp::STAGE_CHUNK - land_used);
                     e = hipMemcpyAsync(st->land[job.buf] + land_used, cols[ci].d_src + done, take, hipMemcpyDeviceToHost, st->s_down);
