@@ -85,7 +85,10 @@ __device__ __forceinline__ uint32_t spread12(uint32_t x)
 //                        the bucket's slice of the global histogram with plain 16-byte accesses
 // Chunks: workgroup w owns hits [w * OT_CHUNK, (w + 1) * OT_CHUNK) of a strand's table in both passes.
 constexpr uint32_t OT_BUCKETS = 4096;
-constexpr uint32_t OT_CHUNK = 16384;
+#ifndef CRP_OT_CHUNK
+#define CRP_OT_CHUNK 16384
+#endif
+constexpr uint32_t OT_CHUNK = CRP_OT_CHUNK;
 
 template <bool MINUS>
 __device__ __forceinline__ uint32_t seed_of_windows(uint32_t h, uint32_t w, uint32_t u, uint32_t a, uint64_t p,
@@ -108,6 +111,46 @@ __device__ __forceinline__ uint32_t seed_of_windows(uint32_t h, uint32_t w, uint
         if (!(lo > 0 && p < own[2 * (lo - 1) + 1])) return OT_NOT_OWNED;
     }
     return (spread12(h) << 1) | spread12(w);
+}
+
+// A chunk's entries, FOUR consecutive ones per lane and trip: one 16-byte load where four dependent 4-byte loads stood --
+// these passes are latency-bound (six waves per SIMD, every trip a load, an LDS atomic that returns a slot and a store that
+// wait for each other), not bound by the LDS atomics themselves -- and the four atomics / stores of a trip are independent.
+// src + lo is 16-byte aligned (chunks start at multiples of OT_CHUNK); the last chunk's ragged end goes one by one.
+#ifndef CRP_OT_VEC4
+#define CRP_OT_VEC4 1
+#endif
+template <class F>
+__device__ __forceinline__ void for_chunk(const uint32_t *__restrict__ src, uint64_t lo, uint64_t hi, F f)
+{
+#if CRP_OT_VEC4
+    const uint64_t body = lo + ((hi - lo) & ~(uint64_t)3);
+    uint64_t t = lo + 4 * (uint64_t)threadIdx.x;
+#if CRP_OT_VEC4 >= 2
+    for (; t + 4 * BLOCK < body; t += 8 * BLOCK) {  // two loads in flight per lane
+        const uint4 v = *reinterpret_cast<const uint4 *>(src + t);
+        const uint4 w = *reinterpret_cast<const uint4 *>(src + t + 4 * BLOCK);
+        f(t, v.x);
+        f(t + 1, v.y);
+        f(t + 2, v.z);
+        f(t + 3, v.w);
+        f(t + 4 * BLOCK, w.x);
+        f(t + 4 * BLOCK + 1, w.y);
+        f(t + 4 * BLOCK + 2, w.z);
+        f(t + 4 * BLOCK + 3, w.w);
+    }
+#endif
+    for (; t < body; t += 4 * BLOCK) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(src + t);
+        f(t, v.x);
+        f(t + 1, v.y);
+        f(t + 2, v.z);
+        f(t + 3, v.w);
+    }
+    for (uint64_t u = body + threadIdx.x; u < hi; u += BLOCK) f(u, src[u]);
+#else
+    for (uint64_t t = lo + threadIdx.x; t < hi; t += BLOCK) f(t, src[t]);
+#endif
 }
 
 // (Staging each round's stretch of the planes through LDS -- coalesced copies, windows cut from LDS -- was measured
@@ -148,8 +191,7 @@ __global__ __launch_bounds__(BLOCK) void ot_seed_from_raw_kernel(const uint32_t 
     for (uint32_t b = threadIdx.x; b < OT_BUCKETS; b += BLOCK) cnt[b] = 0;
     __syncthreads();
     const uint64_t lo = (uint64_t)blockIdx.x * OT_CHUNK, hi = lo + OT_CHUNK < n ? lo + OT_CHUNK : n;
-    for (uint64_t t = lo + threadIdx.x; t < hi; t += BLOCK) {
-        const uint32_t r = raw[t];
+    auto code_of = [&](uint64_t t, uint32_t r) -> uint32_t {
         uint32_t code = OT_NOT_A_SITE;
         if (r != SEED_RAW_NONE) {
             code = (spread12(r >> 12) << 1) | spread12(r & 0xfffu);
@@ -164,9 +206,24 @@ __global__ __launch_bounds__(BLOCK) void ot_seed_from_raw_kernel(const uint32_t 
                 if (!(a > 0 && p < own[2 * (a - 1) + 1])) code = OT_NOT_OWNED;
             }
         }
-        seeds[t] = code;
         if (code < OT_SEEDS) atomicAdd(&cnt[code >> 12], 1u);
+        return code;
+    };
+#if CRP_OT_VEC4
+    const uint64_t body = lo + ((hi - lo) & ~(uint64_t)3);
+    for (uint64_t t = lo + 4 * (uint64_t)threadIdx.x; t < body; t += 4 * BLOCK) {  // 16 bytes in, 16 bytes out per lane and trip
+        const uint4 r = *reinterpret_cast<const uint4 *>(raw + t);
+        uint4 c;
+        c.x = code_of(t, r.x);
+        c.y = code_of(t + 1, r.y);
+        c.z = code_of(t + 2, r.z);
+        c.w = code_of(t + 3, r.w);
+        *reinterpret_cast<uint4 *>(seeds + t) = c;
     }
+    for (uint64_t t = body + threadIdx.x; t < hi; t += BLOCK) seeds[t] = code_of(t, raw[t]);
+#else
+    for (uint64_t t = lo + threadIdx.x; t < hi; t += BLOCK) seeds[t] = code_of(t, raw[t]);
+#endif
     __syncthreads();
     for (uint32_t b = threadIdx.x; b < OT_BUCKETS; b += BLOCK)
         if (cnt[b]) atomicAdd(&bucket_total[b], cnt[b]);
@@ -218,20 +275,18 @@ __global__ __launch_bounds__(BLOCK) void ot_partition1_kernel(const uint32_t *__
     if (threadIdx.x < 64) cnt[threadIdx.x] = 0;
     __syncthreads();
     const uint64_t lo = (uint64_t)blockIdx.x * OT_CHUNK, hi = lo + OT_CHUNK < n ? lo + OT_CHUNK : n;
-    for (uint64_t t = lo + threadIdx.x; t < hi; t += BLOCK) {
-        const uint32_t code = seeds[t];
+    for_chunk(seeds, lo, hi, [&](uint64_t, uint32_t code) {
         if (code < OT_SEEDS) atomicAdd(&cnt[code >> 18], 1u);
-    }
+    });
     __syncthreads();
     if (threadIdx.x < 64) {
         const uint32_t c = cnt[threadIdx.x];
         cnt[threadIdx.x] = c ? atomicAdd(&cursor1[threadIdx.x], c) : 0;
     }
     __syncthreads();
-    for (uint64_t t = lo + threadIdx.x; t < hi; t += BLOCK) {
-        const uint32_t code = seeds[t];
+    for_chunk(seeds, lo, hi, [&](uint64_t, uint32_t code) {
         if (code < OT_SEEDS) part1[atomicAdd(&cnt[code >> 18], 1u)] = code;
-    }
+    });
 }
 
 // Level 2 (n_ptr: the number of entries, known on the device only): entries grouped by super-bucket -> their final
@@ -246,20 +301,18 @@ __global__ __launch_bounds__(BLOCK) void ot_partition_kernel(const uint32_t *__r
     for (uint32_t b = threadIdx.x; b < OT_BUCKETS; b += BLOCK) cnt[b] = 0;
     __syncthreads();
     const uint64_t lo = (uint64_t)blockIdx.x * OT_CHUNK, hi = lo + OT_CHUNK < n ? lo + OT_CHUNK : n;
-    for (uint64_t t = lo + threadIdx.x; t < hi; t += BLOCK) {
-        const uint32_t code = seeds[t];
+    for_chunk(seeds, lo, hi, [&](uint64_t, uint32_t code) {
         if (code < OT_SEEDS) atomicAdd(&cnt[code >> 12], 1u);
-    }
+    });
     __syncthreads();
     for (uint32_t b = threadIdx.x; b < OT_BUCKETS; b += BLOCK) {
         const uint32_t c = cnt[b];
         cnt[b] = c ? atomicAdd(&cursor[b], c) : 0;  // this chunk's range in bucket b starts here
     }
     __syncthreads();
-    for (uint64_t t = lo + threadIdx.x; t < hi; t += BLOCK) {
-        const uint32_t code = seeds[t];
+    for_chunk(seeds, lo, hi, [&](uint64_t, uint32_t code) {
         if (code < OT_SEEDS) part[atomicAdd(&cnt[code >> 12], 1u)] = (uint16_t)(code & 0xfffu);
-    }
+    });
 }
 
 __global__ __launch_bounds__(1024) void ot_bucket_hist_kernel(const uint16_t *__restrict__ part,
@@ -272,7 +325,26 @@ __global__ __launch_bounds__(1024) void ot_bucket_hist_kernel(const uint16_t *__
     if (lo == hi) return;  // nothing to add to this slice
     for (uint32_t k = threadIdx.x; k < 4096; k += 1024) bins[k] = 0;
     __syncthreads();
+#if CRP_OT_VEC4
+    {   // eight 16-bit entries per lane and trip on the 16-byte-aligned body, the ragged ends one by one
+        const uint32_t a0 = min(hi, (lo + 7u) & ~7u), a1 = a0 + ((hi - a0) & ~7u);
+        for (uint32_t t = lo + threadIdx.x; t < a0; t += 1024) atomicAdd(&bins[part[t]], 1u);
+        for (uint32_t t = a0 + 8 * threadIdx.x; t < a1; t += 8 * 1024) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(part + t);
+            atomicAdd(&bins[v.x & 0xffffu], 1u);
+            atomicAdd(&bins[v.x >> 16], 1u);
+            atomicAdd(&bins[v.y & 0xffffu], 1u);
+            atomicAdd(&bins[v.y >> 16], 1u);
+            atomicAdd(&bins[v.z & 0xffffu], 1u);
+            atomicAdd(&bins[v.z >> 16], 1u);
+            atomicAdd(&bins[v.w & 0xffffu], 1u);
+            atomicAdd(&bins[v.w >> 16], 1u);
+        }
+        for (uint32_t t = a1 + threadIdx.x; t < hi; t += 1024) atomicAdd(&bins[part[t]], 1u);
+    }
+#else
     for (uint32_t t = lo + threadIdx.x; t < hi; t += 1024) atomicAdd(&bins[part[t]], 1u);
+#endif
     __syncthreads();
     uint4 *slice = reinterpret_cast<uint4 *>(hist + (size_t)b * 4096);
     uint4 v = slice[threadIdx.x];
