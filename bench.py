@@ -206,6 +206,21 @@ def _cpu_leg(fp, sample_string, n_bases, threads, seconds):
             "minor_faults": ru1.ru_minflt - ru0.ru_minflt}
 
 
+def _host_cpu(n_cores):
+    """The CPU the baseline ran on: model name and core count from /proc/cpuinfo, the threads this process may use."""
+    model, logical = "unknown", 0
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    logical += 1
+                    if model == "unknown":
+                        model = line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return {"model": model, "logical_cpus": logical or (os.cpu_count() or 0), "usable_by_this_process": n_cores}
+
+
 def cpu_baseline(sample_string, n_bases):
     """Reference-faithful numpy port (oracle/faithful_port.py) on one core, then with every host core
     available to BLAS -- the reference's only multi-threaded calls are its two np.matmul
@@ -223,7 +238,9 @@ def cpu_baseline(sample_string, n_bases):
                      "user %.1f s, sys %.1f s, %d minor page faults)"
                      % (one["bases"], one["gRNAs"], one["wall_s"], one["bases"] / one["wall_s"] / 1e3,
                         one["user_s"], one["sys_s"], one["minor_faults"]),
-           "calibration": "profiles/cpu_calibration.json (real reference vs this port, development container)"}
+           "calibration": "profiles/cpu_calibration.json (real reference vs this port, development container)",
+           # the baseline moved 14 x between the development container and the GPU host: say what it ran on
+           "host": _host_cpu(n_cores)}
     if n_cores > 1:
         allc = _cpu_leg(fp, sample_string, n_bases, n_cores, 8.0)
         out["all_cores"] = {"value": allc["value"], "unit": "gRNAs/s", "cores": n_cores,
@@ -896,6 +913,10 @@ def main():
             t_pin = time.perf_counter()
             out = eng.empty_tables(n_plus, n_minus)
             t_pin = time.perf_counter() - t_pin
+            # (the serial fetch into the same pinned tables: crp_fetch_hits by DMA, no staging copy)
+            t_fetch_pinned = time.perf_counter()
+            arena.fetch(n_plus, n_minus, out=[out[0], None, out[1], out[2], None, out[3]])
+            t_fetch_pinned = time.perf_counter() - t_fetch_pinned
             for rep in range(4):
                 h, st = run(out)
                 if rep:
@@ -906,6 +927,7 @@ def main():
             med = lambda v: sorted(v)[len(v) // 2]
             pipelined = {"pipelined_s": med(fresh), "pipelined_into_pinned_tables_s": med(pinned), "tables_equal_the_serial_scan": bool(same),
                          "runs_s": {"fresh_pageable_tables": fresh, "pinned_tables": pinned}, "pinning_the_tables_once_s": t_pin,
+                         "fetch_tables_into_pinned_arrays_s": t_fetch_pinned,
                          "slices": int(stats_fresh["slices"]), "lanes": int(stats_fresh["lanes"]),
                          "first_slice_on_host_s": stats_fresh["first_slice_on_host_s"],
                          "uploader_busy_s": stats_fresh["uploader_busy_s"], "copier_busy_s": stats_fresh["copier_busy_s"],

@@ -148,7 +148,8 @@ class Arena:
         """Host copies of the tables: [pos_plus, pre_plus | None, score_plus, pos_minus, pre_minus | None, score_minus].
         out: the list a previous fetch returned -- its arrays are filled again where they are large enough (a caller that
         processes genome after genome keeps its pages: a fresh numpy array costs a page fault per 4 KiB on first touch,
-        ~14 GB/s on the MI355X boxes, against the link's 56 GB/s into memory that has been touched)."""
+        ~14 GB/s on the MI355X boxes, against the link's 56 GB/s into memory that has been touched).  Arrays over pinned
+        memory (Engine.empty_tables) are filled by DMA directly, without the staging copy."""
         cols = []
         for k, n in enumerate((n_plus, n_minus)):
             for j, (dtype, wanted) in enumerate(((np.uint32, True), (np.float64, want_pre), (np.float64, True))):

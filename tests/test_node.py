@@ -537,6 +537,40 @@ def test_node_maize_size_genome_on_one_device_equals_engine_genome():
     print("node maize-like on one device: %d characters, %d arenas, %d hits" % (total, 2, n_hits))
 
 
+def _more_devices_than_pieces(out_path):
+    """a genome with fewer pieces than devices -- some devices hold no arena and have only QUEUED the zeroing of
+    their site histogram -- with the histograms summed through device 0 (CRP_NODE_TRANSPORT=peer): the oracle's counts, on a
+    node that is used for three genomes in a row (a stale histogram on an idle device would show in the second and third)."""
+    os.environ["CRP_NODE_TRANSPORT"] = "peer"
+    from cropsr_amd import node as nd
+    from oracle import oracle as orc
+    rng = np.random.default_rng(12)
+    total = 0
+    with nd.Node([0] * 6) as node:
+        for lengths in ([3_000, 2_500], [150_000], [1_000]):
+            contigs = _genome(rng, lengths)
+            want_ot = orc.offtarget_genome(contigs, 20)
+            node.load(contigs)
+            assert sum(1 for k in range(6) if node.n_arenas(k) == 0) >= 1 or len(lengths) == 1 and lengths[0] > 100_000
+            hits = node.scan(20, offtarget=True)
+            total += _check_against_oracle(hits, contigs, orc, 20, ("idle devices", lengths))
+            for k in range(len(contigs)):
+                got = hits.contig(k)
+                assert (got["ot_plus"] == want_ot[k]["ot_plus"]).all() and (got["ot_minus"] == want_ot[k]["ot_minus"]).all(), (lengths, k)
+    with open(out_path, "w") as f:
+        f.write(str(total))
+
+
+@pytest.mark.gpu
+def test_node_offtarget_with_more_devices_than_pieces(tmp_path):
+    out = tmp_path / "idle.txt"
+    code = "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_node; test_node._more_devices_than_pieces(%r)" % (
+        ROOT, os.path.join(ROOT, "tests"), str(out))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert int(out.read_text()) > 5_000
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,extra", [("sample", ()), ("multi", ()), ("mixed", ("--score-finalize", "host")),
                                         ("mixed", ("-l", "23")), ("rightend", ("-l", "64"))])

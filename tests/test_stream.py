@@ -173,3 +173,35 @@ def test_scan_stream_switchgrass_like_equals_one_arena_scan():
     print("switchgrass-like host to host: serial upload %.1f ms + scan and fetch %.1f ms; pipelined, fresh pageable tables %s ms; "
           "pinned tables %s ms; last run: %s" % ((t1 - t0) * 1e3, (t2 - t1) * 1e3, ["%.1f" % (w * 1e3) for w in walls],
                                                  ["%.1f" % (w * 1e3) for w in pinned], stats))
+
+
+@pytest.mark.gpu
+def test_integration_md_stream_snippet_runs(oracle):
+    """The ctypes patch INTEGRATION.md shows for the pipelined seam 1, executed as printed (after the seam-2 block, which opens
+    `_crp` and `_ctx`): the tables it ends up with are the oracle's, contig after contig."""
+    import types
+    from conftest import ROOT
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+
+    def block(after):
+        at = text.index(after)
+        code = text[text.index("```python", at) + len("```python"):]
+        return code[:code.index("```")]
+    seam2 = block("### Seam 2").replace('"/path/to/cropsr_amd/libcropsr_hip.so"', repr(os.path.join(ROOT, "cropsr_amd", "libcropsr_hip.so")))
+    stream = block("### Seam 1 as a pipeline")
+    assert "crp_scan_stream(" in stream
+    rng = np.random.default_rng(78)
+    contigs = _genome(rng, [220_000, 3_000, 64, 0, 90_000])
+    env = {"fasta_file": {"k%d" % k: c.decode("ascii") for k, c in enumerate(contigs)}, "args": types.SimpleNamespace(l=20)}
+    exec(seam2, env)
+    exec(stream, env)
+    per = list(env["per_contig"])
+    a = b = 0
+    for k, c in enumerate(contigs):
+        want = oracle.scan_score(c, 20)
+        n_p, n_m = per[2 * k], per[2 * k + 1]
+        assert (env["pos_p"][a:a + n_p] == want["pos_plus"]).all() and (bits(env["sc_p"][a:a + n_p]) == bits(want["score_plus"])).all()
+        assert (env["pos_m"][b:b + n_m] == want["pos_minus"]).all() and (bits(env["sc_m"][b:b + n_m]) == bits(want["score_minus"])).all()
+        a, b = a + n_p, b + n_m
+    assert a == env["n_plus"].value and b == env["n_minus"].value and a + b > 20_000
+    env["_crp"].crp_destroy(env["_ctx"])
