@@ -12,9 +12,13 @@
 #include <sys/mman.h>
 
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <mutex>
 #include <new>
 #include <string>
 #include <thread>
@@ -37,43 +41,123 @@ inline uint64_t round_up(uint64_t x, uint64_t m) { return (x + m - 1) / m * m; }
 
 namespace crp {
 
+// ---- host-side copies between the caller's pages and the pinned staging buffers
+// A pool of copy threads that lives as long as the process: starting eight threads per 32 MiB chunk, one after the other,
+// cost a quarter of the copy itself (8 x 20-40 us against 0.6 ms) -- the staging copy, not the link, bounded an upload at 41 of
+// the link's 56 GB/s.  Any number of callers may hand work to the pool at the same time (the pipelined scan's uploader and
+// copier do); the caller takes part in its own job, so a pool that could not be started, or is busy, only makes a copy
+// slower, never wrong.  The threads are never joined (a process that exits while they sleep on the condition variable is fine).
+namespace {
+
+struct PoolJob {
+    const std::function<void(int)> *fn = nullptr;
+    int n = 0;
+    std::atomic<int> next{0}, done{0};
+};
+
+class CopyPool {
+public:
+    static CopyPool &get()
+    {
+        static CopyPool *pool = new (std::nothrow) CopyPool();  // (leaked on purpose: see above)
+        static CopyPool none(0);
+        return pool ? *pool : none;
+    }
+    // fn(0) .. fn(n - 1), each exactly once, on the pool's threads and on this one; returns when all are done
+    void run(int n, const std::function<void(int)> &fn)
+    {
+        if (n <= 0) return;
+        if (n == 1 || n_threads_ == 0) {
+            for (int k = 0; k < n; ++k) fn(k);
+            return;
+        }
+        PoolJob job;
+        job.fn = &fn;
+        job.n = n;
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            jobs_.push_back(&job);
+        }
+        wake_.notify_all();
+        work_on(job);
+        std::unique_lock<std::mutex> lk(m_);  // (the job leaves the queue before this returns: nobody holds a pointer to it afterwards)
+        for (auto it = jobs_.begin(); it != jobs_.end(); ++it)
+            if (*it == &job) {
+                jobs_.erase(it);
+                break;
+            }
+        finished_.wait(lk, [&] { return job.done.load() == job.n; });
+    }
+
+private:
+    explicit CopyPool(int n) : n_threads_(n) {}
+    CopyPool()
+    {
+        const unsigned hw = std::thread::hardware_concurrency();
+        int want = (int)std::max(1u, std::min(32u, hw ? hw / 2 : 4u));
+        if (const char *e = std::getenv("CRP_COPY_POOL_THREADS")) want = std::max(0, std::min(64, std::atoi(e)));
+        for (int k = 0; k < want; ++k) {
+            try {
+                std::thread([this] { loop(); }).detach();
+                ++n_threads_;
+            } catch (...) {
+                break;
+            }
+        }
+    }
+    void work_on(PoolJob &job)
+    {
+        for (;;) {
+            const int k = job.next.fetch_add(1);
+            if (k >= job.n) return;
+            (*job.fn)(k);
+            if (job.done.fetch_add(1) + 1 == job.n) {
+                std::lock_guard<std::mutex> lk(m_);  // (the waiter checks `done` under this mutex)
+                finished_.notify_all();
+            }
+        }
+    }
+    void loop()
+    {
+        std::unique_lock<std::mutex> lk(m_);
+        for (;;) {
+            wake_.wait(lk, [&] {
+                for (PoolJob *j : jobs_)
+                    if (j->next.load() < j->n) return true;
+                return false;
+            });
+            PoolJob *job = nullptr;
+            for (PoolJob *j : jobs_)
+                if (j->next.load() < j->n) {
+                    job = j;
+                    break;
+                }
+            if (!job) continue;
+            // claim one piece while the job is known to be alive (it is still in the queue and we hold the mutex)
+            const int k = job->next.fetch_add(1);
+            if (k >= job->n) continue;
+            lk.unlock();
+            (*job->fn)(k);
+            const bool last = job->done.fetch_add(1) + 1 == job->n;
+            lk.lock();
+            if (last) finished_.notify_all();
+        }
+    }
+    std::mutex m_;
+    std::condition_variable wake_, finished_;
+    std::vector<PoolJob *> jobs_;
+    int n_threads_ = 0;
+};
+
+}  // namespace
+
 // memcpy spread over a few threads.  (Asking the kernel for the destination's pages up front -- MADV_POPULATE_WRITE -- was
 // measured and dropped: numpy's large arrays are already advised for huge pages and the plain copy was faster there,
 // 0.044 s against 0.055 s for the bench workload's tables; profiles/microbench/pcie_copy.hip.)
 void parallel_copy(void *dst, const void *src, size_t n, int threads)
 {
-    constexpr size_t MIN_PER_THREAD = 2ull << 20;
-    const int t = (int)std::max<size_t>(1, std::min<size_t>((size_t)threads, n / MIN_PER_THREAD));
-    auto piece = [=](size_t a, size_t b) {
-        std::memcpy(static_cast<uint8_t *>(dst) + a, static_cast<const uint8_t *>(src) + a, b - a);
-    };
-    if (t <= 1) {
-        piece(0, n);
-        return;
-    }
-    // (nothing may throw across the C ABI: no allocation here, and a thread that cannot be started is replaced by
-    // doing its slice on this one)
-    constexpr int MAX_THREADS = 64;
-    std::thread pool[MAX_THREADS];
-    size_t todo[MAX_THREADS][2];
-    int n_todo = 0;
-    const int tt = std::min(t, MAX_THREADS);
-    const size_t per_t = ((n + tt - 1) / tt + 4095) & ~(size_t)4095;
-    for (int k = 1; k < tt; ++k) {
-        const size_t a = std::min(n, per_t * k), b = std::min(n, a + per_t);
-        if (a >= b) continue;
-        try {
-            pool[k] = std::thread(piece, a, b);
-        } catch (...) {
-            todo[n_todo][0] = a;
-            todo[n_todo][1] = b;
-            ++n_todo;
-        }
-    }
-    piece(0, std::min(n, per_t));
-    for (int k = 0; k < n_todo; ++k) piece(todo[k][0], todo[k][1]);
-    for (int k = 1; k < tt; ++k)
-        if (pool[k].joinable()) pool[k].join();
+    const CopySeg seg{dst, src, n};
+    parallel_copy_multi(&seg, 1, threads);
 }
 
 // several copies at once, the bytes of all of them dealt evenly to the threads (a slice's four table columns are 5-20 MB
@@ -84,10 +168,9 @@ void parallel_copy_multi(const CopySeg *segs, int n_segs, int threads)
     for (int i = 0; i < n_segs; ++i) total += segs[i].bytes;
     if (!total) return;
     constexpr size_t MIN_PER_THREAD = 1ull << 20;
-    constexpr int MAX_THREADS = 64;
-    const int tt = (int)std::max<size_t>(1, std::min<size_t>(std::min(threads, MAX_THREADS), total / MIN_PER_THREAD));
+    const int tt = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(1, std::min(threads, 64)), total / MIN_PER_THREAD));
     const size_t per_t = ((total + tt - 1) / tt + 4095) & ~(size_t)4095;
-    auto work = [=](int k) {  // thread k takes the bytes [k * per_t, (k + 1) * per_t) of the concatenation
+    auto work = [=](int k) {  // piece k: the bytes [k * per_t, (k + 1) * per_t) of the concatenation
         size_t lo = per_t * (size_t)k, hi = std::min(total, lo + per_t), base = 0;
         for (int i = 0; i < n_segs && lo < hi; ++i) {
             const size_t end = base + segs[i].bytes;
@@ -99,19 +182,15 @@ void parallel_copy_multi(const CopySeg *segs, int n_segs, int threads)
             base = end;
         }
     };
-    std::thread pool[MAX_THREADS];
-    bool started[MAX_THREADS] = {};
-    for (int k = 1; k < tt; ++k) {
-        try {
-            pool[k] = std::thread(work, k);
-            started[k] = true;
-        } catch (...) {
-        }
+    if (tt <= 1) {
+        work(0);
+        return;
     }
-    work(0);
-    for (int k = 1; k < tt; ++k) {
-        if (started[k]) pool[k].join();
-        else work(k);
+    try {
+        const std::function<void(int)> fn = work;
+        CopyPool::get().run(tt, fn);
+    } catch (...) {  // (no memory for the std::function: copy here; a piece copied twice is still the same bytes)
+        for (int k = 0; k < tt; ++k) work(k);
     }
 }
 
