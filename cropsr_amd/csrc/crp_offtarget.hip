@@ -315,6 +315,143 @@ __global__ __launch_bounds__(BLOCK) void ot_partition_kernel(const uint32_t *__r
     });
 }
 
+// ---- level 1 with the chunk STAGED: loaded once into registers (16-byte loads, all in flight), counted and ranked with LDS
+// atomics out of the registers, sorted into LDS, and written out in slot order -- consecutive lanes write consecutive addresses
+// of one run, so the scatter goes out in whole sectors instead of 4-byte pieces of 32-byte ones, and the codes are read from HBM
+// once instead of twice: 0.120 -> 0.076 ms per strand.  (CRP_OT_STAGED=0: the unstaged kernels, for A/B builds.)
+#ifndef CRP_OT_STAGED
+#define CRP_OT_STAGED 1
+#endif
+constexpr uint32_t OT_STAGE = 8192;            // entries per workgroup: 32 KiB of LDS for the sorted chunk
+constexpr int OT_STAGE_TRIPS = OT_STAGE / (4 * BLOCK);  // 16-byte loads per lane
+
+// the chunk [lo, hi) of src into v[] (OT_NOT_A_SITE beyond hi); src + lo is 16-byte aligned
+__device__ __forceinline__ void load_stage(const uint32_t *__restrict__ src, uint64_t lo, uint64_t hi, uint4 (&v)[OT_STAGE_TRIPS])
+{
+#pragma unroll
+    for (int it = 0; it < OT_STAGE_TRIPS; ++it) {
+        const uint64_t t = lo + 4 * ((uint64_t)it * BLOCK + threadIdx.x);
+        if (t + 4 <= hi) {
+            v[it] = *reinterpret_cast<const uint4 *>(src + t);
+        } else {
+            v[it].x = t < hi ? src[t] : OT_NOT_A_SITE;
+            v[it].y = t + 1 < hi ? src[t + 1] : OT_NOT_A_SITE;
+            v[it].z = t + 2 < hi ? src[t + 2] : OT_NOT_A_SITE;
+            v[it].w = t + 3 < hi ? src[t + 3] : OT_NOT_A_SITE;
+        }
+    }
+}
+
+template <class F>
+__device__ __forceinline__ void for_stage(const uint4 (&v)[OT_STAGE_TRIPS], F f)
+{
+#pragma unroll
+    for (int it = 0; it < OT_STAGE_TRIPS; ++it) {
+        f(v[it].x);
+        f(v[it].y);
+        f(v[it].z);
+        f(v[it].w);
+    }
+}
+
+// inclusive scan over the 64 lanes of a wave
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t x)
+{
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t y = __shfl_up(x, d, 64);
+        if (lane >= d) x += y;
+    }
+    return x;
+}
+
+__global__ __launch_bounds__(BLOCK) void ot_partition1_staged_kernel(const uint32_t *__restrict__ seeds, uint64_t n,
+                                                                      uint32_t *__restrict__ cursor1, uint32_t *__restrict__ part1)
+{
+    __shared__ uint32_t sorted[OT_STAGE];
+    __shared__ uint32_t cnt[64], delta[64];
+    __shared__ uint32_t n_valid;
+    const uint64_t lo = (uint64_t)blockIdx.x * OT_STAGE, hi = lo + OT_STAGE < n ? lo + OT_STAGE : n;
+    if (threadIdx.x < 64) cnt[threadIdx.x] = 0;
+    uint4 v[OT_STAGE_TRIPS];
+    load_stage(seeds, lo, hi, v);
+    __syncthreads();
+    for_stage(v, [&](uint32_t code) {
+        if (code < OT_SEEDS) atomicAdd(&cnt[code >> 18], 1u);
+    });
+    __syncthreads();
+    if (threadIdx.x < 64) {  // wave 0: where every digit's run starts in the chunk, and in the super-bucket it goes to
+        const uint32_t c = cnt[threadIdx.x];
+        const uint32_t incl = wave_inclusive_scan(c), ex = incl - c;
+        const uint32_t g = c ? atomicAdd(&cursor1[threadIdx.x], c) : 0;
+        delta[threadIdx.x] = g - ex;  // (mod 2^32)
+        cnt[threadIdx.x] = ex;
+        if (threadIdx.x == 63) n_valid = incl;
+    }
+    __syncthreads();
+    for_stage(v, [&](uint32_t code) {
+        if (code < OT_SEEDS) sorted[atomicAdd(&cnt[code >> 18], 1u)] = code;
+    });
+    __syncthreads();
+    const uint32_t m = n_valid;
+    for (uint32_t i = threadIdx.x; i < m; i += BLOCK) {
+        const uint32_t code = sorted[i];
+        part1[delta[code >> 18] + i] = code;
+    }
+}
+
+// Level 2 with the chunk held in registers between its two passes: the codes are read from HBM once (0.103 -> 0.099 ms per
+// strand).  Sorting it through LDS as level 1 does costs more than it saves here -- 4096 counters to scan and 64 KiB of LDS per
+// workgroup: 0.126 ms (measured, profiles/EXPERIMENTS.md round 6).
+constexpr int OT_CHUNK_TRIPS = OT_CHUNK / (4 * BLOCK);
+__global__ __launch_bounds__(BLOCK) void ot_partition_reg_kernel(const uint32_t *__restrict__ seeds, uint64_t n,
+                                                                  const unsigned long long *__restrict__ n_ptr,
+                                                                  uint32_t *__restrict__ cursor, uint16_t *__restrict__ part)
+{
+    __shared__ uint32_t cnt[OT_BUCKETS];  // first the chunk's count per bucket, then its next write index
+    if (n_ptr) n = *n_ptr;
+    const uint64_t lo = (uint64_t)blockIdx.x * OT_CHUNK;
+    if (lo >= n) return;
+    const uint64_t hi = lo + OT_CHUNK < n ? lo + OT_CHUNK : n;
+    for (uint32_t b = threadIdx.x; b < OT_BUCKETS; b += BLOCK) cnt[b] = 0;
+    uint4 v[OT_CHUNK_TRIPS];
+#pragma unroll
+    for (int it = 0; it < OT_CHUNK_TRIPS; ++it) {
+        const uint64_t t = lo + 4 * ((uint64_t)it * BLOCK + threadIdx.x);
+        if (t + 4 <= hi) {
+            v[it] = *reinterpret_cast<const uint4 *>(seeds + t);
+        } else {
+            v[it].x = t < hi ? seeds[t] : OT_NOT_A_SITE;
+            v[it].y = t + 1 < hi ? seeds[t + 1] : OT_NOT_A_SITE;
+            v[it].z = t + 2 < hi ? seeds[t + 2] : OT_NOT_A_SITE;
+            v[it].w = t + 3 < hi ? seeds[t + 3] : OT_NOT_A_SITE;
+        }
+    }
+    __syncthreads();
+    auto each = [&](auto f) {
+#pragma unroll
+        for (int it = 0; it < OT_CHUNK_TRIPS; ++it) {
+            f(v[it].x);
+            f(v[it].y);
+            f(v[it].z);
+            f(v[it].w);
+        }
+    };
+    each([&](uint32_t code) {
+        if (code < OT_SEEDS) atomicAdd(&cnt[code >> 12], 1u);
+    });
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < OT_BUCKETS; b += BLOCK) {
+        const uint32_t c = cnt[b];
+        cnt[b] = c ? atomicAdd(&cursor[b], c) : 0;  // this chunk's range in bucket b starts here
+    }
+    __syncthreads();
+    each([&](uint32_t code) {
+        if (code < OT_SEEDS) part[atomicAdd(&cnt[code >> 12], 1u)] = (uint16_t)(code & 0xfffu);
+    });
+}
+
 __global__ __launch_bounds__(1024) void ot_bucket_hist_kernel(const uint16_t *__restrict__ part,
                                                                const uint32_t *__restrict__ bucket_start,
                                                                uint32_t *__restrict__ hist)
@@ -544,10 +681,18 @@ int crp_offtarget_add(crp_arena *a, int guide_len, const uint64_t *own_ranges, u
                                    a->d_ot_own, (uint32_t)n_ranges, a->d_ot_seed[1], d_total);
             hipLaunchKernelGGL(crp::ot_bucket_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_total, d_start, d_cursor, d_cursor1,
                                d_n + s);
+#if CRP_OT_STAGED
+            const uint32_t stages = (uint32_t)((n + crp::OT_STAGE - 1) / crp::OT_STAGE);
+            hipLaunchKernelGGL(crp::ot_partition1_staged_kernel, dim3(stages), dim3(crp::BLOCK), 0, ctx->stream, a->d_ot_seed[s], n, d_cursor1,
+                               ctx->d_ot_part1);
+            hipLaunchKernelGGL(crp::ot_partition_reg_kernel, dim3(chunks), dim3(crp::BLOCK), 0, ctx->stream, ctx->d_ot_part1, n,
+                               reinterpret_cast<const unsigned long long *>(d_n + s), d_cursor, ctx->d_ot_part);
+#else
             hipLaunchKernelGGL(crp::ot_partition1_kernel, dim3(chunks), dim3(crp::BLOCK), 0, ctx->stream, a->d_ot_seed[s], n, d_cursor1,
                                ctx->d_ot_part1);
             hipLaunchKernelGGL(crp::ot_partition_kernel, dim3(chunks), dim3(crp::BLOCK), 0, ctx->stream, ctx->d_ot_part1, n,
                                reinterpret_cast<const unsigned long long *>(d_n + s), d_cursor, ctx->d_ot_part);
+#endif
             hipLaunchKernelGGL(crp::ot_bucket_hist_kernel, dim3(crp::OT_BUCKETS), dim3(1024), 0, ctx->stream, ctx->d_ot_part, d_start,
                                ctx->d_ot_hist);
             CRP_HIP(ctx, hipGetLastError());
