@@ -1,6 +1,6 @@
 #!/bin/bash
 # Collect the rocprofv3 evidence bench.py's roofline numbers are judged against.
-# Run on the GPU box from the repo root:   bash profiles/collect.sh r05 [tair10|ecoli|sorghum]
+# Run on the GPU box from the repo root:   bash profiles/collect.sh r06 [tair10|ecoli|sorghum]
 # Writes raw rocprof output under gpurun_out/prof_<tag>/ (scratch) and the
 # summaries under gpurun_out/profiles_<tag>/ -- copy those into profiles/.
 #   1. --kernel-trace --stats      : per-kernel average durations of the bench command
@@ -8,7 +8,7 @@
 #   3. --pmc WRITE_SIZE            : HBM write traffic  (separate pass)
 #   4. --pmc SQ_* (two passes)     : where the emit kernel's wave time goes
 set -e
-TAG=${1:-r05}
+TAG=${1:-r06}
 WL=${2:-}   # optional: tair10 | ecoli | sorghum -- the same passes on one of the smaller configs of BASELINE.json (-> *_$WL directories)
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
@@ -18,7 +18,7 @@ rm -rf "$RAW" "$OUT"
 mkdir -p "$RAW" "$OUT"
 # 300 timed steps: rocprofv3's per-kernel AVERAGE is over every launch of the process, and the ~100 untimed launches
 # in front of the timed region include the ones that bring the clocks up (bench.py --preheat-ms)
-BENCH="python3 bench.py --steps 300 --warmup 2 --cpu-sample-bases 0 --offtarget-steps 3${WL:+ --workload $WL}"
+BENCH="python3 bench.py --steps 300 --warmup 2 --cpu-sample-bases 0 --offtarget-steps 3 --no-pipelined${WL:+ --workload $WL}"
 
 rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/trace -- $BENCH > $OUT/bench_under_trace.json 2> $RAW/trace.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $RAW/fetch -- $BENCH > /dev/null 2> $RAW/fetch.err

@@ -1,9 +1,9 @@
 #!/bin/bash
 # The files of profiles/rNN/ that profiles/collect.sh does not write, for the SAME library build:
-#   bash profiles/extras.sh r05 [soak]     (GPU box, repo root; `soak` adds the 900-trial fuzz in all four scan-mode x geometry combinations and of the node handle, ~9 minutes)
+#   bash profiles/extras.sh r06 [soak]     (GPU box, repo root; `soak` adds the 900-trial fuzz in all four scan-mode x geometry combinations and of the node handle, ~9 minutes)
 # Everything lands under gpurun_out/profiles_<tag>/; copy it into profiles/<tag>/ beside collect.sh's files.
 set -e
-TAG=${1:-r05}
+TAG=${1:-r06}
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 RAW=gpurun_out/prof_$TAG
@@ -47,9 +47,15 @@ python3 tools/e2e_cli.py sorghum --annotate 34000 --devices 0,0,0,0 > $OUT/e2e_c
 python3 tools/annotate_bench.py sorghum 34000 > $OUT/annotate_lookup_sorghum.json 2> $RAW/ann1.err
 python3 tools/annotate_bench.py tair10 27000 > $OUT/annotate_lookup_tair10.json 2> $RAW/ann2.err
 { for p in 1 4; do python3 tools/e2e_cli.py tair10 --procs $p --md5 --cli-flag=--offtarget; done; } > $OUT/multi_process_cli_md5.txt 2> $RAW/md5.err
+# round 6: seam 1 as a pipeline on the default genome (the C-side wall clock of crp_scan_stream under the knobs) and the link / file
+# microbenchmarks its design rests on
+python3 tools/stream_tune.py > $OUT/stream_tune.jsonl 2> $RAW/stream_tune.err
+hipcc -O2 --offload-arch=gfx950 profiles/microbench/duplex_copy.hip -o $RAW/duplex_copy && $RAW/duplex_copy 1024 > $OUT/duplex_copy.json
+g++ -O2 -pthread profiles/microbench/file_write.cpp -o $RAW/file_write && $RAW/file_write /tmp/crp_file_write.tmp 6 16 > $OUT/file_write.txt
 if [ "$2" = soak ]; then
   CROPSR_FUZZ_TRIALS=900 CROPSR_FUZZ_PROGRESS=$RAW/fuzz_progress.txt python3 -m pytest -q tests/test_gpu_parity.py::test_randomised_arenas_vs_oracle \
       tests/test_offtarget.py::test_gpu_randomised_genomes_vs_oracle tests/test_node.py::test_node_randomised_genomes_vs_oracle \
+      tests/test_stream.py::test_scan_stream_randomised_genomes_vs_oracle tests/test_fake_rccl.py::test_node_randomised_genomes_on_rccl_double \
       > $OUT/fuzz_soak_900_trials_x4_modes.log 2>&1
 fi
 ls -la $OUT

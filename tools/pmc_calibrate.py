@@ -85,7 +85,8 @@ def main():
             return None
         return launches_per_step * (2 * v["FETCH_SIZE_bytes_raw"] + v["WRITE_SIZE_bytes_raw"])
     groups = {"seed_partition_histogram": [("crp::ot_seed_from_raw_kernel", 2), ("crp::ot_bucket_scan_kernel", 2),
-                                           ("crp::ot_partition1_kernel", 2), ("crp::ot_partition_kernel", 2),
+                                           # (round 6: level 1 staged through LDS, level 2 with its chunk in registers)
+                                           ("crp::ot_partition1_staged_kernel", 2), ("crp::ot_partition_reg_kernel", 2),
                                            ("crp::ot_bucket_hist_kernel", 2)],
               "ball_passes": [("crp::ot_ball_kernel<0, true>", 1), ("crp::ot_ball_kernel<8, false>", 1), ("crp::ot_ball_kernel<16, false>", 1)],
               "lookup_gather": [("crp::ot_lookup_kernel", 2)]}
@@ -101,7 +102,7 @@ def main():
                "lookup_gather_bytes_per_request": (ot["lookup_gather"] / bench["config"]["kept_hits_total"]
                                                    if ot.get("lookup_gather") and bench.get("config") else None),
                "correction": "reads = FETCH_SIZE x 1024 x 2 (every line reaching the fabric is tallied at 64 B: calibrated on "
-                             "streams, strided and random 16-byte gathers, profiles/r05/fetch_calibration.json); writes = "
+                             "streams, strided and random 16-byte gathers, profiles/r06/fetch_calibration.json); writes = "
                              "WRITE_SIZE x 1024 (exact for streaming stores; 32-byte sectors per scattered store)",
                "source": "tools/pmc_calibrate.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"}
     # the annotation look-up: bench.py's own annotate block runs it on the BENCH workload's tables (that is the figure the

@@ -3,7 +3,7 @@
 # and the annotation join's kernels.  GPU box, repo root:  bash tools/pmc_calibrate.sh [tag]
 # Separate --pmc passes, --kernel-trace only beside them (MI355X_MICROARCH.md; the pool refuses other combinations).
 set -e
-TAG=${1:-r05}
+TAG=${1:-r06}
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 RAW=gpurun_out/pmc_cal_$TAG
@@ -14,7 +14,7 @@ $RAW/fetch_cal > $RAW/patterns.jsonl
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $RAW/cal_fetch -- $RAW/fetch_cal > /dev/null 2> $RAW/cal_fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $RAW/cal_write -- $RAW/fetch_cal > /dev/null 2> $RAW/cal_write.err
 # the product's kernels on the bench genome: scan, off-target block (5 steps), annotation join (tools/annotate_bench.py)
-BENCH="python3 bench.py --steps 20 --warmup 2 --cpu-sample-bases 0 --offtarget-steps 5"
+BENCH="python3 bench.py --steps 20 --warmup 2 --cpu-sample-bases 0 --offtarget-steps 5 --no-pipelined"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $RAW/bench_fetch -- $BENCH > /dev/null 2> $RAW/bench_fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $RAW/bench_write -- $BENCH > /dev/null 2> $RAW/bench_write.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/bench_trace -- $BENCH > $RAW/bench_under_trace.json 2> $RAW/bench_trace.err
