@@ -1214,6 +1214,12 @@ def main():
             env = {k: v for k, v in os.environ.items()
                    if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_ADDR",
                                 "MASTER_PORT", "CROPSR_LAUNCHED", "CROPSR_RDZV_ENDPOINT", "TORCHELASTIC_RUN_ID")}
+            if args.collective_timeout > 0:
+                # the library bounds its own RCCL waits (crp_node.cpp): a bootstrap or a group that never comes back is given up
+                # inside the child, which then finishes on device-to-device copies and SAYS so (`note`) -- well inside the limit
+                # after which the child would be killed with nothing to show
+                env.setdefault("CRP_NODE_COMM_INIT_TIMEOUT_S", "%.0f" % max(10.0, 0.4 * args.collective_timeout))
+                env.setdefault("CRP_NODE_COLLECTIVE_TIMEOUT_S", "%.0f" % max(10.0, 0.3 * args.collective_timeout))
             t_child = time.perf_counter()
             try:
                 limit = (args.collective_timeout + 120.0) if args.collective_timeout > 0 else None

@@ -451,10 +451,10 @@ def test_bench_strong_block_on_rccl_double():
     """bench.py's process-per-GPU line with three ranks sharing GPU 0 and RCCL forced (CROPSR_BENCH_FORCE_RCCL=1): fences and
     sums on ncclAllReduce, the weak gatherv and the strong block's gatherv on crp_gather_hits -- digest_ok, RCCL named."""
     import fake_rccl
-    with fake_rccl.Session(CROPSR_BENCH_FORCE_RCCL="1") as s:
+    with fake_rccl.Session(CROPSR_BENCH_FORCE_RCCL="1", CRP_NODE_TRANSPORT="try") as s:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1",
                "--master-port", "29571", os.path.join(ROOT, "bench.py"), "--gpus", "3", "--share-gpu0", "--scale", "0.02", "--steps", "2",
-               "--warmup", "1", "--offtarget-steps", "1", "--no-node-block"]
+               "--warmup", "1", "--offtarget-steps", "1"]
         p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=s.env())
         assert p.returncode == 0, p.stderr[-4000:]
         lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
@@ -462,5 +462,12 @@ def test_bench_strong_block_on_rccl_double():
         d = json.loads(lines[0])
         assert d["n_gpus"] == 3 and "rccl_error" not in d and d["gatherv_ok"] is True
         assert d["strong"]["digest_ok"] is True and d["strong"]["gatherv_transport"].startswith("RCCL")
+        # rank 0's closing node block: a child process drives the same three (logical) devices through the node handle --
+        # ncclCommInitAll + one grouped send/recv in ONE process (CRP_NODE_TRANSPORT=try: RCCL although GPU 0 is listed thrice)
+        nb = d["single_process_node"]
+        assert "error" not in nb and nb["digest_ok"] is True and nb["gatherv"]["transport"].startswith("RCCL"), nb
         stats = s.stats()
-        assert len(stats) == 3 and all(x["mismatches"] == 0 for x in stats) and max(x["pairs"] for x in stats) > 4, stats
+        ranks = [x for x in stats if not x["in_process"]]
+        node = [x for x in stats if x["in_process"]]
+        assert len(ranks) == 3 and all(x["mismatches"] == 0 for x in stats) and max(x["pairs"] for x in ranks) > 4, stats
+        assert len(node) == 3 and node[0]["pairs"] > 4, stats

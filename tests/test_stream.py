@@ -118,6 +118,8 @@ def test_scan_stream_randomised_genomes_vs_oracle(oracle):
             l = 20 if rng.random() < 0.7 else int(rng.integers(0, 51))
             pre = bool(rng.random() < 0.25)
             slice_chars = int(rng.choice([1, 400, 1000, 5000, 30_000, 100_000, 0]))
+            # both scan modes and both tile shapes behind the pipeline (the three-launch sequence runs inside the drainer's wait)
+            eng.configure(two_pass=bool(rng.random() < 0.3), geometry=str(rng.choice(["auto", "large", "small"])))
             hits = eng.scan_stream(contigs, l, want_pre=pre, slice_chars=slice_chars, density=float(rng.choice([0.02, 0.2, 1.0])))
             total += _check_against_oracle(hits, contigs, oracle, l, (trial, l, pre, slice_chars), pre=pre)
             cuts += int(hits.stream_stats["slices"] > 1)
