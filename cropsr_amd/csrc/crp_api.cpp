@@ -197,7 +197,7 @@ void parallel_copy_multi(const CopySeg *segs, int n_segs, int threads)
 int staging_ready(crp_ctx *ctx)
 {
     if (ctx->pin[0]) return CRP_OK;
-    for (int b = 0; b < 2; ++b) {
+    for (int b = 0; b < crp_ctx::N_PIN; ++b) {
         CRP_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->pin[b]), STAGE_CHUNK, hipHostMallocDefault));
         CRP_HIP(ctx, hipEventCreateWithFlags(&ctx->pin_done[b], hipEventDisableTiming));
         ctx->pin_busy[b] = false;
@@ -381,7 +381,7 @@ int crp_destroy(crp_ctx *ctx)
     (void)hipFree(ctx->d_rscore);
     (void)hipFree(ctx->d_scalar);
     if (ctx->h_scalar) (void)hipHostFree(ctx->h_scalar);
-    for (int b = 0; b < 2; ++b) {
+    for (int b = 0; b < crp_ctx::N_PIN; ++b) {
         if (ctx->pin[b]) (void)hipHostFree(ctx->pin[b]);
         if (ctx->pin_done[b]) (void)hipEventDestroy(ctx->pin_done[b]);
     }
@@ -581,7 +581,7 @@ int crp_arena_add_contig_ascii(crp_arena *a, const uint8_t *text, uint64_t len, 
             CRP_HIP(ctx, hipMemcpyAsync(ctx->d_text, text + c0, c1 - c0, hipMemcpyHostToDevice, ctx->stream));
         } else if (c1 > c0) {
             const int b = ctx->pin_next;
-            ctx->pin_next ^= 1;
+            ctx->pin_next = (ctx->pin_next + 1) % crp_ctx::N_PIN;
             if (ctx->pin_busy[b]) {
                 CRP_HIP(ctx, hipEventSynchronize(ctx->pin_done[b]));
                 ctx->pin_busy[b] = false;
@@ -637,7 +637,7 @@ int crp_arena_add_contigs_ascii(crp_arena *a, const uint8_t *const *texts, const
         int rc = crp::staging_ready(ctx);
         if (rc != CRP_OK) return rc;
         const int b = ctx->pin_next;
-        ctx->pin_next ^= 1;
+        ctx->pin_next = (ctx->pin_next + 1) % crp_ctx::N_PIN;
         if (ctx->pin_busy[b]) {
             CRP_HIP(ctx, hipEventSynchronize(ctx->pin_done[b]));
             ctx->pin_busy[b] = false;

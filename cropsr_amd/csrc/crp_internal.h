@@ -35,9 +35,12 @@ struct crp_ctx {
     uint32_t mute_tile = 0xffffffffu;  // test hook (environment CRP_TEST_MUTE_TILE): see crp_kernels.h
     // host <-> device staging for large transfers from / to pageable caller memory (crp_api.cpp: staged_h2d / staged_d2h):
     // two pinned buffers, filled / drained by a few host threads while the other one is on the link
-    uint8_t *pin[2] = {nullptr, nullptr};
-    hipEvent_t pin_done[2] = {nullptr, nullptr};
-    bool pin_busy[2] = {false, false};
+    // (three: the uploads ring through all of them, so the host is a whole round ahead of the link and the copy engine
+    // always has the next round queued; the staged copies of tables use the first two)
+    static constexpr int N_PIN = 3;
+    uint8_t *pin[N_PIN] = {nullptr, nullptr, nullptr};
+    hipEvent_t pin_done[N_PIN] = {nullptr, nullptr, nullptr};
+    bool pin_busy[N_PIN] = {false, false, false};
     int pin_next = 0;  // the buffer the next upload round takes
     int copy_threads = 8;  // environment CRP_COPY_THREADS
     // measurement
