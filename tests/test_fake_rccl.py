@@ -253,7 +253,7 @@ def _child_failure(out, world, mode):
 
 # ------------------------------------------------------------------ the node handle (one process) on the double
 @pytest.mark.gpu
-@pytest.mark.parametrize("world", [2, 3, 4, 7])
+@pytest.mark.parametrize("world", [2, 3, 4, 7, 8])
 def test_node_logical_devices_on_rccl_double(world):
     """ncclCommInitAll over `world` logical devices, then every gather as ONE group of sends and receives: packed and raw
     positions, the pre-sigmoid column, another root -- the oracle's rows, every send matched by a receive of the same size."""
@@ -400,7 +400,7 @@ def test_cli_devices_on_a_hung_rccl_exits_like_the_reference(manifest, tmp_path)
 
 # ------------------------------------------------------------------ one process per GPU (crp_comm.cpp) on the double
 @pytest.mark.gpu
-@pytest.mark.parametrize("nproc,extra", [(2, ()), (3, ("--offtarget", "--annotate")), (2, ("--score-finalize", "host"))])
+@pytest.mark.parametrize("nproc,extra", [(2, ()), (3, ("--offtarget", "--annotate")), (2, ("--score-finalize", "host")), (4, ("--offtarget",))])
 def test_cli_multi_process_on_rccl_double(nproc, extra, manifest, tmp_path):
     """`python -m torch.distributed.run --nproc-per-node N -m cropsr_amd ...` with every rank on GPU 0 and the exchange on
     RCCL (no CROPSR_GATHER=host): ncclCommInitRank over the mailbox, crp_gather_hits' two all-gather rounds and its grouped
