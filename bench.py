@@ -923,6 +923,7 @@ def main():
                     pinned.append(st["wall_s"])
                 del h
             del out
+            q_after = eng.query()
             up_bytes, down_bytes = int(sum(int(x.size) for x in kept_strings)), 12 * int(n_plus + n_minus)
             med = lambda v: sorted(v)[len(v) // 2]
             pipelined = {"pipelined_s": med(fresh), "pipelined_into_pinned_tables_s": med(pinned), "pipelined_best_s": min(fresh),
@@ -930,6 +931,8 @@ def main():
                          "runs_s": {"fresh_pageable_tables": fresh, "pinned_tables": pinned}, "pinning_the_tables_once_s": t_pin,
                          "fetch_tables_into_pinned_arrays_s": t_fetch_pinned,
                          "slices": int(stats_fresh["slices"]), "lanes": int(stats_fresh["lanes"]),
+                         # (scans of the pipeline whose look-back timed out and were repeated with three launches: none expected)
+                         "chain_timeouts_after": q_after["chain_timeouts"], "three_launch_mode_after": bool(q_after["two_pass_active"]),
                          "first_slice_on_host_s": stats_fresh["first_slice_on_host_s"],
                          "uploader_busy_s": stats_fresh["uploader_busy_s"], "copier_busy_s": stats_fresh["copier_busy_s"],
                          "bytes_up": up_bytes, "bytes_down": down_bytes,

@@ -13,11 +13,9 @@
 
 #include <algorithm>
 #include <atomic>
-#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <functional>
 #include <mutex>
 #include <new>
 #include <string>
@@ -42,115 +40,11 @@ inline uint64_t round_up(uint64_t x, uint64_t m) { return (x + m - 1) / m * m; }
 namespace crp {
 
 // ---- host-side copies between the caller's pages and the pinned staging buffers
-// A pool of copy threads that lives as long as the process: starting eight threads per 32 MiB chunk, one after the other,
-// cost a quarter of the copy itself (8 x 20-40 us against 0.6 ms) -- the staging copy, not the link, bounded an upload at 41 of
-// the link's 56 GB/s.  Any number of callers may hand work to the pool at the same time (the pipelined scan's uploader and
-// copier do); the caller takes part in its own job, so a pool that could not be started, or is busy, only makes a copy
-// slower, never wrong.  The threads are never joined (a process that exits while they sleep on the condition variable is fine).
-namespace {
-
-struct PoolJob {
-    const std::function<void(int)> *fn = nullptr;
-    int n = 0;
-    std::atomic<int> next{0}, done{0};
-};
-
-class CopyPool {
-public:
-    static CopyPool &get()
-    {
-        static CopyPool *pool = new (std::nothrow) CopyPool();  // (leaked on purpose: see above)
-        static CopyPool none(0);
-        return pool ? *pool : none;
-    }
-    // fn(0) .. fn(n - 1), each exactly once, on the pool's threads and on this one; returns when all are done
-    void run(int n, const std::function<void(int)> &fn)
-    {
-        if (n <= 0) return;
-        if (n == 1 || n_threads_ == 0) {
-            for (int k = 0; k < n; ++k) fn(k);
-            return;
-        }
-        PoolJob job;
-        job.fn = &fn;
-        job.n = n;
-        {
-            std::lock_guard<std::mutex> lk(m_);
-            jobs_.push_back(&job);
-        }
-        wake_.notify_all();
-        work_on(job);
-        std::unique_lock<std::mutex> lk(m_);  // (the job leaves the queue before this returns: nobody holds a pointer to it afterwards)
-        for (auto it = jobs_.begin(); it != jobs_.end(); ++it)
-            if (*it == &job) {
-                jobs_.erase(it);
-                break;
-            }
-        finished_.wait(lk, [&] { return job.done.load() == job.n; });
-    }
-
-private:
-    explicit CopyPool(int n) : n_threads_(n) {}
-    CopyPool()
-    {
-        const unsigned hw = std::thread::hardware_concurrency();
-        int want = (int)std::max(1u, std::min(32u, hw ? hw / 2 : 4u));
-        if (const char *e = std::getenv("CRP_COPY_POOL_THREADS")) want = std::max(0, std::min(64, std::atoi(e)));
-        for (int k = 0; k < want; ++k) {
-            try {
-                std::thread([this] { loop(); }).detach();
-                ++n_threads_;
-            } catch (...) {
-                break;
-            }
-        }
-    }
-    void work_on(PoolJob &job)
-    {
-        for (;;) {
-            const int k = job.next.fetch_add(1);
-            if (k >= job.n) return;
-            (*job.fn)(k);
-            if (job.done.fetch_add(1) + 1 == job.n) {
-                std::lock_guard<std::mutex> lk(m_);  // (the waiter checks `done` under this mutex)
-                finished_.notify_all();
-            }
-        }
-    }
-    void loop()
-    {
-        std::unique_lock<std::mutex> lk(m_);
-        for (;;) {
-            wake_.wait(lk, [&] {
-                for (PoolJob *j : jobs_)
-                    if (j->next.load() < j->n) return true;
-                return false;
-            });
-            PoolJob *job = nullptr;
-            for (PoolJob *j : jobs_)
-                if (j->next.load() < j->n) {
-                    job = j;
-                    break;
-                }
-            if (!job) continue;
-            // claim one piece while the job is known to be alive (it is still in the queue and we hold the mutex)
-            const int k = job->next.fetch_add(1);
-            if (k >= job->n) continue;
-            lk.unlock();
-            (*job->fn)(k);
-            const bool last = job->done.fetch_add(1) + 1 == job->n;
-            lk.lock();
-            if (last) finished_.notify_all();
-        }
-    }
-    std::mutex m_;
-    std::condition_variable wake_, finished_;
-    std::vector<PoolJob *> jobs_;
-    int n_threads_ = 0;
-};
-
-}  // namespace
-
+// (Round 6 kept the copy threads in a process-wide pool for a while -- no thread start per 32 MiB chunk.  It bought nothing
+// measurable, the staging copy is not what an upload waits for, and with 8 or more threads sleeping in the pool a caller that
+// frees its result arrays between scans -- bench.py's pipelined block on the E. coli-like genome -- saw the NEXT scan's work on
+// the GPU complete 17 ms late, every time (not with 0-2 pool threads, not with the arrays kept alive, not with threads that
+// are started per copy and gone afterwards; profiles/EXPERIMENTS.md round 6).  Threads per copy it is.)
 // memcpy spread over a few threads.  (Asking the kernel for the destination's pages up front -- MADV_POPULATE_WRITE -- was
 // measured and dropped: numpy's large arrays are already advised for huge pages and the plain copy was faster there,
 // 0.044 s against 0.055 s for the bench workload's tables; profiles/microbench/pcie_copy.hip.)
@@ -167,7 +61,8 @@ void parallel_copy_multi(const CopySeg *segs, int n_segs, int threads)
     size_t total = 0;
     for (int i = 0; i < n_segs; ++i) total += segs[i].bytes;
     if (!total) return;
-    constexpr size_t MIN_PER_THREAD = 1ull << 20;
+    // (4 MiB per thread at least: a 32 MiB staging round still takes eight threads, a small genome's tables take one)
+    constexpr size_t MIN_PER_THREAD = 4ull << 20;
     const int tt = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(1, std::min(threads, 64)), total / MIN_PER_THREAD));
     const size_t per_t = ((total + tt - 1) / tt + 4095) & ~(size_t)4095;
     auto work = [=](int k) {  // piece k: the bytes [k * per_t, (k + 1) * per_t) of the concatenation
@@ -186,11 +81,22 @@ void parallel_copy_multi(const CopySeg *segs, int n_segs, int threads)
         work(0);
         return;
     }
-    try {
-        const std::function<void(int)> fn = work;
-        CopyPool::get().run(tt, fn);
-    } catch (...) {  // (no memory for the std::function: copy here; a piece copied twice is still the same bytes)
-        for (int k = 0; k < tt; ++k) work(k);
+    // (nothing may throw across the C ABI: no allocation here, and a thread that cannot be started is replaced by doing its
+    // piece on this one)
+    constexpr int MAX_THREADS = 64;
+    std::thread pool[MAX_THREADS];
+    bool started[MAX_THREADS] = {};
+    for (int k = 1; k < tt; ++k) {
+        try {
+            pool[k] = std::thread(work, k);
+            started[k] = true;
+        } catch (...) {
+        }
+    }
+    work(0);
+    for (int k = 1; k < tt; ++k) {
+        if (started[k]) pool[k].join();
+        else work(k);
     }
 }
 
@@ -233,10 +139,13 @@ int staged_h2d(crp_ctx *ctx, void *d_dst, const void *src, size_t n)
         CRP_HIP(ctx, hipStreamSynchronize(ctx->stream));
         return CRP_OK;
     }
-    if (n < STAGE_CHUNK / 4) {  // small: the runtime's own path (which returns once `src` has been read)
+    if (n < (64u << 10)) {  // tiny: the runtime's own path (it copies such a source into its staging area and returns)
         if (n) CRP_HIP(ctx, hipMemcpyAsync(d_dst, src, n, hipMemcpyHostToDevice, ctx->stream));
         return CRP_OK;
     }
+    // anything larger goes through OUR pinned buffers, never through the runtime's path for pageable memory: that one
+    // registers the caller's pages with the driver, and freeing such memory later costs the process a quiesce and restore of
+    // its GPU queues (staged_d2h below; profiles/EXPERIMENTS.md round 6)
     int rc = staging_ready(ctx);
     if (rc != CRP_OK) return rc;
     int b = 0;
@@ -254,11 +163,10 @@ int staged_h2d(crp_ctx *ctx, void *d_dst, const void *src, size_t n)
 
 int staged_d2h(crp_ctx *ctx, void *dst, const void *d_src, size_t n)
 {
-    if (n < STAGE_CHUNK / 4 || is_pinned_host(dst)) {  // small, or DMA straight into the caller's pinned pages
-        if (n) {
-            CRP_HIP(ctx, hipMemcpyAsync(dst, d_src, n, hipMemcpyDeviceToHost, ctx->stream));
-            CRP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        }
+    if (!n) return CRP_OK;
+    if (is_pinned_host(dst)) {  // DMA straight into the caller's pinned pages
+        CRP_HIP(ctx, hipMemcpyAsync(dst, d_src, n, hipMemcpyDeviceToHost, ctx->stream));
+        CRP_HIP(ctx, hipStreamSynchronize(ctx->stream));
         return CRP_OK;
     }
     int rc = staging_ready(ctx);
@@ -266,6 +174,16 @@ int staged_d2h(crp_ctx *ctx, void *dst, const void *d_src, size_t n)
     for (int b = 0; b < 2; ++b) {
         rc = pin_wait(ctx, b);
         if (rc != CRP_OK) return rc;
+    }
+    if (n <= STAGE_CHUNK) {
+        // Small: one bounce through a staging buffer.  NEVER the runtime's own path for pageable memory: it registers the
+        // caller's pages with the driver for the copy, and when the caller later frees that memory (numpy arrays of a few MB)
+        // the driver quiesces and restores the process's GPU queues -- the next launch completed 17 ms late, every time
+        // (bench.py --workload ecoli, profiles/EXPERIMENTS.md round 6).
+        CRP_HIP(ctx, hipMemcpyAsync(ctx->pin[0], d_src, n, hipMemcpyDeviceToHost, ctx->stream));
+        CRP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        parallel_copy(dst, ctx->pin[0], n, ctx->copy_threads);
+        return CRP_OK;
     }
     // chunk k is copied out of its pinned buffer by the host threads (which also take the first-touch page faults of a
     // fresh destination, in parallel) while chunk k + 1 crosses the link into the other one
@@ -1134,10 +1052,12 @@ int crp_score_30mers(crp_ctx *ctx, const uint8_t *rows, uint64_t n, int order, d
         CRP_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_rscore), cap * sizeof(double)));
         ctx->d_rows_cap = cap;
     }
-    CRP_HIP(ctx, hipMemcpyAsync(ctx->d_rows, rows, n * 30, hipMemcpyHostToDevice, ctx->stream));
+    int rc = crp::staged_h2d(ctx, ctx->d_rows, rows, n * 30);  // (the caller's rows and results are pageable: our staging, not the runtime's)
+    if (rc != CRP_OK) return rc;
     CRP_HIP(ctx, crp::launch_score30(ctx->stream, ctx->d_rows, n, order, ctx->d_rpre, ctx->d_rscore));
-    if (pre) CRP_HIP(ctx, hipMemcpyAsync(pre, ctx->d_rpre, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    CRP_HIP(ctx, hipMemcpyAsync(score, ctx->d_rscore, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (pre) rc = crp::staged_d2h(ctx, pre, ctx->d_rpre, n * sizeof(double));
+    if (rc == CRP_OK) rc = crp::staged_d2h(ctx, score, ctx->d_rscore, n * sizeof(double));
+    if (rc != CRP_OK) return rc;
     CRP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return CRP_OK;
 }

@@ -728,7 +728,10 @@ int crp_offtarget_hist_get(crp_ctx *ctx, uint32_t *hist)
     if (!ctx || !hist) return CRP_ERR_INVALID;
     if (!ctx->d_ot_hist) return CRP_ERR_STATE;
     CRP_HIP(ctx, hipSetDevice(ctx->device));
-    CRP_HIP(ctx, hipMemcpyAsync(hist, ctx->d_ot_hist, (size_t)crp::OT_SEEDS * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    {
+        const int rc = crp::staged_d2h(ctx, hist, ctx->d_ot_hist, (size_t)crp::OT_SEEDS * sizeof(uint32_t));
+        if (rc != CRP_OK) return rc;
+    }
     CRP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return CRP_OK;
 }
@@ -738,7 +741,10 @@ int crp_offtarget_hist_set(crp_ctx *ctx, const uint32_t *hist)
     if (!ctx || !hist) return CRP_ERR_INVALID;
     if (!ctx->d_ot_hist || ctx->ot_solved) return CRP_ERR_STATE;
     CRP_HIP(ctx, hipSetDevice(ctx->device));
-    CRP_HIP(ctx, hipMemcpyAsync(ctx->d_ot_hist, hist, (size_t)crp::OT_SEEDS * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    {
+        const int rc = crp::staged_h2d(ctx, ctx->d_ot_hist, hist, (size_t)crp::OT_SEEDS * sizeof(uint32_t));
+        if (rc != CRP_OK) return rc;
+    }
     CRP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return CRP_OK;
 }
