@@ -41,10 +41,8 @@ namespace crp {
 
 // ---- host-side copies between the caller's pages and the pinned staging buffers
 // (Round 6 kept the copy threads in a process-wide pool for a while -- no thread start per 32 MiB chunk.  It bought nothing
-// measurable, the staging copy is not what an upload waits for, and with 8 or more threads sleeping in the pool a caller that
-// frees its result arrays between scans -- bench.py's pipelined block on the E. coli-like genome -- saw the NEXT scan's work on
-// the GPU complete 17 ms late, every time (not with 0-2 pool threads, not with the arrays kept alive, not with threads that
-// are started per copy and gone afterwards; profiles/EXPERIMENTS.md round 6).  Threads per copy it is.)
+// measurable: the staging copy reads the caller's pages at 41-43 GB/s whatever the thread count and is not what an upload
+// waits for.  Threads per copy it is; profiles/EXPERIMENTS.md round 6.)
 // memcpy spread over a few threads.  (Asking the kernel for the destination's pages up front -- MADV_POPULATE_WRITE -- was
 // measured and dropped: numpy's large arrays are already advised for huge pages and the plain copy was faster there,
 // 0.044 s against 0.055 s for the bench workload's tables; profiles/microbench/pcie_copy.hip.)
