@@ -178,6 +178,46 @@ def test_scan_stream_switchgrass_like_equals_one_arena_scan():
 
 
 @pytest.mark.gpu
+@pytest.mark.slow
+def test_scan_stream_maize_size_genome_equals_engine_genome():
+    """A 2.4 Gb maize-size stand-in -- more than one arena addresses, chromosomes of 150-300 Mb that the default 64 Mi-character
+    slices cut into pieces with halos -- through the pipeline == Engine.genome's tables (arena calls, a genome spread over
+    arenas) by SHA-256 per contig, and the same into tables that are too small first (the capacity protocol at full size)."""
+    import bench_workload as bw
+    from cropsr_amd import Engine
+
+    def digest(h):
+        d = hashlib.sha256()
+        for key in ("pos_plus", "score_plus", "pos_minus", "score_minus"):
+            d.update(np.ascontiguousarray(h[key]).tobytes())
+        return d.hexdigest()
+
+    wl = bw.maize_like()
+    strings = [wl.contig_string(k) for k in range(len(wl.specs))]
+    total = sum(s.size for s in strings)
+    assert total > (1 << 31) and max(s.size for s in strings) > (64 << 20)
+    with Engine(0) as eng:
+        genome = eng.genome(strings)
+        one = genome.scan_score(20)
+        want = [digest(one.contig(k)) for k in range(len(strings))]
+        n_hits = one.n_plus + one.n_minus
+        del one
+        genome.close()
+        hits = eng.scan_stream(strings, 20)
+        stats = hits.stream_stats
+        assert stats["slices"] >= total // (64 << 20)
+        got = [digest(hits.contig(k)) for k in range(len(strings))]
+        assert got == want, [k for k in range(len(strings)) if got[k] != want[k]][:10]
+        assert hits.n_plus + hits.n_minus == n_hits
+        del hits
+        hits = eng.scan_stream(strings, 20, density=1 / 64)  # tables sized for a 64th of the characters: one retry with exact sizes
+        got = [digest(hits.contig(k)) for k in range(len(strings))]
+        assert got == want and hits.n_plus + hits.n_minus == n_hits
+    print("maize-like through the pipeline: %d characters, %d slices on %d lanes, %d hits, %.1f ms host to host"
+          % (total, stats["slices"], stats["lanes"], n_hits, stats["wall_s"] * 1e3))
+
+
+@pytest.mark.gpu
 def test_integration_md_stream_snippet_runs(oracle):
     """The ctypes patch INTEGRATION.md shows for the pipelined seam 1, executed as printed (after the seam-2 block, which opens
     `_crp` and `_ctx`): the tables it ends up with are the oracle's, contig after contig."""
