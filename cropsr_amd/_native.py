@@ -14,6 +14,15 @@ u8p = ctypes.POINTER(ctypes.c_uint8)
 u32p = ctypes.POINTER(ctypes.c_uint32)
 u64p = ctypes.POINTER(ctypes.c_uint64)
 f64p = ctypes.POINTER(ctypes.c_double)
+
+
+class RowSegment(ctypes.Structure):
+    """crp_row_segment (include/cropsr_hip.h): consecutive rows of one contig with their columns, as crp_write_segments takes them."""
+    _fields_ = [("contig_text", ctypes.c_void_p), ("contig_len", ctypes.c_uint64), ("chrom", ctypes.c_void_p), ("chrom_len", ctypes.c_uint64),
+                ("pos", ctypes.c_void_p), ("minus", ctypes.c_void_p), ("score", ctypes.c_void_p), ("ids", ctypes.c_void_p),
+                ("n_rows", ctypes.c_uint64), ("feat_blob", ctypes.c_void_p), ("feat_off", ctypes.c_void_p), ("feat_idx", ctypes.c_void_p),
+                ("offtarget", ctypes.c_void_p)]
+
 voidpp = ctypes.POINTER(ctypes.c_void_p)
 
 # every symbol include/cropsr_hip.h declares: name -> (restype, argtypes)
@@ -53,6 +62,7 @@ SIGNATURES = {
                                        ctypes.POINTER(ctypes.c_int), ctypes.c_int]),
     "crp_write_rows_ex": (ctypes.c_int, [ctypes.c_int, u8p, ctypes.c_uint64, u8p, ctypes.c_uint64, ctypes.c_int, u32p, u8p,
                                          f64p, u8p, ctypes.c_uint64, u8p, u64p, u32p, u32p, u64p, ctypes.c_int]),
+    "crp_write_segments": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_uint64, u64p, ctypes.c_int]),
     "crp_comm_unique_id": (ctypes.c_int, [u8p]),
     "crp_comm_init": (ctypes.c_int, [ctypes.c_void_p, u8p, ctypes.c_int, ctypes.c_int]),
     "crp_comm_destroy": (ctypes.c_int, [ctypes.c_void_p]),

@@ -373,6 +373,7 @@ _ACTIVE_GROUP = None  # the group main() aborts when this rank fails outside an 
 
 
 NATIVE_GUIDE_LENGTHS = (1, 50)  # what the kernels' window logic and the native row formatter are built for
+BATCH_ROWS = 4_000_000  # --each-contig-once: consecutive passes are formatted together until they hold this many rows (CROPSR_BATCH_ROWS)
 
 
 def device_guide_length(l):
@@ -652,6 +653,25 @@ def run(args, backend=None, out=sys.stdout, group=None):
         ids = rows.IdStream(sizes, reverse=True)
     t_stage = time.perf_counter()
     n_rows_written = 0
+    # --each-contig-once with the native writer: a pass is one contig and independent of the others, so consecutive passes
+    # go to the formatter TOGETHER until they make up four million rows (one call, one team of threads, blocks that span short
+    # contigs: a scaffold of 3 500 rows on its own is formatted by a single thread, and a genome has hundreds of them);
+    # the bytes are the passes' bytes one after the other, the per-pass lines of time.txt are written when their rows are
+    import os
+    batching = native and once and not getattr(args, "reference_sleep", False) and os.environ.get("CROPSR_BATCH_PASSES", "1") != "0"
+    batch_limit = int(os.environ.get("CROPSR_BATCH_ROWS", BATCH_ROWS))
+    batch, batch_rows = [], 0
+
+    def flush_batch():
+        nonlocal batch, batch_rows, n_rows_written
+        if not batch:
+            return
+        rows.write_passes_native(args.o, batch, backend.rescore)
+        for ds, _ in batch:
+            n_rows_written += len(ds)
+            timing.write("Total runtime of the program is " + str(time.time() - begin))  # CROPSR.py:477, once per pass
+        batch, batch_rows = [], 0
+
     for name, s, hits in zip(names, strings, all_hits):
         print("Searching on Chromosome: ", name[:25], file=out)  # CROPSR.py:410-411
         print("With start of sequence: ", bytes(s[:25]).decode("latin-1"), file=out)
@@ -671,6 +691,12 @@ def run(args, backend=None, out=sys.stdout, group=None):
             print(f"""
                 {n_sites:n} Cas9 PAM sites were found on {name[1::]}
                 """, file=out)
+        if batching:
+            batch.append((dataset, ids.next(len(dataset))))
+            batch_rows += len(dataset)
+            if batch_rows >= batch_limit:
+                flush_batch()
+            continue
         if native:  # CROPSR.py:442-474
             rows.write_pass_native(args.o, dataset, backend.rescore, ids)
         else:
@@ -680,6 +706,7 @@ def run(args, backend=None, out=sys.stdout, group=None):
         timing.write("Total runtime of the program is " + str(end - begin))  # CROPSR.py:477
         if getattr(args, "reference_sleep", False):
             time.sleep(5)  # CROPSR.py:478
+    flush_batch()
     stages["format_write_s"] = time.perf_counter() - t_stage
     timing.close()
     if ids is not None:

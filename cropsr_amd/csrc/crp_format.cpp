@@ -324,33 +324,66 @@ extern "C" int crp_format_rows(const uint8_t *contig_text, uint64_t contig_len, 
     }
 }
 
-extern "C" int crp_write_rows_ex(int fd, const uint8_t *contig_text, uint64_t contig_len, const uint8_t *chrom,
-                                 uint64_t chrom_len, int guide_len, const uint32_t *pos, const uint8_t *minus,
-                                 const double *score, const uint8_t *ids, uint64_t n_rows, const uint8_t *feat_blob,
-                                 const uint64_t *feat_off, const uint32_t *feat_idx, const uint32_t *offtarget,
-                                 uint64_t *bytes_written, int n_threads)
+// rows of several SEGMENTS appended to fd in segment order: one team of workers for the whole call.  A block -- the unit a
+// worker formats into its buffer and commits with one write(2), in order -- holds up to kBlockRows rows and may span several
+// short segments, so a run of small contigs costs what one contig of their total size costs (the CLI used to make one call per
+// contig: 626 scaffold passes of 3 500 rows each, formatted by ONE thread and joined, took a fifth of the CSV stage).
+extern "C" int crp_write_segments(int fd, int guide_len, const crp_row_segment *segs, uint64_t n_segs, uint64_t *bytes_written, int n_threads)
 {
     crp::Range roctx_range("crp: format + write rows");
-    if (fd < 0 || bad_args(contig_text, chrom, chrom_len, guide_len, pos, minus, score, ids, n_rows))
-        return CRP_ERR_INVALID;
-    if (feat_idx && (!feat_off || !feat_blob)) return CRP_ERR_INVALID;
+    if (fd < 0 || (n_segs && !segs)) return CRP_ERR_INVALID;
     if (bytes_written) *bytes_written = 0;
-    if (n_rows == 0) return CRP_OK;
+    for (uint64_t k = 0; k < n_segs; ++k) {
+        const crp_row_segment &g = segs[k];
+        if (bad_args(g.contig_text, g.chrom, g.chrom_len, guide_len, g.pos, g.minus, g.score, g.ids, g.n_rows)) return CRP_ERR_INVALID;
+        if (g.feat_idx && (!g.feat_off || !g.feat_blob)) return CRP_ERR_INVALID;
+    }
     try {
-        Job job(contig_text, contig_len, chrom, chrom_len, guide_len, pos, minus, score, ids);
-        job.feat_blob = feat_blob;
-        job.feat_off = feat_off;
-        job.feat_idx = feat_idx;
-        job.offtarget = offtarget;
-        if (offtarget) job.row_bound += 4 * 11;
-        if (feat_idx) {  // the longest features entry a row can carry, quoted
-            uint64_t longest = 0;
-            for (uint64_t r = 0; r < n_rows; ++r)
-                if (feat_idx[r] != 0xffffffffu) longest = std::max(longest, feat_off[feat_idx[r] + 1] - feat_off[feat_idx[r]]);
-            job.row_bound += 2 * (size_t)longest + 2;
-        }
+        std::vector<Job> jobs;
+        jobs.reserve((size_t)n_segs);
+        struct Part {
+            uint32_t seg;
+            uint64_t r0, r1;
+        };
+        std::vector<Part> parts;
+        std::vector<size_t> block_at{0};  // block b = parts [block_at[b], block_at[b + 1])
         constexpr uint64_t kBlockRows = 16384;
-        const uint64_t n_blocks = (n_rows + kBlockRows - 1) / kBlockRows;
+        size_t block_bytes = 0, cur_bytes = 0;
+        uint64_t cur_rows = 0;
+        auto close_block = [&]() {
+            if (parts.size() == block_at.back()) return;
+            block_at.push_back(parts.size());
+            block_bytes = std::max(block_bytes, cur_bytes);
+            cur_rows = 0;
+            cur_bytes = 0;
+        };
+        for (uint64_t k = 0; k < n_segs; ++k) {
+            const crp_row_segment &g = segs[k];
+            jobs.emplace_back(g.contig_text, g.contig_len, g.chrom, g.chrom_len, guide_len, g.pos, g.minus, g.score, g.ids);
+            Job &job = jobs.back();
+            job.feat_blob = g.feat_blob;
+            job.feat_off = g.feat_off;
+            job.feat_idx = g.feat_idx;
+            job.offtarget = g.offtarget;
+            if (g.offtarget) job.row_bound += 4 * 11;
+            if (g.feat_idx) {  // the longest features entry a row can carry, quoted
+                uint64_t longest = 0;
+                for (uint64_t r = 0; r < g.n_rows; ++r)
+                    if (g.feat_idx[r] != 0xffffffffu) longest = std::max(longest, g.feat_off[g.feat_idx[r] + 1] - g.feat_off[g.feat_idx[r]]);
+                job.row_bound += 2 * (size_t)longest + 2;
+            }
+            for (uint64_t r0 = 0; r0 < g.n_rows;) {
+                const uint64_t take = std::min(g.n_rows - r0, kBlockRows - cur_rows);
+                parts.push_back(Part{(uint32_t)k, r0, r0 + take});
+                cur_rows += take;
+                cur_bytes += (size_t)take * job.row_bound;
+                r0 += take;
+                if (cur_rows == kBlockRows) close_block();
+            }
+        }
+        close_block();
+        const uint64_t n_blocks = block_at.size() - 1;
+        if (!n_blocks) return CRP_OK;
         const int nt = (int)std::min<uint64_t>((uint64_t)(n_threads < 1 ? 1 : n_threads), n_blocks);
         std::atomic<uint64_t> next_block{0};
         std::mutex mu;
@@ -359,12 +392,16 @@ extern "C" int crp_write_rows_ex(int fd, const uint8_t *contig_text, uint64_t co
         uint64_t total = 0;
         int status = CRP_OK;
         run_threads(nt, [&](int) {
-            char *buf = static_cast<char *>(std::malloc((size_t)kBlockRows * job.row_bound));
+            char *buf = static_cast<char *>(std::malloc(block_bytes));
             for (;;) {
                 const uint64_t b = next_block.fetch_add(1);
                 if (b >= n_blocks) break;
-                const uint64_t r0 = b * kBlockRows, r1 = std::min(n_rows, r0 + kBlockRows);
-                const size_t n = buf ? (size_t)(format_range(job, r0, r1, buf) - buf) : 0;
+                size_t n = 0;
+                if (buf) {
+                    char *o = buf;
+                    for (size_t q = block_at[b]; q < block_at[b + 1]; ++q) o = format_range(jobs[parts[q].seg], parts[q].r0, parts[q].r1, o);
+                    n = (size_t)(o - buf);
+                }
                 std::unique_lock<std::mutex> lock(mu);
                 turn.wait(lock, [&] { return committed == b; });
                 if (!buf && status == CRP_OK) status = CRP_ERR_NOMEM;
@@ -392,6 +429,16 @@ extern "C" int crp_write_rows_ex(int fd, const uint8_t *contig_text, uint64_t co
     } catch (...) {
         return CRP_ERR_NOMEM;
     }
+}
+
+extern "C" int crp_write_rows_ex(int fd, const uint8_t *contig_text, uint64_t contig_len, const uint8_t *chrom,
+                                 uint64_t chrom_len, int guide_len, const uint32_t *pos, const uint8_t *minus,
+                                 const double *score, const uint8_t *ids, uint64_t n_rows, const uint8_t *feat_blob,
+                                 const uint64_t *feat_off, const uint32_t *feat_idx, const uint32_t *offtarget,
+                                 uint64_t *bytes_written, int n_threads)
+{
+    const crp_row_segment seg{contig_text, contig_len, chrom, chrom_len, pos, minus, score, ids, n_rows, feat_blob, feat_off, feat_idx, offtarget};
+    return crp_write_segments(fd, guide_len, &seg, 1, bytes_written, n_threads);
 }
 
 extern "C" int crp_write_rows(int fd, const uint8_t *contig_text, uint64_t contig_len, const uint8_t *chrom,

@@ -378,7 +378,8 @@ int load_device(crp_node *node, int k, const uint8_t *const *texts)
             CRP_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&sl.h_bounds), 4 * np * sizeof(uint32_t), hipHostMallocDefault));
             sl.h_bounds_cap = 4 * np;
         }
-        CRP_HIP(ctx, hipMemcpyAsync(sl.d_needles, needles.data(), 2 * np * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+        rc = crp::staged_h2d(ctx, sl.d_needles, needles.data(), 2 * np * sizeof(uint32_t));  // (never the runtime's path for pageable memory: crp_api.cpp)
+        if (rc != CRP_OK) return rc;
         // its own piece map (begin[], then sub[]): what turns an arena position of an owned row into the position inside its contig
         std::vector<uint32_t> map(2 * np);
         for (size_t q = 0; q < np; ++q) {
@@ -388,7 +389,8 @@ int load_device(crp_node *node, int k, const uint8_t *const *texts)
         }
         rc = crp::grow(ctx, reinterpret_cast<void **>(&sl.d_map_self), &sl.map_self_cap, 2 * np, sizeof(uint32_t));
         if (rc != CRP_OK) return rc;
-        CRP_HIP(ctx, hipMemcpyAsync(sl.d_map_self, map.data(), 2 * np * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+        rc = crp::staged_h2d(ctx, sl.d_map_self, map.data(), 2 * np * sizeof(uint32_t));
+        if (rc != CRP_OK) return rc;
         CRP_HIP(ctx, hipStreamSynchronize(ctx->stream));  // (`needles` and `map` leave scope)
         sl.n_buckets = crp::pos16_buckets_for(sl.arena->padded_words);
     }

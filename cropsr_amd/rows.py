@@ -238,6 +238,7 @@ class ContigTable:
             self.ot = np.ascontiguousarray(np.concatenate([hits["ot_plus"].reshape(-1, 4), hits["ot_minus"].reshape(-1, 4)]),
                                            dtype=np.uint32)
         self.chrom = name_token[1:].encode("utf-8")
+        self.chrom_u8 = np.frombuffer(self.chrom, dtype=np.uint8)  # (the pointer crp_write_segments reads the name through)
         self.text = np.frombuffer(s.encode("ascii", "replace") if isinstance(s, str) else s, dtype=np.uint8)
         self.n_plus = int(hits["pos_plus"].size)
         self.pos = np.ascontiguousarray(np.concatenate([hits["pos_plus"], hits["pos_minus"]]), dtype=np.uint32)
@@ -353,33 +354,48 @@ class NativeDataset:
             out.append(buf[:used.value].tobytes())
         return b"".join(out)
 
-    def chunk_to_fd(self, fd, lo, count, ids_u8, index_range, rescore, ids_rev=None):
-        """The same chunk appended to file descriptor fd (crp_write_rows); returns the byte count."""
+    def chunk_segments(self, segs, keep, lo, count, ids_u8, index_range, rescore, ids_rev=None):
+        """The same chunk as crp_row_segment entries appended to `segs` (for write_segments); every array a segment points
+        into is appended to `keep` and must outlive the call that writes them."""
         from . import _native as nat
-        L = nat.lib()
-        total = 0
         for blk, pos, minus, score, ids_part, (feat_idx, ot) in self._segments(lo, count, ids_u8, index_range, rescore, ids_rev):
-            written = ctypes.c_uint64()
+            g = nat.RowSegment()
+            score = np.ascontiguousarray(score)
+            keep.extend((blk, pos, minus, score, ids_part))
+            g.contig_text, g.contig_len = blk.text.ctypes.data, blk.text.size
+            g.chrom, g.chrom_len = (blk.chrom_u8.ctypes.data if len(blk.chrom) else None), len(blk.chrom)
+            g.pos, g.minus, g.score, g.ids, g.n_rows = pos.ctypes.data, minus.ctypes.data, score.ctypes.data, ids_part.ctypes.data, pos.size
             if feat_idx is not None:
                 feat_idx = np.ascontiguousarray(feat_idx)
+                keep.append(feat_idx)
+                g.feat_blob, g.feat_off, g.feat_idx = blk.feat_blob.ctypes.data, blk.feat_off.ctypes.data, feat_idx.ctypes.data
             if ot is not None:
                 ot = np.ascontiguousarray(ot)
-            st = L.crp_write_rows_ex(
-                fd, blk.text.ctypes.data_as(nat.u8p), blk.text.size,
-                ctypes.cast(ctypes.c_char_p(blk.chrom), nat.u8p), len(blk.chrom), blk.guide_len,
-                pos.ctypes.data_as(nat.u32p), minus.ctypes.data_as(nat.u8p),
-                score.ctypes.data_as(nat.f64p), ids_part.ctypes.data_as(nat.u8p), pos.size,
-                None if feat_idx is None else blk.feat_blob.ctypes.data_as(nat.u8p),
-                None if feat_idx is None else blk.feat_off.ctypes.data_as(nat.u64p),
-                None if feat_idx is None else feat_idx.ctypes.data_as(nat.u32p),
-                None if ot is None else ot.ctypes.data_as(nat.u32p),
-                ctypes.byref(written), self.n_threads)
-            total += written.value
-            if st == nat.CRP_ERR_IO:
-                err = ctypes.get_errno()
-                raise OSError(err, "crp_write_rows: " + os.strerror(err))
-            nat.check(st, "crp_write_rows")
-        return total
+                keep.append(ot)
+                g.offtarget = ot.ctypes.data
+            segs.append(g)
+
+    def chunk_to_fd(self, fd, lo, count, ids_u8, index_range, rescore, ids_rev=None):
+        """The same chunk appended to file descriptor fd (crp_write_segments); returns the byte count."""
+        segs, keep = [], []
+        self.chunk_segments(segs, keep, lo, count, ids_u8, index_range, rescore, ids_rev)
+        return write_segments(fd, segs, self.blocks[0].guide_len if self.blocks else 20, self.n_threads)
+
+
+def write_segments(fd, segs, guide_len, n_threads):
+    """crp_write_segments: the rows of all `segs` (RowSegment entries, in order) appended to fd by one team of formatter
+    threads; returns the byte count.  The caller keeps the arrays the segments point into alive."""
+    from . import _native as nat
+    if not segs:
+        return 0
+    arr = (nat.RowSegment * len(segs))(*segs)
+    written = ctypes.c_uint64()
+    st = nat.lib().crp_write_segments(fd, guide_len, ctypes.cast(arr, ctypes.c_void_p), len(segs), ctypes.byref(written), n_threads)
+    if st == nat.CRP_ERR_IO:
+        err = ctypes.get_errno()
+        raise OSError(err, "crp_write_segments: " + os.strerror(err))
+    nat.check(st, "crp_write_segments")
+    return written.value
 
 
 def ids_as_bytes(ids_u1):
@@ -428,30 +444,46 @@ class IdStream:
     """The ids of consecutive write passes, drawn ahead of their use on a worker thread.
 
     The passes of one run draw from one RNG stream in a fixed order and their sizes are known
-    once the scan is done, so pass k+1's ids are drawn while pass k is formatted and written.
-    Nothing else may touch np.random while the stream is open."""
+    once the scan is done, so the ids of the next passes are drawn while a pass is formatted and written: at least
+    `depth` passes ahead, and as many more as fit `rows_ahead` rows (a run of short contigs is drawn while the long one
+    in front of it is written).  Nothing else may touch np.random while the stream is open."""
 
-    def __init__(self, sizes, depth=2, reverse=False):
-        import queue
+    def __init__(self, sizes, depth=2, reverse=False, rows_ahead=8_000_000):
+        import collections
         import threading
         self._sizes = list(sizes)
-        self._q = queue.Queue(maxsize=depth)
+        self._q = collections.deque()
+        self._rows = 0
+        self._cv = threading.Condition()
         self._stop = False
 
         def work():
             try:
                 for size in self._sizes:
-                    if self._stop:
-                        return
-                    self._q.put((size, draw_ids(size, reverse=reverse)))
+                    with self._cv:
+                        self._cv.wait_for(lambda: self._stop or len(self._q) < depth or self._rows + size <= rows_ahead)
+                        if self._stop:
+                            return
+                    item = (size, draw_ids(size, reverse=reverse))
+                    with self._cv:
+                        self._q.append(item)
+                        self._rows += size
+                        self._cv.notify_all()
             except BaseException as e:  # handed to the consumer
-                self._q.put((None, e))
+                with self._cv:
+                    self._q.append((None, e))
+                    self._cv.notify_all()
 
         self._thread = threading.Thread(target=work, daemon=True)
         self._thread.start()
 
     def next(self, size):
-        got, ids = self._q.get()
+        with self._cv:
+            self._cv.wait_for(lambda: len(self._q) > 0)
+            got, ids = self._q.popleft()
+            if got is not None:
+                self._rows -= got
+            self._cv.notify_all()
         if got is None:
             raise ids
         if got != size:
@@ -459,21 +491,31 @@ class IdStream:
         return ids
 
     def close(self):
-        self._stop = True
-        while self._thread.is_alive():
-            try:
-                self._q.get(timeout=0.05)
-            except Exception:
-                pass
+        with self._cv:
+            self._stop = True
+            self._cv.notify_all()
+        self._thread.join()
 
 
 def write_pass_native(path, dataset, rescore, ids=None):
-    """write_pass with the native formatter: same RNG draws, same chunk walk, same bytes.
-    `ids` (an IdStream built with reverse=True) supplies ids drawn ahead; by default they are
-    drawn here."""
+    """write_pass with the native formatter: same RNG draws, same chunk walk, same bytes -- every chunk of the pass in ONE call
+    of the formatter.  `ids` (an IdStream built with reverse=True) supplies ids drawn ahead; by default they are drawn here."""
     size = len(dataset)
     ids_rev = draw_ids(size, reverse=True) if ids is None else ids.next(size)
-    with open(path, "ab") as f:
-        fd = f.fileno()
+    return write_passes_native(path, [(dataset, ids_rev)], rescore)
+
+
+def write_passes_native(path, passes, rescore):
+    """Several write passes -- (dataset, ids_rev) each: the rows of the pass and its ids last-first (draw_ids(reverse=True)) --
+    appended to `path` by ONE call of the native formatter: the bytes of write_pass_native pass after pass.  What the CLI does
+    with a run of short contigs under --each-contig-once (a pass of 3 500 rows alone is formatted by one thread)."""
+    segs, keep = [], []
+    guide_len, n_threads = 20, 1
+    for dataset, ids_rev in passes:
+        size = len(dataset)
+        if dataset.blocks:
+            guide_len, n_threads = dataset.blocks[0].guide_len, dataset.n_threads
         for index_range, count in flush_plan(size):
-            dataset.chunk_to_fd(fd, index_range, count, None, index_range, rescore, ids_rev=ids_rev)
+            dataset.chunk_segments(segs, keep, index_range, count, None, index_range, rescore, ids_rev=ids_rev)
+    with open(path, "ab") as f:
+        return write_segments(f.fileno(), segs, guide_len, n_threads)

@@ -243,6 +243,29 @@ int crp_write_rows_ex(int fd, const uint8_t *contig_text, uint64_t contig_len, c
                       const uint8_t *ids, uint64_t n_rows, const uint8_t *feat_blob, const uint64_t *feat_off,
                       const uint32_t *feat_idx, const uint32_t *offtarget, uint64_t *bytes_written, int n_threads);
 
+/* Rows of several SEGMENTS -- a segment is what crp_write_rows_ex takes: consecutive rows of one contig with their columns --
+ * appended to fd in segment order by ONE call: the rows a write pass of the reference sends through csv.writer.writerows
+ * (CROPSR.py:442-474; with the reference's accumulating Complete_dataset, :407, a pass holds the rows of every contig so far),
+ * or the passes of several short contigs together.  A worker's block (16384 rows, one write(2)) may span segments, so a run of
+ * short contigs costs what one contig of their total size costs.  Bytes: exactly the concatenation of the segments'
+ * crp_write_rows_ex output.  feat_idx / offtarget may be NULL per segment like there; guide_len is the call's. */
+typedef struct crp_row_segment {
+    const uint8_t *contig_text;
+    uint64_t contig_len;
+    const uint8_t *chrom;
+    uint64_t chrom_len;
+    const uint32_t *pos;
+    const uint8_t *minus;
+    const double *score;
+    const uint8_t *ids;
+    uint64_t n_rows;
+    const uint8_t *feat_blob;
+    const uint64_t *feat_off;
+    const uint32_t *feat_idx;
+    const uint32_t *offtarget;
+} crp_row_segment;
+int crp_write_segments(int fd, int guide_len, const crp_row_segment *segs, uint64_t n_segs, uint64_t *bytes_written, int n_threads);
+
 /* ---- multi-GPU: one process per GPU, RCCL over xGMI ------------------------ */
 /* The reference has no parallelism (its only hint is the dead cropsr_functions.py:256-273).  The path
  * shards by contig with no collective on the data path; the one exchange is the final gatherv of the

@@ -103,6 +103,59 @@ int main(int argc, char **argv)
         std::fclose(f);
         if (st != CRP_OK || written_plain != used) { std::printf("write_rows_ex (plain) status %d\n", st); ++failures; }
     }
+    {  // crp_write_segments: many segments in one call (short ones sharing a block, empty ones, one spanning several
+       // blocks) == the segments' crp_format_rows bytes one after the other, with 1, 3 and 7 workers
+        struct Seg {
+            std::vector<uint8_t> text, minus, ids;
+            std::vector<uint32_t> pos;
+            std::vector<double> score;
+            std::string chrom;
+        };
+        std::vector<Seg> segs(40);
+        std::vector<crp_row_segment> view(segs.size());
+        std::vector<uint8_t> want;
+        for (size_t k = 0; k < segs.size(); ++k) {
+            Seg &g = segs[k];
+            const uint64_t len = 40 + rng() % 3000;
+            const uint64_t n = k % 9 == 4 ? 0 : (k == 17 ? 50000 : 1 + rng() % 6000);
+            g.text.resize(len);
+            for (auto &c : g.text) c = (uint8_t)alphabet[rng() % (sizeof alphabet - 1)];
+            g.pos.resize(n);
+            g.minus.resize(n);
+            g.ids.resize(7 * n);
+            g.score.resize(n);
+            for (uint64_t r = 0; r < n; ++r) {
+                g.pos[r] = (uint32_t)(rng() % (len + 8));
+                g.minus[r] = (uint8_t)(rng() & 1);
+                g.score[r] = (double)(rng() % 1000003) / 1000003.0;
+                for (int c = 0; c < 7; ++c) g.ids[7 * r + c] = (uint8_t)('A' + rng() % 26);
+            }
+            g.chrom = k % 3 ? "scaffold_" + std::to_string(k) : std::string("s,\"") + std::to_string(k);
+            std::vector<uint8_t> out(n * 512 + 64);
+            uint64_t used = 0;
+            if (crp_format_rows(g.text.data(), len, (const uint8_t *)g.chrom.data(), g.chrom.size(), 20, g.pos.data(), g.minus.data(),
+                                g.score.data(), g.ids.data(), n, out.data(), out.size(), &used, 2) != CRP_OK)
+                ++failures;
+            want.insert(want.end(), out.begin(), out.begin() + (long)used);
+            view[k] = crp_row_segment{g.text.data(), len, (const uint8_t *)g.chrom.data(), g.chrom.size(), g.pos.data(), g.minus.data(),
+                                      g.score.data(), g.ids.data(), n, nullptr, nullptr, nullptr, nullptr};
+        }
+        for (int threads : {1, 3, 7}) {
+            std::FILE *f = std::fopen(path, "wb");
+            if (!f) return 2;
+            uint64_t written = 0;
+            const int st = crp_write_segments(fileno(f), 20, view.data(), view.size(), &written, threads);
+            std::fclose(f);
+            std::vector<uint8_t> back(written);
+            f = std::fopen(path, "rb");
+            const size_t got = written ? std::fread(back.data(), 1, written, f) : 0;
+            std::fclose(f);
+            if (st != CRP_OK || written != want.size() || got != written || back != want) { std::printf("write_segments (%d threads) differs\n", threads); ++failures; }
+        }
+        uint64_t none = 7;
+        if (crp_write_segments(1, 20, nullptr, 0, &none, 4) != CRP_OK || none != 0) ++failures;
+        if (crp_write_segments(-1, 20, view.data(), view.size(), nullptr, 4) != CRP_ERR_INVALID) ++failures;
+    }
     {  // crp_legacy_ids: forward and last-first draws from the same MT19937 state agree row for row
         std::vector<uint32_t> key(624), key2;
         for (auto &k : key) k = (uint32_t)rng();

@@ -238,3 +238,122 @@ def test_native_legacy_id_draws_equal_numpy():
             assert (got == (want[::-1] if reverse else want)).all(), (seed, reverse)
             assert now[0] == after[0] and (now[1] == after[1]).all() and now[2:] == after[2:]
         assert np.random.randint(0, 1 << 30) == (np.random.set_state(after), np.random.randint(0, 1 << 30))[1]
+
+
+def test_write_segments_equals_the_segments_one_after_the_other(oracle, tmp_path):
+    """crp_write_segments: several segments in one call -- short ones that share a 16384-row block, an empty one, one that
+    spans several blocks, one with the four off-target columns and one with a features column -- == the bytes of one
+    crp_write_rows_ex call per segment, whatever the thread count."""
+    import ctypes
+    from cropsr_amd import _native as nat
+    rng = np.random.default_rng(5)
+    tables = [_table_for(oracle, n, seed=100 + k) for k, n in enumerate([900, 0, 40, 230000, 7, 30000, 5000, 2500])]
+    blob = np.frombuffer(b"geneA,\"x\" CDS", dtype=np.uint8)
+    off = np.array([0, 5, 9, 13], dtype=np.uint64)
+    extras = []
+    for k, (t, _) in enumerate(tables):
+        feat = rng.integers(0, 4, t.n).astype(np.uint32) if k == 5 else None
+        if feat is not None:
+            feat[feat == 3] = 0xFFFFFFFF
+        ot = rng.integers(0, 50, (t.n, 4)).astype(np.uint32) if k == 6 else None
+        extras.append((feat, ot))
+
+    def one_by_one(path):
+        with open(path, "ab") as f:
+            for (t, ids_u8), (feat, ot) in zip(tables, extras):
+                written = ctypes.c_uint64()
+                st = nat.lib().crp_write_rows_ex(
+                    f.fileno(), t.text.ctypes.data_as(nat.u8p), t.text.size, ctypes.cast(ctypes.c_char_p(t.chrom), nat.u8p), len(t.chrom), 20,
+                    t.pos.ctypes.data_as(nat.u32p), t.minus.ctypes.data_as(nat.u8p), t.score.ctypes.data_as(nat.f64p),
+                    ids_u8.ctypes.data_as(nat.u8p), t.n, None if feat is None else blob.ctypes.data_as(nat.u8p),
+                    None if feat is None else off.ctypes.data_as(nat.u64p), None if feat is None else feat.ctypes.data_as(nat.u32p),
+                    None if ot is None else ot.ctypes.data_as(nat.u32p), ctypes.byref(written), 3)
+                assert st == 0
+
+    def together(path, threads):
+        segs = []
+        for (t, ids_u8), (feat, ot) in zip(tables, extras):
+            g = nat.RowSegment()
+            g.contig_text, g.contig_len, g.chrom, g.chrom_len = t.text.ctypes.data, t.text.size, t.chrom_u8.ctypes.data, len(t.chrom)
+            g.pos, g.minus, g.score, g.ids, g.n_rows = t.pos.ctypes.data, t.minus.ctypes.data, t.score.ctypes.data, ids_u8.ctypes.data, t.n
+            if feat is not None:
+                g.feat_blob, g.feat_off, g.feat_idx = blob.ctypes.data, off.ctypes.data, feat.ctypes.data
+            if ot is not None:
+                g.offtarget = ot.ctypes.data
+            segs.append(g)
+        with open(path, "ab") as f:
+            return rows.write_segments(f.fileno(), segs, 20, threads)
+
+    a = tmp_path / "a.csv"
+    a.write_bytes(b"h\r\n")
+    one_by_one(a)
+    want = a.read_bytes()
+    assert want.count(b"\r\n") >= sum(t.n for t, _ in tables)
+    for threads in (1, 4, 9):
+        b = tmp_path / ("b%d.csv" % threads)
+        b.write_bytes(b"h\r\n")
+        assert together(b, threads) == len(want) - 3
+        assert b.read_bytes() == want
+    with open(a, "rb") as f, pytest.raises(OSError):  # not open for writing
+        together_fd = f.fileno()
+        g = nat.RowSegment()
+        t, ids_u8 = tables[0]
+        g.contig_text, g.contig_len, g.chrom, g.chrom_len = t.text.ctypes.data, t.text.size, t.chrom_u8.ctypes.data, len(t.chrom)
+        g.pos, g.minus, g.score, g.ids, g.n_rows = t.pos.ctypes.data, t.minus.ctypes.data, t.score.ctypes.data, ids_u8.ctypes.data, t.n
+        rows.write_segments(together_fd, [g], 20, 2)
+    assert rows.write_segments(-1, [], 20, 2) == 0  # nothing to write: no call
+
+
+def test_passes_written_together_equal_passes_written_one_by_one(oracle, tmp_path):
+    """rows.write_passes_native (what the CLI does with a run of short contigs under --each-contig-once) == one
+    write_pass_native per pass: same ids from the same RNG stream, same chunk walk, same re-scored tail rows, same bytes."""
+    tables = [_table_for(oracle, n, seed=300 + k)[0] for k, n in enumerate([1200, 50, 0, 64000, 333, 9000])]
+    calls = []
+
+    def rescore(seqs, order):  # (stands in for seam 2: a value that depends on the rows and the order asked for)
+        calls.append((len(seqs), order))
+        return seqs[:, :4].sum(axis=1) / 1000.0 + order
+
+    def datasets():
+        out = []
+        for t in tables:
+            ds = rows.NativeDataset(n_threads=3)
+            ds.append(t)
+            out.append(ds)
+        return out
+
+    a, b = tmp_path / "a.csv", tmp_path / "b.csv"
+    np.random.seed(99)
+    for ds in datasets():
+        rows.write_pass_native(str(a), ds, rescore)
+    after_a, calls_a = np.random.random(), list(calls)
+    del calls[:]
+    np.random.seed(99)
+    sizes = [t.n for t in tables]
+    ids = rows.IdStream(sizes, reverse=True)
+    batch = [(ds, ids.next(len(ds))) for ds in datasets()]
+    rows.write_passes_native(str(b), batch, rescore)
+    ids.close()
+    assert np.random.random() == after_a and calls == calls_a and len(calls) >= 3
+    assert a.read_bytes() == b.read_bytes() and a.read_bytes().count(b"\r\n") >= sum(sizes)
+
+
+@pytest.mark.parametrize("name", ["multi", "mixed"])
+def test_each_contig_once_batched_passes_equal_single_passes(name, oracle, manifest, tmp_path, monkeypatch):
+    """--each-contig-once: the CLI hands consecutive passes to the formatter together (cli.BATCH_ROWS); the CSV, the
+    stdout text and the number of lines in time.txt are those of one formatter call per pass (CROPSR_BATCH_PASSES=0) --
+    with the default limit (everything in one batch here) and with a limit of 20 rows (several batches, the last one partial)."""
+    from conftest import golden_fasta_path, oracle_scan_provider, run_cli
+    fasta = golden_fasta_path(name, tmp_path)
+    got = {}
+    for label, env in (("single", {"CROPSR_BATCH_PASSES": "0"}), ("batched", {}), ("small batches", {"CROPSR_BATCH_ROWS": "20"})):
+        for k in ("CROPSR_BATCH_PASSES", "CROPSR_BATCH_ROWS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        d = tmp_path / label.replace(" ", "_")
+        d.mkdir()
+        csv_bytes, text = run_cli(d, monkeypatch, fasta, oracle_scan_provider(oracle), manifest["seed"], extra=("--each-contig-once",))
+        got[label] = (csv_bytes, text, (d / "time.txt").read_text().count("Total runtime"))
+    assert got["single"][0].count(b"\r\n") > 20
+    assert got["batched"] == got["single"] and got["small batches"] == got["single"]
