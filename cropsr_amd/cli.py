@@ -246,6 +246,9 @@ class EngineBackend:
         import os
         if self.group is None and os.environ.get("CROPSR_STREAM", "1") != "0":
             self.engine.stream_prepare()
+            # and one scan of a few hundred characters through them: a process's first launch of the scan kernels loads their
+            # code object (17-25 ms, otherwise paid by the genome's first slice)
+            self.engine.scan_stream([np.frombuffer(b"ACGTTGCAAGGCCTTA" * 40, dtype=np.uint8)], 20)
 
     def scan(self, contig_strings, guide_len, offtarget=False, annotation=None):
         """One pass on the GPU for all contig strings (seam 1 + 2).  The plain scan goes through crp_scan_stream -- upload,
