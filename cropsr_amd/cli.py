@@ -664,52 +664,79 @@ def run(args, backend=None, out=sys.stdout, group=None):
     batching = native and once and not getattr(args, "reference_sleep", False) and os.environ.get("CROPSR_BATCH_PASSES", "1") != "0"
     batch_limit = int(os.environ.get("CROPSR_BATCH_ROWS", BATCH_ROWS))
     batch, batch_rows = [], 0
+    in_flight = []  # at most one: (thread, the passes it writes, [its exception]) -- a batch is formatted and written on a
+                    # helper thread while this one builds the next batch's tables and collects its ids
+
+    def finish_write(swallow=False):
+        nonlocal n_rows_written
+        while in_flight:
+            th, passes, err = in_flight.pop()
+            th.join()
+            if err and not swallow:
+                raise err[0]
+            for ds, _ in passes:
+                n_rows_written += len(ds)
+                timing.write("Total runtime of the program is " + str(time.time() - begin))  # CROPSR.py:477, once per pass
 
     def flush_batch():
-        nonlocal batch, batch_rows, n_rows_written
+        nonlocal batch, batch_rows
         if not batch:
             return
-        rows.write_passes_native(args.o, batch, backend.rescore)
-        for ds, _ in batch:
-            n_rows_written += len(ds)
-            timing.write("Total runtime of the program is " + str(time.time() - begin))  # CROPSR.py:477, once per pass
+        finish_write()  # (the file takes one writer at a time, in order)
+        import threading
+        passes, err = batch, []
+
+        def work():
+            try:
+                rows.write_passes_native(args.o, passes, backend.rescore)
+            except BaseException as e:
+                err.append(e)
+
+        th = threading.Thread(target=work, name="cropsr-csv")
+        in_flight.append((th, passes, err))
+        th.start()
         batch, batch_rows = [], 0
 
-    for name, s, hits in zip(names, strings, all_hits):
-        print("Searching on Chromosome: ", name[:25], file=out)  # CROPSR.py:410-411
-        print("With start of sequence: ", bytes(s[:25]).decode("latin-1"), file=out)
-        feats = None
-        if request is not None:  # the device's label-set id per row ('+' rows, then '-' rows) + the string table
-            feats = (request.annotation.strings, np.concatenate([hits["feat_plus"], hits["feat_minus"]]))
-        block = (rows.ContigTable(name, s, hits, args.l, features=feats) if native
-                 else rows.ContigRows(name, bytes(s).decode("latin-1"), hits, args.l, features=feats))
-        if once:
-            dataset = rows.NativeDataset() if native else rows.Dataset()  # opt-in fix of CROPSR.py:407
-        dataset.append(block)
-        if verbose:
-            # CROPSR.py:436-439 counts regex matches BEFORE the keep-filter; the
-            # engine reports kept hits, so re-count only for this message.
-            import re
-            n_sites = sum(1 for _ in re.finditer(rb"(?=.GG)", s)) + sum(1 for _ in re.finditer(rb"(?=CC.)", s))
-            print(f"""
+    try:
+        for name, s, hits in zip(names, strings, all_hits):
+            print("Searching on Chromosome: ", name[:25], file=out)  # CROPSR.py:410-411
+            print("With start of sequence: ", bytes(s[:25]).decode("latin-1"), file=out)
+            feats = None
+            if request is not None:  # the device's label-set id per row ('+' rows, then '-' rows) + the string table
+                feats = (request.annotation.strings, np.concatenate([hits["feat_plus"], hits["feat_minus"]]))
+            block = (rows.ContigTable(name, s, hits, args.l, features=feats) if native
+                     else rows.ContigRows(name, bytes(s).decode("latin-1"), hits, args.l, features=feats))
+            if once:
+                dataset = rows.NativeDataset() if native else rows.Dataset()  # opt-in fix of CROPSR.py:407
+            dataset.append(block)
+            if verbose:
+                # CROPSR.py:436-439 counts regex matches BEFORE the keep-filter; the
+                # engine reports kept hits, so re-count only for this message.
+                import re
+                n_sites = sum(1 for _ in re.finditer(rb"(?=.GG)", s)) + sum(1 for _ in re.finditer(rb"(?=CC.)", s))
+                print(f"""
                 {n_sites:n} Cas9 PAM sites were found on {name[1::]}
                 """, file=out)
-        if batching:
-            batch.append((dataset, ids.next(len(dataset))))
-            batch_rows += len(dataset)
-            if batch_rows >= batch_limit:
-                flush_batch()
-            continue
-        if native:  # CROPSR.py:442-474
-            rows.write_pass_native(args.o, dataset, backend.rescore, ids)
-        else:
-            rows.write_pass(args.o, dataset, backend.rescore)
-        n_rows_written += len(dataset)
-        end = time.time()
-        timing.write("Total runtime of the program is " + str(end - begin))  # CROPSR.py:477
-        if getattr(args, "reference_sleep", False):
-            time.sleep(5)  # CROPSR.py:478
-    flush_batch()
+            if batching:
+                batch.append((dataset, ids.next(len(dataset))))
+                batch_rows += len(dataset)
+                if batch_rows >= batch_limit:
+                    flush_batch()
+                continue
+            if native:  # CROPSR.py:442-474
+                rows.write_pass_native(args.o, dataset, backend.rescore, ids)
+            else:
+                rows.write_pass(args.o, dataset, backend.rescore)
+            n_rows_written += len(dataset)
+            end = time.time()
+            timing.write("Total runtime of the program is " + str(end - begin))  # CROPSR.py:477
+            if getattr(args, "reference_sleep", False):
+                time.sleep(5)  # CROPSR.py:478
+        flush_batch()
+        finish_write()
+    except BaseException:
+        finish_write(swallow=True)  # (no writer thread outlives a failing run)
+        raise
     stages["format_write_s"] = time.perf_counter() - t_stage
     timing.close()
     if ids is not None:

@@ -31,6 +31,9 @@
 #include <vector>
 
 #include <unistd.h>
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+#include <immintrin.h>
+#endif
 
 namespace {
 
@@ -458,60 +461,188 @@ extern "C" int crp_write_rows(int fd, const uint8_t *contig_text, uint64_t conti
 // MT19937 state it took from np.random.get_state() and puts the advanced state back, so the
 // global stream continues exactly as if numpy had made the draws.  reverse != 0 stores row r at
 // row n_rows - 1 - r (the order the reference consumes ids in, CROPSR.py:448-449).
+//
+// Round 6: with the formatter taking whole passes (crp_write_segments) this sequential stream became what the CSV stage waits
+// for (0.745 s for 52.4 M rows against 0.744 s of formatting and writing), so the three steps -- state transition, tempering +
+// rejection, placing the characters -- also exist as AVX-512 code (VBMI2 byte compress; picked at run time, CRP_IDS_SCALAR=1
+// forces the portable loop): 64 outputs per step, same outputs consumed, same state left behind.
+namespace {
+
+constexpr int kMtN = 624, kMtM = 397;
+alignas(64) const char kIdAlphabet[65] = "ABCDEFGHIJKLMNOPQRSTUVWXYZ0123456789????????????????????????????";
+
+void mt_refill_scalar(uint32_t *mt)  // the standard MT19937 state transition
+{
+    int k = 0;
+    for (; k < kMtN - kMtM; ++k) {
+        const uint32_t y = (mt[k] & 0x80000000u) | (mt[k + 1] & 0x7fffffffu);
+        mt[k] = mt[k + kMtM] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    }
+    for (; k < kMtN - 1; ++k) {
+        const uint32_t y = (mt[k] & 0x80000000u) | (mt[k + 1] & 0x7fffffffu);
+        mt[k] = mt[k + (kMtM - kMtN)] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    }
+    const uint32_t y = (mt[kMtN - 1] & 0x80000000u) | (mt[0] & 0x7fffffffu);
+    mt[kMtN - 1] = mt[kMtM - 1] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+}
+
+// `take` outputs from src: tempered, low six bits, kept when <= 35; the kept ones as characters to out (room for `take`)
+int mt_chars_scalar(const uint32_t *src, int take, uint8_t *out)
+{
+    int n = 0;
+    for (int i = 0; i < take; ++i) {  // no data-dependent branch: a conditional increment
+        uint32_t y = src[i];
+        y ^= y >> 11;
+        y ^= (y << 7) & 0x9d2c5680u;
+        y ^= (y << 15) & 0xefc60000u;
+        y ^= y >> 18;
+        const uint32_t v = y & 63u;
+        out[n] = (uint8_t)kIdAlphabet[v];
+        n += v <= 35u;
+    }
+    return n;
+}
+
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+#define CRP_AVX512 __attribute__((target("avx512f,avx512bw,avx512vl,avx512vbmi,avx512vbmi2")))
+
+CRP_AVX512 inline __m512i mt_next16(__m512i cur, __m512i nxt, __m512i far)
+{
+    const __m512i y = _mm512_or_si512(_mm512_and_si512(cur, _mm512_set1_epi32((int)0x80000000u)), _mm512_and_si512(nxt, _mm512_set1_epi32(0x7fffffff)));
+    const __m512i mag = _mm512_and_si512(_mm512_sub_epi32(_mm512_setzero_si512(), _mm512_and_si512(y, _mm512_set1_epi32(1))),
+                                         _mm512_set1_epi32((int)0x9908b0dfu));
+    return _mm512_xor_si512(_mm512_xor_si512(far, _mm512_srli_epi32(y, 1)), mag);
+}
+
+// the same transition sixteen words at a time: word k needs the OLD words k, k + 1 and k + 397 (or the NEW word k - 227), and a
+// vector of sixteen never reaches a word its own store has touched
+CRP_AVX512 void mt_refill_avx512(uint32_t *mt)
+{
+    int k = 0;
+    for (; k + 16 <= kMtN - kMtM; k += 16)
+        _mm512_storeu_si512(mt + k, mt_next16(_mm512_loadu_si512(mt + k), _mm512_loadu_si512(mt + k + 1), _mm512_loadu_si512(mt + k + kMtM)));
+    for (; k < kMtN - kMtM; ++k) {
+        const uint32_t y = (mt[k] & 0x80000000u) | (mt[k + 1] & 0x7fffffffu);
+        mt[k] = mt[k + kMtM] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    }
+    for (; k + 16 <= kMtN - 1; k += 16)
+        _mm512_storeu_si512(mt + k, mt_next16(_mm512_loadu_si512(mt + k), _mm512_loadu_si512(mt + k + 1), _mm512_loadu_si512(mt + k + (kMtM - kMtN))));
+    for (; k < kMtN - 1; ++k) {
+        const uint32_t y = (mt[k] & 0x80000000u) | (mt[k + 1] & 0x7fffffffu);
+        mt[k] = mt[k + (kMtM - kMtN)] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    }
+    const uint32_t y = (mt[kMtN - 1] & 0x80000000u) | (mt[0] & 0x7fffffffu);
+    mt[kMtN - 1] = mt[kMtM - 1] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+}
+
+CRP_AVX512 inline __m128i mt_temper16_low6(__m512i y)
+{
+    y = _mm512_xor_si512(y, _mm512_srli_epi32(y, 11));
+    y = _mm512_xor_si512(y, _mm512_and_si512(_mm512_slli_epi32(y, 7), _mm512_set1_epi32((int)0x9d2c5680u)));
+    y = _mm512_xor_si512(y, _mm512_and_si512(_mm512_slli_epi32(y, 15), _mm512_set1_epi32((int)0xefc60000u)));
+    y = _mm512_xor_si512(y, _mm512_srli_epi32(y, 18));
+    return _mm512_cvtepi32_epi8(_mm512_and_si512(y, _mm512_set1_epi32(63)));
+}
+
+// cnt (1...64) outputs from src -> the kept characters, packed, to out (64 bytes are written whatever the count)
+CRP_AVX512 int mt_chars_avx512(const uint32_t *src, int cnt, uint8_t *out)
+{
+    __m128i part[4];
+    for (int g = 0; g < 4; ++g) {
+        const int lanes = cnt - 16 * g < 0 ? 0 : (cnt - 16 * g > 16 ? 16 : cnt - 16 * g);
+        part[g] = mt_temper16_low6(_mm512_maskz_loadu_epi32((__mmask16)((1u << lanes) - 1u), src + 16 * g));  // (masked lanes are not read)
+    }
+    __m512i v = _mm512_castsi128_si512(part[0]);
+    v = _mm512_inserti32x4(v, part[1], 1);
+    v = _mm512_inserti32x4(v, part[2], 2);
+    v = _mm512_inserti32x4(v, part[3], 3);
+    const __mmask64 valid = cnt >= 64 ? ~(__mmask64)0 : (((__mmask64)1 << cnt) - 1);
+    const __mmask64 keep = _mm512_cmple_epu8_mask(v, _mm512_set1_epi8(35)) & valid;
+    const __m512i chars = _mm512_permutexvar_epi8(v, _mm512_load_si512(kIdAlphabet));
+    _mm512_storeu_si512(out, _mm512_maskz_compress_epi8(keep, chars));
+    return (int)__builtin_popcountll((unsigned long long)keep);
+}
+
+// r rows of 7 characters (src, first to last) -> dst_end - 7 r ... dst_end, last row first
+CRP_AVX512 void rows_reversed_avx512(uint8_t *dst_end, const uint8_t *src, size_t r)
+{
+    alignas(64) uint8_t idx[64];
+    for (int j = 0; j < 64; ++j) idx[j] = (uint8_t)(j < 56 ? 7 * (7 - j / 7) + j % 7 : 0);
+    const __m512i perm = _mm512_load_si512(idx);
+    const __mmask64 m56 = (((__mmask64)1) << 56) - 1;
+    size_t i = 0;
+    for (; i + 8 <= r; i += 8)  // eight rows per step: rows i ... i + 7 land, reversed, right below what is already there
+        _mm512_mask_storeu_epi8(dst_end - 7 * (i + 8), m56, _mm512_permutexvar_epi8(perm, _mm512_maskz_loadu_epi8(m56, src + 7 * i)));
+    for (; i < r; ++i) std::memcpy(dst_end - 7 * (i + 1), src + 7 * i, 7);
+}
+
+bool ids_have_avx512()
+{
+    static const bool yes = [] {
+        if (const char *e = std::getenv("CRP_IDS_SCALAR"))
+            if (*e && *e != '0') return false;
+        __builtin_cpu_init();
+        return __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512vl") &&
+               __builtin_cpu_supports("avx512vbmi") && __builtin_cpu_supports("avx512vbmi2");
+    }();
+    return yes;
+}
+#else
+bool ids_have_avx512() { return false; }
+void mt_refill_avx512(uint32_t *) {}
+int mt_chars_avx512(const uint32_t *, int, uint8_t *) { return 0; }
+void rows_reversed_avx512(uint8_t *, const uint8_t *, size_t) {}
+#endif
+
+}  // namespace
+
 extern "C" int crp_legacy_ids(uint32_t *mt_key, int32_t *mt_pos, uint8_t *ids, uint64_t n_rows, int reverse)
 {
     if (!mt_key || !mt_pos || (n_rows && !ids) || *mt_pos < 0 || *mt_pos > 624) return CRP_ERR_INVALID;
-    static const char kAlphabet[65] = "ABCDEFGHIJKLMNOPQRSTUVWXYZ0123456789????????????????????????????";
-    constexpr int N = 624, M = 397;
+    const bool vec = ids_have_avx512();
     int pos = *mt_pos;
-    auto refill = [&]() {  // the standard MT19937 state transition
-        int k = 0;
-        for (; k < N - M; ++k) {
-            const uint32_t y = (mt_key[k] & 0x80000000u) | (mt_key[k + 1] & 0x7fffffffu);
-            mt_key[k] = mt_key[k + M] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
-        }
-        for (; k < N - 1; ++k) {
-            const uint32_t y = (mt_key[k] & 0x80000000u) | (mt_key[k + 1] & 0x7fffffffu);
-            mt_key[k] = mt_key[k + (M - N)] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
-        }
-        const uint32_t y = (mt_key[N - 1] & 0x80000000u) | (mt_key[0] & 0x7fffffffu);
-        mt_key[N - 1] = mt_key[M - 1] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
-        pos = 0;
-    };
-    // Batches without a data-dependent branch: temper up to one state block, keep the outputs that
-    // pass the rejection test by a conditional increment, then place the characters.  A batch never
-    // takes more outputs than characters are still missing, so the stream is left exactly where
-    // numpy would leave it (the output that yields the last character is the last one consumed).
+    // The characters come out in stream order and are staged a few thousand rows at a time (cache-resident), so that the
+    // last-first order costs no second pass over the whole array.  A step never takes more outputs than characters are still
+    // missing, so the stream is left exactly where numpy would leave it (the output that yields the last character is the last
+    // one consumed): 64 outputs give at most 64 characters, so the vector step runs while 64 or more are missing.
+    constexpr size_t kStageRows = 4096;
+    alignas(64) uint8_t stage[7 * kStageRows + kMtN + 64];
+    size_t fill = 0;
+    uint64_t rows_out = 0;
     const uint64_t need = 7 * n_rows;
     uint64_t produced = 0;
-    uint8_t stage[N + 8];
+    auto flush = [&]() {
+        const size_t r = fill / 7;
+        if (!r) return;
+        if (!reverse) std::memcpy(ids + 7 * rows_out, stage, 7 * r);
+        else if (vec) rows_reversed_avx512(ids + 7 * (n_rows - rows_out), stage, r);
+        else
+            for (size_t i = 0; i < r; ++i) std::memcpy(ids + 7 * (n_rows - 1 - rows_out - i), stage + 7 * i, 7);
+        rows_out += r;
+        std::memmove(stage, stage + 7 * r, fill - 7 * r);
+        fill -= 7 * r;
+    };
     while (produced < need) {
-        if (pos == N) refill();
+        if (pos == kMtN) {
+            if (vec) mt_refill_avx512(mt_key);
+            else mt_refill_scalar(mt_key);
+            pos = 0;
+        }
         const uint64_t missing = need - produced;
-        const int take = (uint64_t)(N - pos) < missing ? N - pos : (int)missing;
-        int n = 0;
-        for (int i = 0; i < take; ++i) {
-            uint32_t y = mt_key[pos + i];
-            y ^= y >> 11;
-            y ^= (y << 7) & 0x9d2c5680u;
-            y ^= (y << 15) & 0xefc60000u;
-            y ^= y >> 18;
-            const uint32_t v = y & 63u;
-            stage[n] = (uint8_t)kAlphabet[v & 63u];  // kAlphabet is padded to 64 entries below
-            n += v <= 35u;
+        int n, took;
+        if (vec && missing >= 64) {
+            took = kMtN - pos < 64 ? kMtN - pos : 64;
+            n = mt_chars_avx512(mt_key + pos, took, stage + fill);
+        } else {
+            took = (uint64_t)(kMtN - pos) < missing ? kMtN - pos : (int)missing;
+            n = mt_chars_scalar(mt_key + pos, took, stage + fill);
         }
-        pos += take;
-        std::memcpy(ids + produced, stage, (size_t)n);
+        pos += took;
+        fill += (size_t)n;
         produced += (uint64_t)n;
+        if (fill >= 7 * kStageRows) flush();
     }
-    if (reverse)  // rows were drawn first-to-last; hand them over last-first
-        for (uint64_t a = 0, b = n_rows; a + 1 < b; ++a) {
-            --b;
-            uint8_t t[7];
-            std::memcpy(t, ids + 7 * a, 7);
-            std::memcpy(ids + 7 * a, ids + 7 * b, 7);
-            std::memcpy(ids + 7 * b, t, 7);
-        }
+    flush();
     *mt_pos = pos;
     return CRP_OK;
 }

@@ -2,6 +2,7 @@
 module fed with the reference-style row tuples (rows.ContigRows, itself pinned by
 the golden CSVs).  CPU only: the formatter is host code."""
 import csv
+import os
 import io
 import struct
 
@@ -357,3 +358,45 @@ def test_each_contig_once_batched_passes_equal_single_passes(name, oracle, manif
         got[label] = (csv_bytes, text, (d / "time.txt").read_text().count("Total runtime"))
     assert got["single"][0].count(b"\r\n") > 20
     assert got["batched"] == got["single"] and got["small batches"] == got["single"]
+
+
+def test_id_draws_vector_and_portable_paths_agree():
+    """crp_legacy_ids picks AVX-512 code at run time where the CPU has it (VBMI2: the GPU boxes' EPYCs, this container's
+    Xeon); CRP_IDS_SCALAR=1 forces the portable loop.  Both continue numpy's stream identically: same characters for
+    forward and last-first order, same MT19937 state afterwards -- sizes around the 64-output step, the 624-word block and
+    the 4096-row staging buffer."""
+    import hashlib
+    import subprocess
+    import sys
+    code = r'''
+import hashlib, sys
+import numpy as np
+sys.path.insert(0, %r)
+from cropsr_amd import rows
+h = hashlib.sha256()
+for seed, warm, size in ((5, 0, 1), (6, 7, 9), (7, 100, 10), (8, 0, 89), (9, 623, 4095), (10, 1, 4096), (11, 2, 4097), (12, 0, 70001), (13, 55, 300000)):
+    for reverse in (False, True):
+        np.random.seed(seed)
+        np.random.random(warm)
+        h.update(rows.draw_ids(size, reverse=reverse).tobytes())
+        h.update(np.random.get_state()[1].tobytes())
+        h.update(str(np.random.get_state()[2]).encode())
+print(h.hexdigest())
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for label, value in (("auto", ""), ("portable", "1")):
+        env = dict(os.environ, CRP_IDS_SCALAR=value)
+        p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+        assert p.returncode == 0, p.stderr[-2000:]
+        out[label] = p.stdout.strip()
+    lut = np.frombuffer(b"ABCDEFGHIJKLMNOPQRSTUVWXYZ0123456789", dtype=np.uint8)
+    h = hashlib.sha256()
+    for seed, warm, size in ((5, 0, 1), (6, 7, 9), (7, 100, 10), (8, 0, 89), (9, 623, 4095), (10, 1, 4096), (11, 2, 4097), (12, 0, 70001), (13, 55, 300000)):
+        for reverse in (False, True):
+            np.random.seed(seed)
+            np.random.random(warm)
+            want = lut[np.random.randint(0, 36, size=[size, 7])]
+            h.update((want[::-1] if reverse else want).tobytes())
+            h.update(np.random.get_state()[1].tobytes())
+            h.update(str(np.random.get_state()[2]).encode())
+    assert out["auto"] == out["portable"] == h.hexdigest()
